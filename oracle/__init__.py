@@ -1,0 +1,24 @@
+"""CPU oracle for the CaDM CEM-planning / ensemble-training hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``cadm_amd/`` may import this
+package; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg use it, and only as the checker / reported baseline.
+
+PARITY UNPINNED: the reference (younggyoseo/CaDM, TensorFlow 1.15) cannot be
+imported in this image (tensorflow, gym, mujoco_py, baselines are absent) and
+ships no tests, golden vectors or fixtures for this path.
+The arithmetic itself lives in third-party TensorFlow 1.15.0 kernels
+(tf.matmul, tf.nn.softplus, tf.nn.top_k, tf.random.*, AdamOptimizer) whose
+published semantics are restated here; every function cites the reference
+call site (file:line under /root/reference) it follows.
+
+What pins the oracle instead (tests/test_oracle_*.py):
+  * a LITERAL transcription of the reference graph (tile / transpose / reshape
+    chain, including index quirks Q1/Q2) checked against an independent
+    INDEX-MAPPED formulation;
+  * fp64 evaluation as mathematical truth next to the fp32 evaluation;
+  * analytic known-answer cases (zero weights, sigma=0 stats, top-k ties, ...);
+  * torch.autograd (fp64) for the training-step gradients;
+  * the TF1 Adam closed form;
+  * Random123 known-answer vectors for Philox4x32-10.
+"""
