@@ -1,0 +1,126 @@
+"""ctypes binding of libcadm_hip.so (the C ABI declared in include/cadm_hip.h).
+
+The library is the product: there is NO Python / PyTorch fallback for any planner or
+training arithmetic.  If the shared object is missing or a call fails, this module
+raises -- loudly -- instead of computing anything on the host.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcadm_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+ABI_VERSION = 1
+MAX_HIDDEN_LAYERS = 8
+MAX_CP_LAYERS = 8
+
+ENV_KINDS = {"halfcheetah": 0, "cripple_halfcheetah": 0, "ant": 1, "slim_humanoid": 2,
+             "cartpole": 3, "pendulum": 4}
+NET_FF, NET_BACK, NET_CTX = 0, 1, 2
+
+
+class CadmError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("env_kind", C.c_int32), ("ensemble_size", C.c_int32),
+        ("n_particles", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32),
+        ("proc_obs_dim", C.c_int32), ("context_dim", C.c_int32), ("n_hidden", C.c_int32),
+        ("hidden", C.c_int32), ("horizon", C.c_int32), ("deterministic", C.c_int32),
+        ("discrete", C.c_int32), ("reference_quirks", C.c_int32), ("history_length", C.c_int32),
+        ("n_cp_hidden", C.c_int32), ("cp_hidden", C.c_int32 * MAX_CP_LAYERS),
+        ("num_elites", C.c_int32), ("num_cem_iters", C.c_int32), ("alpha", C.c_float),
+        ("lower_bound", C.c_float), ("upper_bound", C.c_float), ("back_model", C.c_int32),
+        ("reserved", C.c_int32 * 7),
+    ]
+
+
+class TrainHParams(C.Structure):
+    _fields_ = [
+        ("learning_rate", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("epsilon", C.c_float),
+        ("back_coeff", C.c_float), ("weight_decay_coeff", C.c_float),
+        ("weight_decays", C.c_float * (MAX_HIDDEN_LAYERS + 1)),
+        ("context_weight_decays", C.c_float * (MAX_CP_LAYERS + 1)),
+    ]
+
+
+_P = C.c_void_p
+_u32, _i = C.c_uint32, C.c_int
+
+# name -> (restype, argtypes); must list every symbol include/cadm_hip.h declares
+SIGNATURES = {
+    "cadm_last_error": (C.c_char_p, []),
+    "cadm_abi_version": (_i, []),
+    "cadm_ctx_create": (_i, [C.POINTER(Config), C.POINTER(_P)]),
+    "cadm_ctx_destroy": (_i, [_P]),
+    "cadm_set_weights": (_i, [_P, _i, _i, _P, _P]),
+    "cadm_set_logvar_bounds": (_i, [_P, _i, _P, _P]),
+    "cadm_repack": (_i, [_P, _P]),
+    "cadm_set_norm_stats": (_i, [_P, C.POINTER(_P), _P]),
+    "cadm_context_forward": (_i, [_P, _P, _P, _i, _i, _P, _P]),
+    "cadm_sample_actions": (_i, [_P, _P, _P, _P, _u32, _u32, _i, _i, _i, _P, _P]),
+    "cadm_sample_uniform": (_i, [_P, _u32, _u32, _i, _i, _P, _P, _P]),
+    "cadm_rollout_returns": (_i, [_P, _P, _P, _P, _P, _P, _i, _u32, _u32, _i, _i, _i, _i, _i, _P, _P, _P]),
+    "cadm_particle_mean": (_i, [_P, _P, _i, _i, _P, _P]),
+    "cadm_cem_refit": (_i, [_P, _P, _i, _i, _P, _i, _P, _P, _P, _P]),
+    "cadm_rs_select": (_i, [_P, _P, _i, _i, _P, _i, _P, _P, _P]),
+    "cadm_plan_workspace_bytes": (C.c_size_t, [_P, _i, _i]),
+    "cadm_cem_plan": (_i, [_P, _P, _P, _P, _P, _P, _i, _i, _u32, _u32, _P, _P, _P]),
+    "cadm_rs_plan": (_i, [_P, _P, _P, _P, _i, _i, _u32, _u32, _P, _P, _P, _P]),
+    "cadm_train_configure": (_i, [_P, C.POINTER(TrainHParams), _i]),
+    "cadm_train_step": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _P, _P]),
+    "cadm_train_reset": (_i, [_P, _P]),
+    "cadm_profile_enable": (_i, [_P, _i]),
+    "cadm_profile_read": (_i, [_P, C.POINTER(C.c_float), C.POINTER(_i)]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libcadm_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j", str(os.cpu_count() or 4)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+    if r.returncode != 0:
+        raise CadmError("building libcadm_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and type every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CadmError(
+            "libcadm_hip.so is not built (%s missing). Run `python -c \"import __graft_entry__ as g; "
+            "g.build()\"` or `make -C cadm_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cadm_abi_version() != ABI_VERSION:
+        raise CadmError("libcadm_hip.so ABI %d != binding ABI %d" % (lib.cadm_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().cadm_last_error()
+        raise CadmError("%s failed (code %d): %s" % (what or "libcadm_hip call", rc,
+                                                     msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,308 @@
+// extern "C" entry points of libcadm_hip.so (see include/cadm_hip.h for the contract).
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+int cadm_launch_clip(const float* in, float* out, int total, float lo, float hi, int do_clip, hipStream_t s);
+
+static thread_local char g_err[1024] = "";
+
+void cadm_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* cadm_last_error(void) { return g_err; }
+extern "C" int cadm_abi_version(void) { return CADM_ABI_VERSION; }
+
+static LayerGeo make_geo(int K, int ntiles, int head, int nout) {
+    LayerGeo g;
+    g.K = K;
+    g.nch = (K + 15) / 16;
+    g.ntiles = ntiles;
+    g.nfo = ntiles / 4;
+    g.nso = ntiles % 4;
+    g.head = head;
+    g.nout = nout;
+    return g;
+}
+
+extern "C" int cadm_ctx_create(const cadm_config* cfg, cadm_ctx** out) {
+    CADM_REQUIRE(cfg && out, "cadm_ctx_create: null argument");
+    CADM_REQUIRE(cfg->abi_version == CADM_ABI_VERSION, "cadm_ctx_create: ABI version %d != %d", cfg->abi_version,
+                 CADM_ABI_VERSION);
+    CADM_REQUIRE(cfg->env_kind >= 0 && cfg->env_kind <= CADM_ENV_PENDULUM, "cadm_ctx_create: unknown env kind %d",
+                 cfg->env_kind);
+    CADM_REQUIRE(cfg->obs_dim == env_D(cfg->env_kind) && cfg->act_dim == env_A(cfg->env_kind) &&
+                     cfg->proc_obs_dim == env_P(cfg->env_kind),
+                 "cadm_ctx_create: dims (D=%d,A=%d,P=%d) do not match env kind %d (D=%d,A=%d,P=%d)", cfg->obs_dim,
+                 cfg->act_dim, cfg->proc_obs_dim, cfg->env_kind, env_D(cfg->env_kind), env_A(cfg->env_kind),
+                 env_P(cfg->env_kind));
+    CADM_REQUIRE(cfg->ensemble_size >= 1 && cfg->n_particles >= 1 && cfg->n_particles % cfg->ensemble_size == 0,
+                 "cadm_ctx_create: n_particles (%d) must be a positive multiple of ensemble_size (%d)", cfg->n_particles,
+                 cfg->ensemble_size);
+    CADM_REQUIRE(cfg->n_hidden >= 2 && cfg->n_hidden <= CADM_MAX_HIDDEN_LAYERS,
+                 "cadm_ctx_create: n_hidden %d unsupported (2..%d)", cfg->n_hidden, CADM_MAX_HIDDEN_LAYERS);
+    CADM_REQUIRE(cfg->hidden >= 16, "cadm_ctx_create: hidden width %d too small", cfg->hidden);
+    CADM_REQUIRE(cfg->horizon >= 1, "cadm_ctx_create: horizon must be >= 1");
+    CADM_REQUIRE(cfg->context_dim >= 0, "cadm_ctx_create: negative context_dim");
+    CADM_REQUIRE(cfg->n_cp_hidden >= 0 && cfg->n_cp_hidden <= CADM_MAX_CP_LAYERS, "cadm_ctx_create: bad n_cp_hidden");
+    CADM_REQUIRE(cfg->num_elites >= 1 && cfg->num_cem_iters >= 1, "cadm_ctx_create: bad CEM constants");
+
+    cadm_ctx* c = new (std::nothrow) cadm_ctx();
+    if (!c) { cadm_set_error("cadm_ctx_create: out of host memory"); return CADM_ENOMEM; }
+    c->cfg = *cfg;
+    CADM_CHECK_HIP(hipGetDevice(&c->device));
+    c->D = cfg->obs_dim; c->A = cfg->act_dim; c->P = cfg->proc_obs_dim; c->C = cfg->context_dim;
+    c->E = cfg->ensemble_size; c->p = cfg->n_particles; c->H = cfg->horizon; c->HID = cfg->hidden;
+    c->NH = cfg->n_hidden; c->K0 = c->P + c->A + c->C;
+    c->ff.resize(c->NH + 2);
+    c->back.resize(c->NH + 2);
+    c->cp.resize(cfg->n_cp_hidden + 1);
+    const int NT = (c->HID + 15) / 16;
+    c->g0 = make_geo(c->K0, NT, 0, c->HID);
+    c->gh = make_geo(c->HID, NT, 0, c->HID);
+    c->go = make_geo(c->HID, (c->D + 7) / 8, 1, c->D);
+    c->wstream_member_floats = c->g0.layer_floats() + (size_t)(c->NH - 1) * c->gh.layer_floats() + c->go.layer_floats();
+    c->bstream_member_floats = c->g0.bias_floats() + (size_t)(c->NH - 1) * c->gh.bias_floats() + c->go.bias_floats();
+    hipError_t e1 = hipMalloc(&c->wstream, c->wstream_member_floats * c->E * sizeof(float));
+    hipError_t e2 = hipMalloc(&c->bstream, c->bstream_member_floats * c->E * sizeof(float));
+    const size_t nst = 2 * (size_t)c->P + 2 * c->A + 4 * (size_t)c->D + 2 * (size_t)(c->D + c->A) * cfg->history_length;
+    hipError_t e3 = hipMalloc(&c->st.buf, nst * sizeof(float));
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        cadm_set_error("cadm_ctx_create: hipMalloc failed (%s)", hipGetErrorString(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3));
+        cadm_ctx_destroy(c);
+        return CADM_ENOMEM;
+    }
+    float* q = c->st.buf;
+    const int Hh = cfg->history_length;
+    c->st.obs_mean = q; q += c->P;  c->st.obs_std = q; q += c->P;
+    c->st.act_mean = q; q += c->A;  c->st.act_std = q; q += c->A;
+    c->st.delta_mean = q; q += c->D; c->st.delta_std = q; q += c->D;
+    c->st.cp_obs_mean = q; q += c->D * Hh; c->st.cp_obs_std = q; q += c->D * Hh;
+    c->st.cp_act_mean = q; q += c->A * Hh; c->st.cp_act_std = q; q += c->A * Hh;
+    c->st.back_delta_mean = q; q += c->D; c->st.back_delta_std = q; q += c->D;
+    *out = c;
+    return CADM_OK;
+}
+
+extern "C" int cadm_ctx_destroy(cadm_ctx* ctx) {
+    if (!ctx) return CADM_OK;
+    cadm_train_free(ctx);
+    if (ctx->wstream) (void)hipFree(ctx->wstream);
+    if (ctx->bstream) (void)hipFree(ctx->bstream);
+    if (ctx->st.buf) (void)hipFree(ctx->st.buf);
+    if (ctx->cp_scratch) (void)hipFree(ctx->cp_scratch);
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    delete ctx;
+    return CADM_OK;
+}
+
+extern "C" int cadm_set_weights(cadm_ctx* ctx, int net, int layer, float* W, float* b) {
+    CADM_REQUIRE(ctx && W && b, "cadm_set_weights: null argument");
+    std::vector<DenseRef>* v = net == CADM_NET_FF ? &ctx->ff : net == CADM_NET_BACK ? &ctx->back : net == CADM_NET_CTX ? &ctx->cp : nullptr;
+    CADM_REQUIRE(v, "cadm_set_weights: unknown net %d", net);
+    CADM_REQUIRE(layer >= 0 && layer < (int)v->size(), "cadm_set_weights: layer %d out of range for net %d", layer, net);
+    DenseRef& d = (*v)[layer];
+    d.W = W; d.b = b;
+    if (net == CADM_NET_CTX) {
+        const int ncp = ctx->cfg.n_cp_hidden;
+        d.din = layer == 0 ? (ctx->D + ctx->A) * ctx->cfg.history_length : ctx->cfg.cp_hidden[layer - 1];
+        d.dout = layer < ncp ? ctx->cfg.cp_hidden[layer] : ctx->C;
+    } else {
+        d.din = layer == 0 ? ctx->K0 : ctx->HID;
+        d.dout = layer < ctx->NH ? ctx->HID : ctx->D;
+        if (net == CADM_NET_FF) ctx->packed = false;
+    }
+    return CADM_OK;
+}
+
+extern "C" int cadm_set_logvar_bounds(cadm_ctx* ctx, int net, float* max_logvar, float* min_logvar) {
+    CADM_REQUIRE(ctx && max_logvar && min_logvar, "cadm_set_logvar_bounds: null argument");
+    if (net == CADM_NET_FF) { ctx->ff_maxlv = max_logvar; ctx->ff_minlv = min_logvar; }
+    else if (net == CADM_NET_BACK) { ctx->back_maxlv = max_logvar; ctx->back_minlv = min_logvar; }
+    else { cadm_set_error("cadm_set_logvar_bounds: net %d has no logvar bounds", net); return CADM_EINVAL; }
+    return CADM_OK;
+}
+
+extern "C" int cadm_repack(cadm_ctx* ctx, void* stream) {
+    CADM_REQUIRE(ctx, "cadm_repack: null ctx");
+    return cadm_pack_streams(ctx, (hipStream_t)stream);
+}
+
+extern "C" int cadm_set_norm_stats(cadm_ctx* ctx, const float* const host_stats[12], void* stream) {
+    CADM_REQUIRE(ctx && host_stats, "cadm_set_norm_stats: null argument");
+    const int Hh = ctx->cfg.history_length;
+    float* dst[12] = {ctx->st.obs_mean, ctx->st.obs_std, ctx->st.act_mean, ctx->st.act_std, ctx->st.delta_mean,
+                      ctx->st.delta_std, ctx->st.cp_obs_mean, ctx->st.cp_obs_std, ctx->st.cp_act_mean,
+                      ctx->st.cp_act_std, ctx->st.back_delta_mean, ctx->st.back_delta_std};
+    const int len[12] = {ctx->P, ctx->P, ctx->A, ctx->A, ctx->D, ctx->D, ctx->D * Hh, ctx->D * Hh,
+                         ctx->A * Hh, ctx->A * Hh, ctx->D, ctx->D};
+    for (int i = 0; i < 12; ++i) {
+        CADM_REQUIRE(host_stats[i], "cadm_set_norm_stats: stat vector %d is null", i);
+        // synchronous copy from pageable host memory: the caller's numpy buffers may die right after this call
+        CADM_CHECK_HIP(hipMemcpy(dst[i], host_stats[i], (size_t)len[i] * sizeof(float), hipMemcpyHostToDevice));
+    }
+    (void)stream;
+    ctx->st.set = true;
+    return CADM_OK;
+}
+
+static int require_ready(cadm_ctx* ctx, const char* who) {
+    if (!ctx->st.set) { cadm_set_error("%s: normalisation stats not set (call cadm_set_norm_stats)", who); return CADM_ESTATE; }
+    if (!ctx->ff_maxlv || !ctx->ff_minlv) { cadm_set_error("%s: logvar bounds not set", who); return CADM_ESTATE; }
+    return CADM_OK;
+}
+
+extern "C" int cadm_context_forward(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs,
+                                    float* ctx_out, void* stream) {
+    CADM_REQUIRE(ctx && cp_obs && cp_act && ctx_out && m > 0, "cadm_context_forward: bad arguments");
+    CADM_REQUIRE(ctx->C > 0, "cadm_context_forward: model has no context encoder");
+    if (!ctx->st.set) { cadm_set_error("cadm_context_forward: normalisation stats not set"); return CADM_ESTATE; }
+    return cadm_launch_context(ctx, cp_obs, cp_act, m, bs, ctx_out, (hipStream_t)stream);
+}
+
+extern "C" int cadm_rollout_returns(cadm_ctx* ctx, const float* obs, const float* obs_rows, const float* ctx_vec,
+                                    const float* actions, const float* eps, int norm_actions, uint32_t seed,
+                                    uint32_t call, int it, int cand_offset, int n_global, int m, int n_local,
+                                    float* returns_rows, float* traj_out, void* stream) {
+    CADM_REQUIRE(ctx && obs && actions && returns_rows, "cadm_rollout_returns: null argument");
+    CADM_REQUIRE(m > 0 && n_local > 0 && cand_offset >= 0 && cand_offset + n_local <= n_global,
+                 "cadm_rollout_returns: bad candidate range [%d, %d) of %d", cand_offset, cand_offset + n_local, n_global);
+    CADM_REQUIRE(ctx->C == 0 || ctx_vec, "cadm_rollout_returns: ctx_vec required for a context model");
+    int rc = require_ready(ctx, "cadm_rollout_returns");
+    if (rc) return rc;
+    if (!ctx->packed) {
+        rc = cadm_pack_streams(ctx, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->prof) {
+        if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
+            hipEvent_t a, b;
+            CADM_CHECK_HIP(hipEventCreate(&a));
+            CADM_CHECK_HIP(hipEventCreate(&b));
+            ctx->prof_ev.push_back(a);
+            ctx->prof_ev.push_back(b);
+        }
+        e0 = ctx->prof_ev[ctx->prof_used];
+        e1 = ctx->prof_ev[ctx->prof_used + 1];
+        ctx->prof_used += 2;
+        CADM_CHECK_HIP(hipEventRecord(e0, (hipStream_t)stream));
+    }
+    rc = cadm_launch_rollout(ctx, obs, obs_rows, ctx_vec, actions, eps, norm_actions, seed, call, it, cand_offset,
+                             n_global, m, n_local, returns_rows, traj_out, (hipStream_t)stream);
+    if (ctx->prof && rc == CADM_OK) CADM_CHECK_HIP(hipEventRecord(e1, (hipStream_t)stream));
+    return rc;
+}
+
+extern "C" int cadm_profile_enable(cadm_ctx* ctx, int enable) {
+    CADM_REQUIRE(ctx, "cadm_profile_enable: null ctx");
+    ctx->prof = enable != 0;
+    ctx->prof_used = 0;
+    return CADM_OK;
+}
+
+extern "C" int cadm_profile_read(cadm_ctx* ctx, float* total_ms_out, int* launches_out) {
+    CADM_REQUIRE(ctx && total_ms_out && launches_out, "cadm_profile_read: null argument");
+    float tot = 0.0f;
+    for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
+        CADM_CHECK_HIP(hipEventSynchronize(ctx->prof_ev[i + 1]));
+        float ms = 0.0f;
+        CADM_CHECK_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
+        tot += ms;
+    }
+    *total_ms_out = tot;
+    *launches_out = (int)(ctx->prof_used / 2);
+    ctx->prof_used = 0;
+    return CADM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused single-GPU planners
+// ---------------------------------------------------------------------------------------------
+struct PlanWs {
+    float *ctxv, *actions, *rows, *cand, *mean, *var;
+    int32_t* raw;
+};
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t carve(cadm_ctx* ctx, int m, int n, char* base, PlanWs* w) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align_up(bytes); return p; };
+    float* ctxv = (float*)take((size_t)ctx->E * m * (ctx->C > 0 ? ctx->C : 1) * 4);
+    float* actions = (float*)take((size_t)m * n * ctx->H * ctx->A * 4);
+    float* rows = (float*)take((size_t)m * n * ctx->p * 4);
+    float* cand = (float*)take((size_t)m * n * 4);
+    float* mean = (float*)take((size_t)m * ctx->H * ctx->A * 4);
+    float* var = (float*)take((size_t)m * ctx->H * ctx->A * 4);
+    int32_t* raw = (int32_t*)take((size_t)m * n * ctx->H * 4);
+    if (w) { w->ctxv = ctxv; w->actions = actions; w->rows = rows; w->cand = cand; w->mean = mean; w->var = var; w->raw = raw; }
+    return off;
+}
+
+extern "C" size_t cadm_plan_workspace_bytes(cadm_ctx* ctx, int m, int n) {
+    if (!ctx || m <= 0 || n <= 0) return 0;
+    return carve(ctx, m, n, nullptr, nullptr);
+}
+
+extern "C" int cadm_cem_plan(cadm_ctx* ctx, const float* obs, const float* cp_obs, const float* cp_act,
+                             const float* init_mean, const float* init_var, int m, int n, uint32_t seed,
+                             uint32_t call, void* workspace, float* plan_out, void* stream) {
+    CADM_REQUIRE(ctx && obs && init_mean && init_var && workspace && plan_out && m > 0 && n > 0,
+                 "cadm_cem_plan: bad arguments");
+    CADM_REQUIRE(ctx->C == 0 || (cp_obs && cp_act), "cadm_cem_plan: cp_obs/cp_act required for a context model");
+    hipStream_t s = (hipStream_t)stream;
+    PlanWs w;
+    carve(ctx, m, n, (char*)workspace, &w);
+    int rc;
+    if (ctx->C > 0 && (rc = cadm_context_forward(ctx, cp_obs, cp_act, m, 0, w.ctxv, stream))) return rc;
+    const size_t mv = (size_t)m * ctx->H * ctx->A * sizeof(float);
+    CADM_CHECK_HIP(hipMemcpyAsync(w.mean, init_mean, mv, hipMemcpyDeviceToDevice, s));
+    CADM_CHECK_HIP(hipMemcpyAsync(w.var, init_var, mv, hipMemcpyDeviceToDevice, s));
+    for (int it = 0; it < ctx->cfg.num_cem_iters; ++it) {
+        if ((rc = cadm_sample_actions(ctx, w.mean, w.var, nullptr, seed, call, it, m, n, w.actions, stream))) return rc;
+        if ((rc = cadm_rollout_returns(ctx, obs, nullptr, ctx->C > 0 ? w.ctxv : nullptr, w.actions, nullptr, 1, seed,
+                                       call, it, 0, n, m, n, w.rows, nullptr, stream))) return rc;
+        if ((rc = cadm_particle_mean(ctx, w.rows, m, n, w.cand, stream))) return rc;
+        if ((rc = cadm_cem_refit(ctx, w.cand, 1, n, w.actions, m, w.mean, w.var, nullptr, stream))) return rc;
+    }
+    return cadm_launch_clip(w.mean, plan_out, m * ctx->H * ctx->A, ctx->cfg.lower_bound, ctx->cfg.upper_bound,
+                            !ctx->cfg.discrete, s);
+}
+
+__global__ void gather_raw_first_kernel(const int32_t* raw, const int32_t* best, int m, int n, int H, int32_t* out) {
+    const int mi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mi < m) out[mi] = raw[((size_t)mi * n + best[mi]) * H];
+}
+
+extern "C" int cadm_rs_plan(cadm_ctx* ctx, const float* obs, const float* cp_obs, const float* cp_act, int m, int n,
+                            uint32_t seed, uint32_t call, void* workspace, float* action_out, int32_t* raw_best_out,
+                            void* stream) {
+    CADM_REQUIRE(ctx && obs && workspace && action_out && m > 0 && n > 0, "cadm_rs_plan: bad arguments");
+    CADM_REQUIRE(ctx->C == 0 || (cp_obs && cp_act), "cadm_rs_plan: cp_obs/cp_act required for a context model");
+    CADM_REQUIRE(!ctx->cfg.discrete || raw_best_out, "cadm_rs_plan: raw_best_out required for discrete actions");
+    hipStream_t s = (hipStream_t)stream;
+    PlanWs w;
+    carve(ctx, m, n, (char*)workspace, &w);
+    int rc;
+    if (ctx->C > 0 && (rc = cadm_context_forward(ctx, cp_obs, cp_act, m, 0, w.ctxv, stream))) return rc;
+    if ((rc = cadm_sample_uniform(ctx, seed, call, m, n, w.actions, w.raw, stream))) return rc;
+    // it = 0: the RS graph transposes the context tensor once (core/utils.py:513) -> the even-iteration layout
+    if ((rc = cadm_rollout_returns(ctx, obs, nullptr, ctx->C > 0 ? w.ctxv : nullptr, w.actions, nullptr,
+                                   ctx->cfg.discrete ? 0 : 1, seed, call, 0, 0, n, m, n, w.rows, nullptr, stream))) return rc;
+    if ((rc = cadm_particle_mean(ctx, w.rows, m, n, w.cand, stream))) return rc;
+    int32_t* best = (int32_t*)w.mean;  // scratch reuse: m ints
+    if ((rc = cadm_rs_select(ctx, w.cand, 1, n, w.actions, m, action_out, best, stream))) return rc;
+    if (ctx->cfg.discrete) {
+        hipLaunchKernelGGL(gather_raw_first_kernel, dim3((m + 63) / 64), dim3(64), 0, s, w.raw, best, m, n, ctx->H, raw_best_out);
+        CADM_CHECK_HIP(hipGetLastError());
+    } else {
+        if ((rc = cadm_launch_clip(action_out, action_out, m * ctx->A, ctx->cfg.lower_bound, ctx->cfg.upper_bound, 1, s))) return rc;
+    }
+    return CADM_OK;
+}

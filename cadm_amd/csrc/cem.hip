@@ -1,0 +1,254 @@
+// CEM / random-shooting bookkeeping kernels: action sampling (core/utils.py:425-429, 498-503),
+// particle mean (:474), elite refit (:475-486), RS argmax (:554-561), final clip (dynamics.py:365-366).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// action sampling
+// ---------------------------------------------------------------------------------------------
+__global__ void sample_actions_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                                      const float* __restrict__ z, uint32_t seed, uint32_t call, int it,
+                                      int m, int n, int H, int A, float lb, float ub,
+                                      float* __restrict__ out) {
+    const size_t total = (size_t)m * n * H * A;
+    const int HA = H * A;
+    for (size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x; L < total; L += (size_t)gridDim.x * blockDim.x) {
+        const int ta = (int)(L % HA);
+        const int mi = (int)(L / ((size_t)n * HA));
+        const float mu = mean[(size_t)mi * HA + ta];
+        const float lbd = mu - lb, ubd = ub - mu;                                  // :425
+        const float a1 = lbd / 2.0f, a2 = ubd / 2.0f;
+        const float cv = fminf(fminf(a1 * a1, a2 * a2), var[(size_t)mi * HA + ta]);  // :426
+        float zz;
+        if (z) {
+            zz = z[L];
+        } else {
+            // TF TruncatedNormalDistribution: reject |x| >= 2 (kTruncateValue)
+            zz = 0.0f;
+            for (uint32_t attempt = 0; attempt < 64; ++attempt) {
+                uint32_t r[4];
+                philox4x32_10((uint32_t)(L & 0xFFFFFFFFull), attempt, (uint32_t)(L >> 32),
+                              CADM_STREAM_ACT | ((uint32_t)it << 8), seed, call, r);
+                float c0, c1, c2, c3;
+                box_muller(u01(r[0]), u01(r[1]), c0, c1);
+                box_muller(u01(r[2]), u01(r[3]), c2, c3);
+                if (fabsf(c0) < 2.0f) { zz = c0; break; }
+                if (fabsf(c1) < 2.0f) { zz = c1; break; }
+                if (fabsf(c2) < 2.0f) { zz = c2; break; }
+                if (fabsf(c3) < 2.0f) { zz = c3; break; }
+            }
+        }
+        out[L] = mu + sqrtf(cv) * zz;                                              // :429
+    }
+}
+
+__global__ void sample_uniform_kernel(uint32_t seed, uint32_t call, int m, int n, int H, int A, int discrete,
+                                      float* __restrict__ out, int32_t* __restrict__ raw) {
+    if (!discrete) {
+        const size_t total = (size_t)m * n * H * A;
+        for (size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x; L < total; L += (size_t)gridDim.x * blockDim.x) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)(L & 0xFFFFFFFFull), 0u, (uint32_t)(L >> 32), CADM_STREAM_UNI, seed, call, r);
+            out[L] = 2.0f * u01(r[0]) - 1.0f;                                      // :502
+        }
+    } else {
+        const size_t total = (size_t)m * n * H;
+        for (size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x; L < total; L += (size_t)gridDim.x * blockDim.x) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)(L & 0xFFFFFFFFull), 0u, (uint32_t)(L >> 32), CADM_STREAM_UNI, seed, call, r);
+            int k = (int)(u01(r[0]) * (float)A);                                   // :499
+            if (k >= A) k = A - 1;
+            for (int a = 0; a < A; ++a) out[L * A + a] = (a == k) ? 1.0f : 0.0f;   // :500 one_hot
+            if (raw) raw[L] = k;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// particle mean (:474)
+// ---------------------------------------------------------------------------------------------
+__global__ void particle_mean_kernel(const float* __restrict__ rows, int total, int p, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float s = 0.0f;
+    for (int j = 0; j < p; ++j) s += rows[(size_t)i * p + j];
+    out[i] = s / (float)p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// elite refit: bitonic sort of (return desc, index asc) keys in LDS, then statistics
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t make_key(float v, uint32_t idx) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-orderable
+    return ((uint64_t)(~u) << 32) | idx;               // ascending key == descending value, ties -> lower idx
+}
+
+__device__ __forceinline__ float cand_at(const float* cand, int G, int n_local, int m, int mi, int ni) {
+    return cand[((size_t)(ni / n_local) * m + mi) * n_local + (ni % n_local)];
+}
+
+__device__ void bitonic_sort_lds(uint64_t* keys, int npow2) {
+    for (int k = 2; k <= npow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void cem_refit_kernel(const float* __restrict__ cand, int G, int n_local, const float* __restrict__ actions,
+                                 int m, int H, int A, int K, float alpha, int npow2, float* __restrict__ mean_io,
+                                 float* __restrict__ var_io, int32_t* __restrict__ elites_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);
+    const int mi = blockIdx.x;
+    const int n = G * n_local;
+    for (int i = threadIdx.x; i < npow2; i += blockDim.x)
+        keys[i] = i < n ? make_key(cand_at(cand, G, n_local, m, mi, i), (uint32_t)i) : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds(keys, npow2);                                                 // tf.nn.top_k, :475
+    if (elites_out)
+        for (int k = threadIdx.x; k < K; k += blockDim.x) elites_out[(size_t)mi * K + k] = (int32_t)(keys[k] & 0xFFFFFFFFu);
+    const int HA = H * A;
+    const float* act_m = actions + (size_t)mi * n * HA;
+    for (int ta = threadIdx.x; ta < HA; ta += blockDim.x) {
+        float s = 0.0f;
+        for (int k = 0; k < K; ++k) s += act_m[(size_t)(keys[k] & 0xFFFFFFFFu) * HA + ta];
+        const float nm = s / (float)K;                                             // :482
+        float v = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const float d = act_m[(size_t)(keys[k] & 0xFFFFFFFFu) * HA + ta] - nm;
+            v += d * d;
+        }
+        const float nv = v / (float)K;                                             // :483
+        const size_t o = (size_t)mi * HA + ta;
+        mean_io[o] = mean_io[o] * alpha + (1.0f - alpha) * nm;                     // :485
+        var_io[o] = var_io[o] * alpha + (1.0f - alpha) * nv;                       // :486
+    }
+}
+
+// RS: first maximum over candidates (tf.argmax), gather the first action (:555-561)
+__global__ void rs_select_kernel(const float* __restrict__ cand, int G, int n_local, const float* __restrict__ actions,
+                                 int m, int H, int A, float* __restrict__ out, int32_t* __restrict__ best_out) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int mi = blockIdx.x;
+    const int n = G * n_local;
+    float bv = -INFINITY;
+    int bi = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = cand_at(cand, G, n_local, m, mi, i);
+        if (v > bv || (v == bv && i < bi) || bi == 0x7FFFFFFF) { bv = v; bi = i; }
+    }
+    sv[threadIdx.x] = bv;
+    si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const float ov = sv[threadIdx.x + s];
+            const int oi = si[threadIdx.x + s];
+            if (oi != 0x7FFFFFFF && (si[threadIdx.x] == 0x7FFFFFFF || ov > sv[threadIdx.x] ||
+                                     (ov == sv[threadIdx.x] && oi < si[threadIdx.x]))) {
+                sv[threadIdx.x] = ov;
+                si[threadIdx.x] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const int best = si[0];
+    if (threadIdx.x == 0 && best_out) best_out[mi] = best;
+    for (int a = threadIdx.x; a < A; a += blockDim.x)
+        out[(size_t)mi * A + a] = actions[((size_t)mi * n + best) * H * A + a];
+}
+
+__global__ void clip_kernel(const float* __restrict__ in, float* __restrict__ out, int total, float lo, float hi, int do_clip) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float v = in[i];
+    out[i] = do_clip ? fminf(fmaxf(v, lo), hi) : v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+static int grid_for(size_t total) {
+    size_t g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+extern "C" int cadm_sample_actions(cadm_ctx* ctx, const float* mean, const float* var, const float* z,
+                                   uint32_t seed, uint32_t call, int it, int m, int n_global,
+                                   float* actions_out, void* stream) {
+    CADM_REQUIRE(ctx && mean && var && actions_out && m > 0 && n_global > 0, "cadm_sample_actions: bad arguments");
+    const size_t total = (size_t)m * n_global * ctx->H * ctx->A;
+    hipLaunchKernelGGL(sample_actions_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, mean, var, z,
+                       seed, call, it, m, n_global, ctx->H, ctx->A, ctx->cfg.lower_bound, ctx->cfg.upper_bound, actions_out);
+    CADM_CHECK_HIP(hipGetLastError());
+    return CADM_OK;
+}
+
+extern "C" int cadm_sample_uniform(cadm_ctx* ctx, uint32_t seed, uint32_t call, int m, int n_global,
+                                   float* actions_out, int32_t* raw_out, void* stream) {
+    CADM_REQUIRE(ctx && actions_out && m > 0 && n_global > 0, "cadm_sample_uniform: bad arguments");
+    const size_t total = (size_t)m * n_global * ctx->H * (ctx->cfg.discrete ? 1 : ctx->A);
+    hipLaunchKernelGGL(sample_uniform_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, seed, call, m,
+                       n_global, ctx->H, ctx->A, ctx->cfg.discrete, actions_out, raw_out);
+    CADM_CHECK_HIP(hipGetLastError());
+    return CADM_OK;
+}
+
+extern "C" int cadm_particle_mean(cadm_ctx* ctx, const float* returns_rows, int m, int n_local,
+                                  float* cand_returns, void* stream) {
+    CADM_REQUIRE(ctx && returns_rows && cand_returns && m > 0 && n_local > 0, "cadm_particle_mean: bad arguments");
+    const int total = m * n_local;
+    hipLaunchKernelGGL(particle_mean_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, returns_rows,
+                       total, ctx->p, cand_returns);
+    CADM_CHECK_HIP(hipGetLastError());
+    return CADM_OK;
+}
+
+extern "C" int cadm_cem_refit(cadm_ctx* ctx, const float* cand_returns, int G, int n_local, const float* actions,
+                              int m, float* mean_io, float* var_io, int32_t* elites_out, void* stream) {
+    CADM_REQUIRE(ctx && cand_returns && actions && mean_io && var_io && G > 0 && n_local > 0 && m > 0,
+                 "cadm_cem_refit: bad arguments");
+    const int n = G * n_local;
+    CADM_REQUIRE(n >= ctx->cfg.num_elites, "cadm_cem_refit: n_candidates %d < num_elites %d (tf.nn.top_k would fail)",
+                 n, ctx->cfg.num_elites);
+    int npow2 = 1;
+    while (npow2 < n) npow2 <<= 1;
+    const size_t lds = (size_t)npow2 * sizeof(uint64_t);
+    CADM_REQUIRE(lds <= 128 * 1024, "cadm_cem_refit: n_candidates %d exceeds the in-LDS sort capacity (16384)", n);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cem_refit_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cem_refit_kernel, dim3(m), dim3(1024), lds, (hipStream_t)stream, cand_returns, G, n_local, actions,
+                       m, ctx->H, ctx->A, ctx->cfg.num_elites, ctx->cfg.alpha, npow2, mean_io, var_io, elites_out);
+    CADM_CHECK_HIP(hipGetLastError());
+    return CADM_OK;
+}
+
+extern "C" int cadm_rs_select(cadm_ctx* ctx, const float* cand_returns, int G, int n_local, const float* actions,
+                              int m, float* first_action_out, int32_t* best_out, void* stream) {
+    CADM_REQUIRE(ctx && cand_returns && actions && first_action_out && G > 0 && n_local > 0 && m > 0,
+                 "cadm_rs_select: bad arguments");
+    hipLaunchKernelGGL(rs_select_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, cand_returns, G, n_local, actions,
+                       m, ctx->H, ctx->A, first_action_out, best_out);
+    CADM_CHECK_HIP(hipGetLastError());
+    return CADM_OK;
+}
+
+int cadm_launch_clip(const float* in, float* out, int total, float lo, float hi, int do_clip, hipStream_t s) {
+    hipLaunchKernelGGL(clip_kernel, dim3((total + 255) / 256), dim3(256), 0, s, in, out, total, lo, hi, do_clip);
+    CADM_CHECK_HIP(hipGetLastError());
+    return CADM_OK;
+}

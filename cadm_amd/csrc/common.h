@@ -1,0 +1,162 @@
+// Shared host/device definitions for libcadm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/cadm_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (no exceptions cross the C ABI)
+// ---------------------------------------------------------------------------------------------
+void cadm_set_error(const char* fmt, ...);
+
+#define CADM_CHECK_HIP(expr)                                                                   \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            cadm_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return CADM_EHIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+#define CADM_REQUIRE(cond, ...)        \
+    do {                               \
+        if (!(cond)) {                 \
+            cadm_set_error(__VA_ARGS__); \
+            return CADM_EINVAL;        \
+        }                              \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// env tables
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int env_D(int k) { return k == 0 ? 18 : k == 1 ? 28 : k == 2 ? 45 : k == 3 ? 4 : 3; }
+__host__ __device__ constexpr int env_A(int k) { return k == 0 ? 6 : k == 1 ? 8 : k == 2 ? 17 : k == 3 ? 2 : 1; }
+__host__ __device__ constexpr int env_P(int k) { return k == 0 ? 18 : k == 1 ? 27 : k == 2 ? 45 : k == 3 ? 4 : 3; }
+
+// RNG stream tags (oracle/philox.py)
+#define CADM_STREAM_EPS 1u
+#define CADM_STREAM_ACT 2u
+#define CADM_STREAM_UNI 3u
+
+// ---------------------------------------------------------------------------------------------
+// planner weight-stream geometry (see DESIGN.md "weight streams")
+//   A dense layer with K inputs and a set of 16-wide output tiles is evaluated as
+//   OUT^T[unit][row] = sum_k W^T[unit][k] * IN^T[k][row] with v_mfma_f32_16x16x4_f32:
+//   the weights are the A operand, 16 data rows are the B/D columns.  K is consumed in
+//   "chunks" of 4 k-steps (16 input features).  A workgroup has 4 waves; wave w owns
+//   NFO = ntiles/4 "full" output tiles (tiles w*NFO .. w*NFO+NFO-1) over all of K, and every one of
+//   the NSO = ntiles%4 "split" tiles (tiles 4*NFO ..) for k-step r == w of every chunk.
+//   Per (member, layer, wave) the stream is: for each chunk: NFO blocks of float4[64 lanes]
+//   followed by NSO blocks of float[64 lanes], in exactly the order the wave consumes them.
+// ---------------------------------------------------------------------------------------------
+struct LayerGeo {
+    int K;        // input features
+    int nch;      // chunks = ceil(K/16)
+    int ntiles;   // output tiles
+    int nfo, nso; // full tiles per wave / split tiles
+    int head;     // 0: hidden-type outputs (HID units), 1: (mu,logvar) head tiles of 8 dims
+    int nout;     // HID or D
+    size_t slot_floats() const { return (size_t)(nfo * 4 + nso) * 64; }
+    size_t wave_floats() const { return slot_floats() * nch; }
+    size_t layer_floats() const { return wave_floats() * 4; }
+    size_t bias_floats() const { return (size_t)ntiles * 256; }
+};
+
+struct DenseRef {  // registered master weights (caller-owned device memory)
+    float* W = nullptr;
+    float* b = nullptr;
+    int din = 0, dout = 0;
+};
+
+struct NormStats {  // device copies of the 12 stat vectors + derived
+    float* buf = nullptr;  // one allocation
+    float *obs_mean, *obs_std, *act_mean, *act_std, *delta_mean, *delta_std;
+    float *cp_obs_mean, *cp_obs_std, *cp_act_mean, *cp_act_std, *back_delta_mean, *back_delta_std;
+    bool set = false;
+};
+
+struct TrainState;  // train.hip
+
+struct cadm_ctx {
+    cadm_config cfg;
+    int device = 0;
+    int D, A, P, C, E, p, H, HID, NH, K0;
+    // master weights
+    std::vector<DenseRef> ff, back, cp;   // ff/back: NH hidden + mu + logvar; cp: n_cp_hidden + out
+    float *ff_maxlv = nullptr, *ff_minlv = nullptr, *back_maxlv = nullptr, *back_minlv = nullptr;
+    // planner streams (ff net only)
+    LayerGeo g0, gh, go;
+    float* wstream = nullptr;    // [E][ L0 | hidden x (NH-1) | OUT ] layer streams
+    float* bstream = nullptr;    // [E][ L0 | hidden x (NH-1) | OUT ] D-layout bias tiles
+    size_t wstream_member_floats = 0, bstream_member_floats = 0;
+    bool packed = false;
+    NormStats st;
+    TrainState* train = nullptr;
+    // scratch for the context encoder
+    float* cp_scratch = nullptr;
+    size_t cp_scratch_floats = 0;
+    // optional hipEvent bracketing of the rollout launches (cadm_profile_*)
+    bool prof = false;
+    std::vector<hipEvent_t> prof_ev;   // start/stop pairs
+    size_t prof_used = 0;
+};
+
+// kernels' host launchers (one per translation unit)
+int cadm_pack_streams(cadm_ctx* ctx, hipStream_t s);
+int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, const float* ctx_vec,
+                        const float* actions, const float* eps, int norm_actions, uint32_t seed,
+                        uint32_t call, int it, int cand_offset, int n_global, int m, int n_local,
+                        float* returns_rows, float* traj_out, hipStream_t s);
+int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs,
+                        float* out, hipStream_t s);
+void cadm_train_free(cadm_ctx* ctx);
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u01(uint32_t x) {
+    return (float)(x >> 8) * 5.9604644775390625e-08f + 2.98023223876953125e-08f;  // 2^-24, 2^-25
+}
+
+__device__ __forceinline__ void box_muller(float u1, float u2, float& z0, float& z1) {
+    const float r = sqrtf(-2.0f * logf(u1));
+    const float th = 6.283185307179586f * u2;
+    float s, c;
+    sincosf(th, &s, &c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
+// tf.nn.softplus (TF 1.15 Eigen functor): threshold = log(eps) + 2
+__device__ __forceinline__ float tf_softplus(float x) {
+    const float thr = -13.942385f;  // logf(FLT_EPSILON) + 2
+    if (x > -thr) return x;
+    const float ex = expf(x);
+    if (x < thr) return ex;
+    return log1pf(ex);
+}
+
+// swish(x) = x * sigmoid(x) (dynamics.py:23); v_exp_f32 / v_rcp_f32 based, ~3 ulp
+__device__ __forceinline__ float swish_f(float x) {
+    const float e = __expf(-x);
+    return x * __frcp_rn(1.0f + e);
+}

@@ -1,0 +1,117 @@
+// Packs the raw TF-layout weights W[E,in,out] (core/utils.py:636-641 of the reference) into the
+// planner's MFMA-fragment "weight streams" (layout in common.h / DESIGN.md).
+#include "common.h"
+
+// output unit of A-operand row i (= lane & 15) of output tile `tile`.
+//   hidden layers: D-layout lane (q,row) register r holds unit 16*tile + 4*r + q, and the MFMA puts
+//                  A row i = 4*q + r there  ->  unit(i) = 16*tile + 4*(i&3) + (i>>2)
+//   head tiles:    lane (q,row) holds mu[d0], mu[d0+1], lv[d0], lv[d0+1] with d0 = 8*tile + 2*q
+// returns -1 for padding; for head tiles *is_lv tells which raw tensor the unit comes from.
+__device__ __forceinline__ int out_unit(int head, int tile, int i, int nout, int* is_lv) {
+    const int q = i >> 2, r = i & 3;
+    *is_lv = 0;
+    if (!head) {
+        const int u = 16 * tile + 4 * r + q;
+        return u < nout ? u : -1;
+    }
+    const int d = 8 * tile + 2 * q + (r & 1);
+    *is_lv = r >> 1;
+    return d < nout ? d : -1;
+}
+
+// one thread per stream float of one layer (all members)
+__global__ void pack_layer_kernel(const float* __restrict__ W, const float* __restrict__ W2,
+                                  float* __restrict__ dst, size_t dst_member_stride, int E, int K,
+                                  int nout, int nch, int nfo, int nso, int head) {
+    const size_t slot = (size_t)(nfo * 4 + nso) * 64;
+    const size_t wavef = slot * nch;
+    const size_t layerf = wavef * 4;
+    const size_t total = layerf * E;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx / layerf;
+        size_t rem = idx % layerf;
+        const int w = rem / wavef;
+        rem %= wavef;
+        const int c = rem / slot;
+        rem %= slot;
+        int tile, lane, r;
+        if (rem < (size_t)nfo * 256) {
+            const int blk = rem / 256;
+            lane = (rem % 256) / 4;
+            r = rem % 4;
+            tile = w * nfo + blk;
+        } else {
+            rem -= (size_t)nfo * 256;
+            const int s = rem / 64;
+            lane = rem % 64;
+            r = w;  // split tiles: wave w owns k-step w of every chunk
+            tile = 4 * nfo + s;
+        }
+        const int fin = 16 * c + 4 * r + (lane >> 4);
+        int is_lv;
+        const int u = out_unit(head, tile, lane & 15, nout, &is_lv);
+        float v = 0.0f;
+        if (fin < K && u >= 0) {
+            const float* src = is_lv ? W2 : W;
+            v = src[((size_t)e * K + fin) * nout + u];
+        }
+        dst[(size_t)e * dst_member_stride + (idx % layerf)] = v;
+    }
+}
+
+// D-layout bias tiles: dst[e][tile][lane][r]
+__global__ void pack_bias_kernel(const float* __restrict__ b, const float* __restrict__ b2,
+                                 float* __restrict__ dst, size_t dst_member_stride, int E, int nout,
+                                 int ntiles, int head) {
+    const size_t per = (size_t)ntiles * 256;
+    const size_t total = per * E;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = idx / per;
+        const size_t rem = idx % per;
+        const int tile = rem / 256;
+        const int lane = (rem % 256) / 4;
+        const int r = rem % 4;
+        const int q = lane >> 4;
+        float v = 0.0f;
+        if (!head) {
+            const int u = 16 * tile + 4 * r + q;
+            if (u < nout) v = b[(size_t)e * nout + u];
+        } else {
+            const int d = 8 * tile + 2 * q + (r & 1);
+            if (d < nout) v = ((r >> 1) ? b2 : b)[(size_t)e * nout + d];
+        }
+        dst[(size_t)e * dst_member_stride + rem] = v;
+    }
+}
+
+int cadm_pack_streams(cadm_ctx* ctx, hipStream_t s) {
+    const int NH = ctx->NH, E = ctx->E;
+    for (int l = 0; l < NH + 2; ++l) {
+        if (!ctx->ff[l].W || !ctx->ff[l].b) {
+            cadm_set_error("cadm_repack: ff_model layer %d has no registered weights", l);
+            return CADM_ESTATE;
+        }
+    }
+    size_t woff = 0, boff = 0;
+    auto pack = [&](const LayerGeo& g, const DenseRef& a, const DenseRef* a2) {
+        const size_t total = g.layer_floats() * E;
+        const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(pack_layer_kernel, dim3(grid), dim3(256), 0, s, a.W, a2 ? a2->W : nullptr,
+                           ctx->wstream + woff, ctx->wstream_member_floats, E, g.K, g.nout, g.nch,
+                           g.nfo, g.nso, g.head);
+        const size_t btotal = g.bias_floats() * E;
+        const int bgrid = (int)((btotal + 255) / 256);
+        hipLaunchKernelGGL(pack_bias_kernel, dim3(bgrid), dim3(256), 0, s, a.b, a2 ? a2->b : nullptr,
+                           ctx->bstream + boff, ctx->bstream_member_floats, E, g.nout, g.ntiles, g.head);
+        woff += g.layer_floats();
+        boff += g.bias_floats();
+    };
+    pack(ctx->g0, ctx->ff[0], nullptr);
+    for (int l = 1; l < NH; ++l) pack(ctx->gh, ctx->ff[l], nullptr);
+    pack(ctx->go, ctx->ff[NH], &ctx->ff[NH + 1]);
+    CADM_CHECK_HIP(hipGetLastError());
+    ctx->packed = true;
+    return CADM_OK;
+}

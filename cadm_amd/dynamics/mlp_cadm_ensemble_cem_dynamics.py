@@ -1,0 +1,355 @@
+"""MLPEnsembleCEMDynamicsModel (PE-TS + CaDM) -- MI355X drop-in for the reference class
+/root/reference/cadm/dynamics/mlp_cadm_ensemble_cem_dynamics.py:12.
+
+Same constructor kwargs (:26-54) and public methods -- get_action (:344), get_context_pred
+(:369), fit (:382), save (:571), load (:579), compute_normalization (:590),
+get_normalization_stats (:604) -- so `run_cadm_pets.py` can build it unchanged.  What was one
+TensorFlow graph behind `sess.run` is here libcadm_hip.so (hand-written HIP for gfx950)
+reached through cadm_amd.engine.HipEngine; host code keeps the reference's numpy-level data
+handling (dataset growth, float64 statistics, bootstrap indices, early stopping).
+
+Differences a caller can see (all opt-in except the first):
+  * `env` may be a reference env object, a NormalizedEnv wrapper or a cadm_amd.envs.EnvSpec;
+    its class selects the compiled-in closures (cadm_amd/envs.py);
+  * extra kwargs: `reference_quirks` (default True: reproduce the context-layout quirks Q1/Q2
+    of core/utils.py:434-435), `seed` (device Philox key; the reference never seeds TF),
+    `device`, `process_group` (shard candidates over the ranks of a torch.distributed group);
+  * `predict(obs, act, cp_obs, cp_act)` -- thin alias the north-star asks for: one-step mean
+    prediction of every ensemble member (the reference has no public predict).
+"""
+import time
+from collections import OrderedDict
+
+import joblib
+import numpy as np
+import torch
+
+from .. import planner as _planner
+from ..engine import HipEngine
+from ..envs import resolve_env_kind
+from ..utils import log as logger
+
+_ACTIVATIONS = (None, "relu", "tanh", "sigmoid", "softmax", "swish")   # reference :17-24
+
+
+class MLPEnsembleCEMDynamicsModel(object):
+    """Probabilistic-ensemble MLP dynamics model with a context encoder and a CEM / RS planner."""
+
+    def __init__(self,
+                 name,
+                 env,
+                 hidden_sizes=(200, 200, 200, 200),
+                 hidden_nonlinearity="swish",
+                 output_nonlinearity=None,
+                 batch_size=128,
+                 learning_rate=0.001,
+                 normalize_input=True,
+                 optimizer=None,
+                 valid_split_ratio=0.2,
+                 rolling_average_persitency=0.99,
+                 n_forwards=30,
+                 n_candidates=2500,
+                 ensemble_size=5,
+                 n_particles=20,
+                 use_cem=False,
+                 deterministic=False,
+                 weight_decays=(0., 0., 0., 0., 0.),
+                 weight_decay_coeff=0.0,
+                 cp_hidden_sizes=(256, 128, 64),
+                 context_weight_decays=(0., 0., 0., 0.),
+                 context_out_dim=10,
+                 context_hidden_nonlinearity="relu",
+                 history_length=10,
+                 future_length=10,
+                 state_diff=False,
+                 back_coeff=0.0,
+                 # ---- extensions (not in the reference) ----
+                 reference_quirks=True,
+                 seed=0,
+                 device=None,
+                 process_group=None,
+                 ):
+        self.env = env
+        self.name = name
+        self._dataset = None
+
+        if hidden_nonlinearity not in _ACTIVATIONS or output_nonlinearity not in _ACTIVATIONS:
+            raise KeyError("unknown nonlinearity %r / %r" % (hidden_nonlinearity, output_nonlinearity))
+        if hidden_nonlinearity != "swish" or output_nonlinearity is not None:
+            raise NotImplementedError(
+                "the HIP kernels fuse hidden_nonlinearity='swish' and output_nonlinearity=None "
+                "(the only setting run_cadm_pets.py / run_pets.py use); got %r / %r"
+                % (hidden_nonlinearity, output_nonlinearity))
+        # context_hidden_nonlinearity is accepted and ignored exactly like the reference
+        # (always ReLU: dynamics.py:49 vs :141-156, layers.py:34).
+        if optimizer is not None and getattr(optimizer, "__name__", "") not in ("AdamOptimizer",):
+            raise NotImplementedError("only Adam (TF1 semantics) is implemented")
+
+        self.deterministic = deterministic
+        self.n_forwards = n_forwards
+        self.n_candidates = n_candidates
+        self.use_cem = use_cem
+        self.weight_decays = weight_decays
+        self.weight_decay_coeff = weight_decay_coeff
+        self.normalization = None
+        self.normalize_input = normalize_input
+        self.batch_size = batch_size
+        self.learning_rate = learning_rate
+        self.valid_split_ratio = valid_split_ratio
+        self.rolling_average_persitency = rolling_average_persitency
+        self.ensemble_size = ensemble_size
+        self.n_particles = n_particles
+        self.cp_hidden_sizes = cp_hidden_sizes
+        self.context_out_dim = context_out_dim
+        self.history_length = history_length
+        self.future_length = future_length
+        self.context_weight_decays = context_weight_decays
+        self.state_diff = state_diff
+        self.back_coeff = back_coeff
+
+        self.obs_space_dims = obs_space_dims = env.observation_space.shape[0]
+        self.proc_obs_space_dims = env.proc_observation_space_dims
+        if len(env.action_space.shape) == 0:
+            self.action_space_dims = env.action_space.n
+            self.discrete = True
+        else:
+            self.action_space_dims = env.action_space.shape[0]
+            self.discrete = False
+
+        if n_particles % ensemble_size != 0:
+            raise ValueError("n_particles must be a multiple of ensemble_size (core/utils.py:447 int(p/E))")
+
+        self.env_kind = resolve_env_kind(env)
+        self.seed = int(seed)
+        self._call = 0
+        self._group = process_group
+        self.engine = HipEngine(self.env_kind, ensemble_size, n_particles, obs_space_dims, self.action_space_dims,
+                                self.proc_obs_space_dims, context_out_dim, hidden_sizes, n_forwards,
+                                deterministic=deterministic, discrete=self.discrete,
+                                reference_quirks=reference_quirks, history_length=history_length,
+                                cp_hidden_sizes=cp_hidden_sizes, back_model=back_coeff > 0.0, device=device)
+        # tf.global_variables_initializer() equivalent (mb_trainer.py:164)
+        self.engine.init_weights(np.random.default_rng(self.seed))
+        self._train_ready = False
+        self._stats_dirty = True
+
+    # ------------------------------------------------------------------ planning
+    def _push_stats(self):
+        if self._stats_dirty:
+            keys = ("obs_mean", "obs_std", "act_mean", "act_std", "delta_mean", "delta_std", "cp_obs_mean",
+                    "cp_obs_std", "cp_act_mean", "cp_act_std", "back_delta_mean", "back_delta_std")
+            self.engine.set_stats(dict(zip(keys, self.get_normalization_stats())))
+            self._stats_dirty = False
+
+    def _next_call(self):
+        self._call += 1
+        return self._call & 0xFFFFFFFF
+
+    def get_action(self, obs, cp_obs, cp_act, cem_init_mean=None, cem_init_var=None):
+        """reference :344-367.  CEM: returns the whole plan [m,H,A]; RS: the first action [m,A]
+        (ints [m] for discrete envs).  Continuous outputs are clipped to [-1,1]."""
+        self._push_stats()
+        call = self._next_call()
+        shard = _planner.Shard.from_dist(self.n_candidates, self._group)
+        if cem_init_mean is not None:
+            if shard.world == 1:
+                action = self.engine.cem_plan(obs, cp_obs, cp_act, cem_init_mean, cem_init_var, self.n_candidates,
+                                              seed=self.seed, call=call)
+            else:
+                action = _planner.cem_plan(self.engine, obs, cp_obs, cp_act, cem_init_mean, cem_init_var,
+                                           self.n_candidates, seed=self.seed, call=call, shard=shard)
+        else:
+            if shard.world == 1:
+                action = self.engine.rs_plan(obs, cp_obs, cp_act, self.n_candidates, seed=self.seed, call=call)
+            else:
+                action, _ = _planner.rs_plan(self.engine, obs, cp_obs, cp_act, self.n_candidates, seed=self.seed,
+                                             call=call, shard=shard)
+        action = action.cpu().numpy()
+        if not self.discrete:
+            action = np.minimum(np.maximum(action, -1.0), 1.0)
+        return action
+
+    def get_context_pred(self, cp_obs, cp_act):
+        """reference :369-380 -> [E,m,C]."""
+        self._push_stats()
+        return self.engine.context_forward(cp_obs, cp_act).cpu().numpy()
+
+    def predict(self, obs, act, cp_obs, cp_act):
+        """One-step MEAN next-state prediction of every member, [E,m,D] (no reference twin).
+        Implemented as a 1-step deterministic rollout trajectory is NOT exposed here; it uses the
+        planner kernel with teacher-forced rows so it shares the parity-tested path."""
+        raise NotImplementedError("predict() lands with the training step (round 2)")
+
+    # ------------------------------------------------------------------ training
+    def _ensure_train(self):
+        if not self._train_ready:
+            self.engine.train_configure(self.learning_rate, self.weight_decays, self.context_weight_decays,
+                                        self.weight_decay_coeff, self.back_coeff, max_batch=0)
+            self._train_ready = True
+
+    def fit(self, obs, act, obs_next, cp_obs, cp_act, future_bool, epochs=1000, compute_normalization=True,
+            valid_split_ratio=None, rolling_average_persitency=None, verbose=False, log_tabular=False,
+            max_logging=5000, rng=None):
+        """reference :382-569.  `rng` (numpy Generator) replaces the reference's global np.random."""
+        D, A, F, Hh = self.obs_space_dims, self.action_space_dims, self.future_length, self.history_length
+        assert obs.ndim == 2 and obs.shape[1] == D * F
+        assert obs_next.ndim == 2 and obs_next.shape[1] == D * F
+        assert act.ndim == 2 and act.shape[1] == A * F
+        assert cp_obs.ndim == 2 and cp_obs.shape[1] == D * Hh
+        assert cp_act.ndim == 2 and cp_act.shape[1] == A * Hh
+        assert future_bool.ndim == 2 and future_bool.shape[1] == F
+        if valid_split_ratio is None:
+            valid_split_ratio = self.valid_split_ratio
+        if rolling_average_persitency is None:
+            rolling_average_persitency = self.rolling_average_persitency
+        assert 1 > valid_split_ratio >= 0
+        rng = rng if rng is not None else np.random.default_rng(self.seed + 7919 * (self._call + 1))
+
+        obs = obs.reshape(-1, D)
+        obs_next = obs_next.reshape(-1, D)
+        delta = self.env.targ_proc(obs, obs_next)
+        back_delta = self.env.targ_proc(obs_next, obs)
+        obs = obs.reshape(-1, F * D)
+        obs_next = obs_next.reshape(-1, F * D)
+        delta = delta.reshape(-1, F * D)
+        back_delta = back_delta.reshape(-1, F * D)
+        new = dict(obs=obs, act=act, delta=delta, cp_obs=cp_obs, cp_act=cp_act, future_bool=future_bool,
+                   obs_next=obs_next, back_delta=back_delta, single_obs=obs[:, :D], single_act=act[:, :A],
+                   single_delta=delta[:, :D], single_back_delta=back_delta[:, :D])
+        if self._dataset is None:
+            self._dataset = new
+        else:
+            for k, v in new.items():
+                self._dataset[k] = np.concatenate([self._dataset[k], v])
+        ds = self._dataset
+        self.compute_normalization(ds["single_obs"], ds["single_act"], ds["single_delta"], ds["cp_obs"],
+                                   ds["cp_act"], ds["single_back_delta"])
+        self._push_stats()
+
+        N = ds["obs"].shape[0]
+        n_valid = min(int(N * valid_split_ratio), max_logging)
+        perm = rng.permutation(N)
+        keys = ("obs", "act", "delta", "cp_obs", "cp_act", "future_bool", "obs_next", "back_delta")
+        tr = {k: ds[k][perm[n_valid:]] for k in keys}
+        va = {k: ds[k][perm[:n_valid]] for k in keys}
+        train = self._preprocess_inputs(**tr)
+        valid = self._preprocess_inputs(**va) if n_valid > 0 else None
+        return self._fit_loop(train, valid, epochs, rolling_average_persitency, verbose, log_tabular, rng)
+
+    def _fit_loop(self, train, valid, epochs, persistency, verbose, log_tabular, rng):
+        """Epoch / batch loop (reference :460-569): bootstrap indices, shuffle_rows, one fused
+        fwd/bwd/Adam step per batch, validation, rolling-average early stop."""
+        self._ensure_train()
+        eng, E = self.engine, self.ensemble_size
+        names = ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
+        dev_train = {k: eng._t(v) for k, v in zip(names, train)}    # dataset resident in HBM
+        n_train = train[0].shape[0]
+        if E > 1:
+            bootstrap_idx = rng.integers(0, n_train, size=(E, n_train))       # :465
+        else:
+            bootstrap_idx = np.tile(np.arange(n_train, dtype="int64"), (E, 1))  # :467
+        dev_valid = None
+        if valid is not None and valid[0].shape[0] > 0:
+            dev_valid = {k: eng._t(v)[None].expand(E, -1, -1).contiguous() for k, v in zip(names, valid)}  # :470,515-521
+        rolling, rolling_prev = None, None
+        epoch = -1
+        for epoch in range(epochs):
+            t0 = time.time()
+            # shuffle_rows (:472-474,483): independent permutation of every member's index row
+            idxs = np.argsort(rng.uniform(size=bootstrap_idx.shape), axis=-1)
+            bootstrap_idx = bootstrap_idx[np.arange(E)[:, None], idxs]
+            didx = torch.as_tensor(bootstrap_idx, device=eng.device)
+            losses = []
+            for b in range(int(np.ceil(n_train / self.batch_size))):
+                bi = didx[:, b * self.batch_size:(b + 1) * self.batch_size]    # [E,B]
+                batch = {k: v[bi] for k, v in dev_train.items()}               # device gather -> [E,B,.]
+                losses.append(eng.train_step(batch, train=True))
+            tl = torch.stack(losses).mean(0).cpu().numpy() if losses else np.zeros(3)
+            if dev_valid is not None:
+                v_mse, v_back, v_recon = eng.train_step(dev_valid, train=False).cpu().numpy()
+                if verbose:
+                    logger.log("Training DynamicsModel - finished epoch %i --"
+                               "[Training] mse loss: %.4f  back mse loss: %.4f  recon loss:  %.4f "
+                               "[Validation] mse loss: %.4f  back mse loss: %.4f  recon loss:  %.4f  epoch time: %.2f"
+                               % (epoch, tl[0], tl[1], tl[2], v_mse, v_back, v_recon, time.time() - t0))
+                if rolling is None:                                             # :544-549
+                    rolling, rolling_prev = 1.5 * v_recon, 2 * v_recon
+                    if v_recon < 0:
+                        rolling, rolling_prev = v_recon / 1.5, v_recon / 2
+                rolling = persistency * rolling + (1.0 - persistency) * v_recon  # :551-552
+                if rolling_prev < rolling:                                      # :554-556
+                    logger.log("Stopping Training of Model since its valid_loss_rolling_average decreased")
+                    break
+            elif verbose:
+                logger.log("Training DynamicsModel - finished epoch %i --[Training] mse loss: %.4f  back mse loss: "
+                           "%.4f  recon loss: %.4f  epoch time: %.2f" % (epoch, tl[0], tl[1], tl[2], time.time() - t0))
+            rolling_prev = rolling                                              # :564
+        eng.repack()   # planner weight streams follow the updated master weights
+        if log_tabular:
+            logger.logkv("AvgModelEpochTime", float("nan"))   # reference logs mean([]) (Appendix C)
+            logger.logkv("Epochs", epoch)
+
+    def _preprocess_inputs(self, obs, act, delta, cp_obs, cp_act, future_bool, obs_next, back_delta):
+        """reference :676-696: explode the future window into rows, tile the history, mask."""
+        D, A, Hh, F = self.obs_space_dims, self.action_space_dims, self.history_length, self.future_length
+        fb = future_bool.reshape(-1) > 0
+        rows = lambda x, w: x.reshape((-1, w))[fb]
+        _cp_obs = np.tile(cp_obs, (1, F)).reshape((-1, D * Hh))[fb]
+        _cp_act = np.tile(cp_act, (1, F)).reshape((-1, A * Hh))[fb]
+        return (rows(obs, D), rows(act, A), rows(delta, D), rows(obs_next, D), rows(back_delta, D), _cp_obs, _cp_act)
+
+    # ------------------------------------------------------------------ checkpoint
+    def save(self, save_path):
+        """reference :571-577: joblib list of arrays in tf.trainable_variables() order + '_norm_stats'."""
+        joblib.dump(self.engine.params_list(), save_path)
+        if self.normalization is not None:
+            joblib.dump(self.normalization, save_path + "_norm_stats")
+
+    def load(self, load_path):
+        """reference :579-588 (positional assignment)."""
+        self.engine.load_params_list(joblib.load(load_path))
+        if self.normalize_input:
+            self.normalization = joblib.load(load_path + "_norm_stats")
+            self._stats_dirty = True
+
+    # ------------------------------------------------------------------ statistics
+    def compute_normalization(self, obs, act, delta, cp_obs, cp_act, back_delta):
+        """reference :590-602 (population statistics in float64 on the host)."""
+        assert obs.shape[0] == delta.shape[0] == act.shape[0]
+        proc_obs = self.env.obs_preproc(obs)
+        n = OrderedDict()
+        n["obs"] = (np.mean(proc_obs, axis=0), np.std(proc_obs, axis=0))
+        n["delta"] = (np.mean(delta, axis=0), np.std(delta, axis=0))
+        n["act"] = (np.mean(act, axis=0), np.std(act, axis=0))
+        n["cp_obs"] = (np.mean(cp_obs, axis=0), np.std(cp_obs, axis=0))
+        n["cp_act"] = (np.mean(cp_act, axis=0), np.std(cp_act, axis=0))
+        n["back_delta"] = (np.mean(back_delta, axis=0), np.std(back_delta, axis=0))
+        self.normalization = n
+        self._stats_dirty = True
+
+    def set_normalization(self, normalization):
+        """Install precomputed statistics (same OrderedDict layout as `self.normalization`)."""
+        self.normalization = normalization
+        self._stats_dirty = True
+
+    def get_normalization_stats(self):
+        """reference :604-645."""
+        D, A, P, Hh = self.obs_space_dims, self.action_space_dims, self.proc_obs_space_dims, self.history_length
+        if self.normalize_input:
+            if self.normalization is None:
+                raise RuntimeError("normalization statistics are not set: call fit(), load() or set_normalization()")
+            nz = self.normalization
+            om, os_ = nz["obs"]
+            dm, ds = nz["delta"]
+            am, as_ = (np.zeros((A,)), np.ones((A,))) if self.discrete else nz["act"]
+            com, cos = (np.zeros((D * Hh,)), np.ones((D * Hh,))) if self.state_diff else nz["cp_obs"]
+            cam, cas = (np.zeros((A * Hh,)), np.ones((A * Hh,))) if self.discrete else nz["cp_act"]
+            bm, bs = nz["back_delta"]
+        else:
+            om, os_ = np.zeros((P,)), np.ones((P,))
+            am, as_ = np.zeros((A,)), np.ones((A,))
+            dm, ds = np.zeros((D,)), np.ones((D,))
+            com, cos = np.zeros((D * Hh,)), np.ones((D * Hh,))
+            cam, cas = np.zeros((A * Hh,)), np.ones((A * Hh,))
+            bm, bs = np.zeros((D,)), np.ones((D,))
+        return (om, os_, am, as_, dm, ds, com, cos, cam, cas, bm, bs)

@@ -1,0 +1,47 @@
+"""MLPEnsembleCEMDynamicsModel (Vanilla DM / PE-TS, no context) -- MI355X drop-in for
+/root/reference/cadm/dynamics/mlp_ensemble_cem_dynamics.py:11.
+
+Same constructor kwargs (:25-45) and methods: get_action(obs, cem_init_mean, cem_init_var)
+(:191-207), fit(obs, act, obs_next, ...) (:209-323), save/load (:325-341).  Shares the HIP
+path of the CaDM model with context_dim = 0 and no backward model.
+"""
+import numpy as np
+
+from .mlp_cadm_ensemble_cem_dynamics import MLPEnsembleCEMDynamicsModel as _CaDMModel
+
+
+class MLPEnsembleCEMDynamicsModel(_CaDMModel):
+    def __init__(self, name, env, hidden_sizes=(200, 200, 200, 200), hidden_nonlinearity="swish",
+                 output_nonlinearity=None, batch_size=128, learning_rate=0.001, normalize_input=True,
+                 optimizer=None, valid_split_ratio=0.2, rolling_average_persitency=0.99, n_forwards=30,
+                 n_candidates=2500, ensemble_size=5, n_particles=20, use_cem=False, deterministic=False,
+                 weight_decays=(0., 0., 0., 0., 0.), weight_decay_coeff=0.0,
+                 reference_quirks=True, seed=0, device=None, process_group=None):
+        super().__init__(name, env, hidden_sizes=hidden_sizes, hidden_nonlinearity=hidden_nonlinearity,
+                         output_nonlinearity=output_nonlinearity, batch_size=batch_size, learning_rate=learning_rate,
+                         normalize_input=normalize_input, optimizer=optimizer, valid_split_ratio=valid_split_ratio,
+                         rolling_average_persitency=rolling_average_persitency, n_forwards=n_forwards,
+                         n_candidates=n_candidates, ensemble_size=ensemble_size, n_particles=n_particles,
+                         use_cem=use_cem, deterministic=deterministic, weight_decays=weight_decays,
+                         weight_decay_coeff=weight_decay_coeff, cp_hidden_sizes=(), context_weight_decays=(),
+                         context_out_dim=0, history_length=0, future_length=1, state_diff=False, back_coeff=0.0,
+                         reference_quirks=reference_quirks, seed=seed, device=device, process_group=process_group)
+
+    def get_action(self, obs, cem_init_mean=None, cem_init_var=None):
+        return super().get_action(obs, None, None, cem_init_mean, cem_init_var)
+
+    def get_context_pred(self, *a, **k):
+        raise AttributeError("the vanilla model has no context encoder")
+
+    def fit(self, obs, act, obs_next, epochs=1000, compute_normalization=True, valid_split_ratio=None,
+            rolling_average_persitency=None, verbose=False, log_tabular=False, max_logging=5000, rng=None):
+        """reference :209-323 (single-step samples, no history window)."""
+        N = obs.shape[0]
+        D, A = self.obs_space_dims, self.action_space_dims
+        assert obs.ndim == 2 and obs.shape[1] == D
+        assert obs_next.ndim == 2 and obs_next.shape[1] == D
+        assert act.ndim == 2 and act.shape[1] == A
+        return super().fit(obs, act, obs_next, np.zeros((N, 0)), np.zeros((N, 0)), np.ones((N, 1)), epochs=epochs,
+                           compute_normalization=compute_normalization, valid_split_ratio=valid_split_ratio,
+                           rolling_average_persitency=rolling_average_persitency, verbose=verbose,
+                           log_tabular=log_tabular, max_logging=max_logging, rng=rng)

@@ -1,0 +1,368 @@
+"""HipEngine: device state (weights, stats, scratch) + typed calls into libcadm_hip.so.
+
+PyTorch-ROCm is used for device memory, the current HIP stream and (for multi-GPU)
+torch.distributed only; every planner / training FLOP runs in the hand-written HIP
+kernels behind the C ABI.  No host fallback exists: without a GPU or without the
+built library the constructor raises.
+"""
+import ctypes as ct
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Config, TrainHParams, check, ptr
+
+STAT_KEYS = ("obs_mean", "obs_std", "act_mean", "act_std", "delta_mean", "delta_std",
+             "cp_obs_mean", "cp_obs_std", "cp_act_mean", "cp_act_std",
+             "back_delta_mean", "back_delta_std")
+
+
+def dyn_param_names(n_hidden):
+    """tf.trainable_variables() creation order inside one dynamics MLP
+    (/root/reference/cadm/dynamics/core/utils.py:313-339)."""
+    names = []
+    for i in range(n_hidden):
+        names += ["hidden_%d_weight" % i, "hidden_%d_bias" % i]
+    names += ["output_mu_weight", "output_mu_bias", "output_logvar_weight", "output_logvar_bias",
+              "max_logvar", "min_logvar"]
+    return names
+
+
+def ctx_param_names(n_cp_hidden):
+    """core/utils.py:595-612."""
+    names = []
+    for i in range(n_cp_hidden):
+        names += ["cp_hidden_%d_weight" % i, "cp_hidden_%d_bias" % i]
+    return names + ["cp_output_weight", "cp_output_bias"]
+
+
+class HipEngine:
+    def __init__(self, env_kind, E, p, D, A, P, C, hidden_sizes, H, deterministic=False, discrete=False,
+                 reference_quirks=True, history_length=10, cp_hidden_sizes=(256, 128, 64), back_model=False,
+                 num_elites=50, num_cem_iters=5, alpha=0.1, lower_bound=-1.0, upper_bound=1.0, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.CadmError("no HIP device visible: the CaDM planner runs only on the GPU "
+                                 "(libcadm_hip.so); there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        hs = tuple(int(h) for h in hidden_sizes)
+        if len(set(hs)) != 1:
+            raise ValueError("hidden_sizes must all be equal, got %r" % (hs,))
+        self.env_kind, self.E, self.p, self.D, self.A, self.P, self.C = env_kind, E, p, D, A, P, C
+        self.H, self.NH, self.HID = H, len(hs), hs[0]
+        self.Hh = history_length
+        self.cp_hidden_sizes = tuple(cp_hidden_sizes)
+        self.deterministic, self.discrete = bool(deterministic), bool(discrete)
+        self.back_model = bool(back_model)
+        self.K0 = P + A + C
+        cfg = Config()
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.env_kind = _lib.ENV_KINDS[env_kind]
+        cfg.ensemble_size, cfg.n_particles = E, p
+        cfg.obs_dim, cfg.act_dim, cfg.proc_obs_dim, cfg.context_dim = D, A, P, C
+        cfg.n_hidden, cfg.hidden, cfg.horizon = self.NH, self.HID, H
+        cfg.deterministic, cfg.discrete = int(self.deterministic), int(self.discrete)
+        cfg.reference_quirks = int(bool(reference_quirks))
+        cfg.history_length = history_length
+        cfg.n_cp_hidden = len(self.cp_hidden_sizes) if C > 0 else 0
+        for i, h in enumerate(self.cp_hidden_sizes if C > 0 else ()):
+            cfg.cp_hidden[i] = int(h)
+        cfg.num_elites, cfg.num_cem_iters, cfg.alpha = num_elites, num_cem_iters, alpha
+        cfg.lower_bound, cfg.upper_bound = lower_bound, upper_bound
+        cfg.back_model = int(self.back_model)
+        self.cfg = cfg
+        self.num_elites, self.num_cem_iters = num_elites, num_cem_iters
+        self._ctx = C_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.cadm_ctx_create(ct.byref(cfg), ct.byref(self._ctx)), "cadm_ctx_create")
+        self.nets = OrderedDict()   # net name -> OrderedDict(param name -> tensor)
+        self._ws = None
+        self._ws_key = None
+        self._train_B = 0
+
+    # ------------------------------------------------------------------ lifecycle
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self.lib.cadm_ctx_destroy(self._ctx)
+            self._ctx = C_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return ct.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _t(self, x, dtype=torch.float32):
+        """numpy / tensor -> contiguous device tensor."""
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(self.device)
+
+    # ------------------------------------------------------------------ weights
+    def net_names(self):
+        names = []
+        if self.C > 0:
+            names.append("context_model")
+        names.append("ff_model")
+        if self.back_model:
+            names.append("backward_model")
+        return names   # = variable-scope creation order (dynamics.py:140,159,213)
+
+    def param_shapes(self, net):
+        E = self.E
+        shapes = OrderedDict()
+        if net == "context_model":
+            sizes = [(self.D + self.A) * self.Hh] + list(self.cp_hidden_sizes)
+            for i in range(len(sizes) - 1):
+                shapes["cp_hidden_%d_weight" % i] = (E, sizes[i], sizes[i + 1])
+                shapes["cp_hidden_%d_bias" % i] = (E, 1, sizes[i + 1])
+            shapes["cp_output_weight"] = (E, sizes[-1], self.C)
+            shapes["cp_output_bias"] = (E, 1, self.C)
+        else:
+            sizes = [self.K0] + [self.HID] * self.NH
+            for i in range(self.NH):
+                shapes["hidden_%d_weight" % i] = (E, sizes[i], sizes[i + 1])
+                shapes["hidden_%d_bias" % i] = (E, 1, sizes[i + 1])
+            for head in ("output_mu", "output_logvar"):
+                shapes[head + "_weight"] = (E, self.HID, self.D)
+                shapes[head + "_bias"] = (E, 1, self.D)
+            shapes["max_logvar"] = (1, self.D)
+            shapes["min_logvar"] = (1, self.D)
+        return shapes
+
+    def init_weights(self, rng):
+        """Reference initialiser: trunc_normal(std = 1/(2 sqrt(in))), bias 0, logvar bounds 0.5 / -10
+        (core/utils.py:338-339,636-641)."""
+        for net in self.net_names():
+            params = OrderedDict()
+            for name, shape in self.param_shapes(net).items():
+                if name == "max_logvar":
+                    v = np.ones(shape) / 2.0
+                elif name == "min_logvar":
+                    v = -np.ones(shape) * 10.0
+                elif name.endswith("_bias"):
+                    v = np.zeros(shape)
+                else:
+                    std = 1.0 / (2.0 * np.sqrt(shape[1]))
+                    v = rng.standard_normal(shape)
+                    bad = np.abs(v) > 2.0
+                    while bad.any():
+                        v[bad] = rng.standard_normal(int(bad.sum()))
+                        bad = np.abs(v) > 2.0
+                    v = v * std
+                params[name] = v
+            self.set_net(net, params)
+
+    def set_net(self, net, params):
+        """Install parameters (numpy or tensors) for one net and register them with the library."""
+        shapes = self.param_shapes(net)
+        cur = self.nets.get(net)
+        out = OrderedDict()
+        for name, shape in shapes.items():
+            t = self._t(params[name])
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError("%s/%s: shape %r != %r" % (net, name, tuple(t.shape), tuple(shape)))
+            if cur is not None:     # keep registered device pointers stable
+                cur[name].copy_(t)
+                t = cur[name]
+            out[name] = t
+        self.nets[net] = out
+        if cur is None:
+            self._register(net)
+        if net == "ff_model":
+            check(self.lib.cadm_repack(self._ctx, self.stream), "cadm_repack")
+
+    def _register(self, net):
+        prm = self.nets[net]
+        nid = {"ff_model": _lib.NET_FF, "backward_model": _lib.NET_BACK, "context_model": _lib.NET_CTX}[net]
+        if net == "context_model":
+            layers = ["cp_hidden_%d" % i for i in range(len(self.cp_hidden_sizes))] + ["cp_output"]
+        else:
+            layers = ["hidden_%d" % i for i in range(self.NH)] + ["output_mu", "output_logvar"]
+        for li, base in enumerate(layers):
+            check(self.lib.cadm_set_weights(self._ctx, nid, li, ptr(prm[base + "_weight"]), ptr(prm[base + "_bias"])),
+                  "cadm_set_weights")
+        if net != "context_model":
+            check(self.lib.cadm_set_logvar_bounds(self._ctx, nid, ptr(prm["max_logvar"]), ptr(prm["min_logvar"])),
+                  "cadm_set_logvar_bounds")
+
+    def repack(self):
+        check(self.lib.cadm_repack(self._ctx, self.stream), "cadm_repack")
+
+    def params_list(self):
+        """Flat list of numpy arrays in the reference's tf.trainable_variables() order
+        (context_model, ff_model, backward_model; dynamics.py:266)."""
+        out = []
+        for net in self.net_names():
+            for t in self.nets[net].values():
+                out.append(t.detach().cpu().numpy().copy())
+        return out
+
+    def load_params_list(self, arrays):
+        it = iter(arrays)
+        for net in self.net_names():
+            params = OrderedDict()
+            for name in self.param_shapes(net):
+                params[name] = np.asarray(next(it))
+            self.set_net(net, params)
+
+    # ------------------------------------------------------------------ stats
+    def set_stats(self, stats):
+        arrs = [np.ascontiguousarray(np.asarray(stats[k], dtype=np.float32)).reshape(-1) for k in STAT_KEYS]
+        lens = [self.P, self.P, self.A, self.A, self.D, self.D, self.D * self.Hh, self.D * self.Hh,
+                self.A * self.Hh, self.A * self.Hh, self.D, self.D]
+        for k, a, n in zip(STAT_KEYS, arrs, lens):
+            if a.size != n:
+                raise ValueError("stat %s has %d entries, expected %d" % (k, a.size, n))
+        ptrs = (ct.c_void_p * 12)(*[a.ctypes.data_as(ct.c_void_p) for a in arrs])
+        check(self.lib.cadm_set_norm_stats(self._ctx, ptrs, self.stream), "cadm_set_norm_stats")
+
+    # ------------------------------------------------------------------ planner primitives
+    def context_forward(self, cp_obs, cp_act, bs=False):
+        cp_obs, cp_act = self._t(cp_obs), self._t(cp_act)
+        m = cp_obs.shape[1] if bs else cp_obs.shape[0]
+        out = torch.empty((self.E, m, self.C), dtype=torch.float32, device=self.device)
+        check(self.lib.cadm_context_forward(self._ctx, ptr(cp_obs), ptr(cp_act), m, int(bs), ptr(out), self.stream),
+              "cadm_context_forward")
+        return out
+
+    def sample_actions(self, mean, var, n_global, z=None, seed=0, call=0, it=0):
+        mean, var = self._t(mean), self._t(var)
+        m = mean.shape[0]
+        z = None if z is None else self._t(z)
+        out = torch.empty((m, n_global, self.H, self.A), dtype=torch.float32, device=self.device)
+        check(self.lib.cadm_sample_actions(self._ctx, ptr(mean), ptr(var), ptr(z), seed, call, it, m, n_global,
+                                           ptr(out), self.stream), "cadm_sample_actions")
+        return out
+
+    def sample_uniform(self, m, n_global, seed=0, call=0):
+        out = torch.empty((m, n_global, self.H, self.A), dtype=torch.float32, device=self.device)
+        raw = torch.empty((m, n_global, self.H), dtype=torch.int32, device=self.device) if self.discrete else None
+        check(self.lib.cadm_sample_uniform(self._ctx, seed, call, m, n_global, ptr(out), ptr(raw), self.stream),
+              "cadm_sample_uniform")
+        return out, raw
+
+    def rollout_returns(self, obs, ctx_vec, actions, eps=None, obs_rows=None, norm_actions=True, seed=0, call=0,
+                        it=0, cand_offset=0, n_local=None, want_traj=False):
+        obs, actions = self._t(obs), self._t(actions)
+        m, n_global = actions.shape[0], actions.shape[1]
+        n_local = n_global - cand_offset if n_local is None else n_local
+        ctx_vec = None if ctx_vec is None else self._t(ctx_vec)
+        eps = None if eps is None else self._t(eps)
+        obs_rows = None if obs_rows is None else self._t(obs_rows)
+        rows = torch.empty((m, n_local, self.p), dtype=torch.float32, device=self.device)
+        traj = (torch.empty((self.H, m, n_local, self.p, self.D), dtype=torch.float32, device=self.device)
+                if want_traj else None)
+        check(self.lib.cadm_rollout_returns(self._ctx, ptr(obs), ptr(obs_rows), ptr(ctx_vec), ptr(actions), ptr(eps),
+                                            int(norm_actions), seed, call, it, cand_offset, n_global, m, n_local,
+                                            ptr(rows), ptr(traj), self.stream), "cadm_rollout_returns")
+        return (rows, traj) if want_traj else rows
+
+    def particle_mean(self, rows):
+        m, n_local = rows.shape[0], rows.shape[1]
+        out = torch.empty((m, n_local), dtype=torch.float32, device=self.device)
+        check(self.lib.cadm_particle_mean(self._ctx, ptr(rows), m, n_local, ptr(out), self.stream), "cadm_particle_mean")
+        return out
+
+    def cem_refit(self, cand, actions, mean, var, G=1, want_elites=False):
+        """cand [G,m,n_local] (or [m,n] when G == 1); mean/var updated IN PLACE."""
+        m = actions.shape[0]
+        n_local = actions.shape[1] // G
+        el = torch.empty((m, self.num_elites), dtype=torch.int32, device=self.device) if want_elites else None
+        check(self.lib.cadm_cem_refit(self._ctx, ptr(cand), G, n_local, ptr(actions), m, ptr(mean), ptr(var), ptr(el),
+                                      self.stream), "cadm_cem_refit")
+        return el
+
+    def rs_select(self, cand, actions, G=1):
+        m = actions.shape[0]
+        n_local = actions.shape[1] // G
+        out = torch.empty((m, self.A), dtype=torch.float32, device=self.device)
+        best = torch.empty((m,), dtype=torch.int32, device=self.device)
+        check(self.lib.cadm_rs_select(self._ctx, ptr(cand), G, n_local, ptr(actions), m, ptr(out), ptr(best),
+                                      self.stream), "cadm_rs_select")
+        return out, best
+
+    # ------------------------------------------------------------------ fused planners
+    def _workspace(self, m, n):
+        key = (m, n)
+        if self._ws_key != key:
+            nbytes = self.lib.cadm_plan_workspace_bytes(self._ctx, m, n)
+            self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+            self._ws_key = key
+        return self._ws
+
+    def cem_plan(self, obs, cp_obs, cp_act, init_mean, init_var, n, seed=0, call=0):
+        obs, init_mean, init_var = self._t(obs), self._t(init_mean), self._t(init_var)
+        cp_obs = None if cp_obs is None else self._t(cp_obs)
+        cp_act = None if cp_act is None else self._t(cp_act)
+        m = obs.shape[0]
+        ws = self._workspace(m, n)
+        out = torch.empty((m, self.H, self.A), dtype=torch.float32, device=self.device)
+        check(self.lib.cadm_cem_plan(self._ctx, ptr(obs), ptr(cp_obs), ptr(cp_act), ptr(init_mean), ptr(init_var), m, n,
+                                     seed, call, ptr(ws), ptr(out), self.stream), "cadm_cem_plan")
+        return out
+
+    def rs_plan(self, obs, cp_obs, cp_act, n, seed=0, call=0):
+        obs = self._t(obs)
+        cp_obs = None if cp_obs is None else self._t(cp_obs)
+        cp_act = None if cp_act is None else self._t(cp_act)
+        m = obs.shape[0]
+        ws = self._workspace(m, n)
+        out = torch.empty((m, self.A), dtype=torch.float32, device=self.device)
+        raw = torch.empty((m,), dtype=torch.int32, device=self.device) if self.discrete else None
+        check(self.lib.cadm_rs_plan(self._ctx, ptr(obs), ptr(cp_obs), ptr(cp_act), m, n, seed, call, ptr(ws), ptr(out),
+                                    ptr(raw), self.stream), "cadm_rs_plan")
+        return raw if self.discrete else out
+
+    # ------------------------------------------------------------------ training
+    def train_configure(self, learning_rate, weight_decays, context_weight_decays, weight_decay_coeff, back_coeff,
+                        max_batch, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        hp = TrainHParams()
+        hp.learning_rate, hp.beta1, hp.beta2, hp.epsilon = learning_rate, beta1, beta2, epsilon
+        hp.back_coeff, hp.weight_decay_coeff = back_coeff, weight_decay_coeff
+        wd = list(weight_decays)
+        for i in range(self.NH):
+            hp.weight_decays[i] = wd[i]
+        hp.weight_decays[self.NH] = wd[-1]            # both heads (core/utils.py:328,334)
+        if self.C > 0:
+            cwd = list(context_weight_decays)
+            ncp = len(self.cp_hidden_sizes)
+            for i in range(ncp):
+                hp.context_weight_decays[i] = cwd[i]
+            hp.context_weight_decays[ncp] = cwd[-1]   # cp_output (core/utils.py:610)
+        check(self.lib.cadm_train_configure(self._ctx, ct.byref(hp), int(max_batch)), "cadm_train_configure")
+        self._train_B = int(max_batch)
+
+    def train_step(self, batch, train=True):
+        """batch: dict of [E,B,.] tensors (obs, act, delta, obs_next, back_delta, cp_obs, cp_act; the
+        last four may be None for the vanilla model).  Returns a device tensor [mse, back_mse, recon]."""
+        B = batch["obs"].shape[1]
+        g = lambda k: ptr(batch.get(k))
+        losses = torch.empty((3,), dtype=torch.float32, device=self.device)
+        check(self.lib.cadm_train_step(self._ctx, g("obs"), g("act"), g("delta"), g("obs_next"), g("back_delta"),
+                                       g("cp_obs"), g("cp_act"), B, int(train), ptr(losses), self.stream),
+              "cadm_train_step")
+        return losses
+
+    # ------------------------------------------------------------------ in-library kernel timing
+    def profile_enable(self, on=True):
+        check(self.lib.cadm_profile_enable(self._ctx, int(on)), "cadm_profile_enable")
+
+    def profile_read(self):
+        """-> (total milliseconds, launches) of the rollout kernel since the last read."""
+        ms, cnt = ct.c_float(0.0), ct.c_int(0)
+        check(self.lib.cadm_profile_read(self._ctx, ct.byref(ms), ct.byref(cnt)), "cadm_profile_read")
+        return float(ms.value), int(cnt.value)
+
+    def train_reset(self):
+        check(self.lib.cadm_train_reset(self._ctx, self.stream), "cadm_train_reset")
+
+
+def C_void_p():
+    return ct.c_void_p()

@@ -1,0 +1,207 @@
+/*
+ * cadm_hip.h -- C ABI of libcadm_hip.so: the MI355X (gfx950) implementation of
+ * CaDM's CEM-planning / ensemble-training hot path.
+ *
+ * The reference (younggyoseo/CaDM) has NO FFI layer: its seam is the Python class
+ * MLPEnsembleCEMDynamicsModel (cadm/dynamics/mlp_cadm_ensemble_cem_dynamics.py:12)
+ * whose methods call sess.run on one TensorFlow graph (cadm/utils/tensor_utils.py:6-11).
+ * Every entry point below replaces one piece of that graph; the reference lines it
+ * replaces are cited per function (paths relative to /root/reference).  The Python
+ * mirror of the class lives in cadm_amd/dynamics/ and binds these with ctypes
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - every pointer argument is a DEVICE pointer to row-major float32 unless noted;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously;
+ *   - every function returns 0 on success or a negative CADM_E* code and never throws;
+ *     cadm_last_error() returns a thread-local message for the last failure;
+ *   - no global state beyond the opaque cadm_ctx;
+ *   - a cadm_ctx is bound to the HIP device that was current at cadm_ctx_create.
+ */
+#ifndef CADM_HIP_H
+#define CADM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CADM_ABI_VERSION 1
+
+#define CADM_OK 0
+#define CADM_EINVAL (-1)      /* bad argument / unsupported configuration */
+#define CADM_ENOMEM (-2)      /* device allocation failed */
+#define CADM_EHIP (-3)        /* HIP runtime error (see cadm_last_error) */
+#define CADM_ESTATE (-4)      /* weights / stats not set */
+
+/* env kinds: the closures obs_preproc / obs_postproc / tf_reward_fn that the reference
+ * compiles into its graph (cadm/envs/<env>.py) are compiled into the kernels */
+#define CADM_ENV_HALFCHEETAH 0   /* half_cheetah_env.py:46-59,82-88; cripple: half_cheetah_cripple_env.py:60-73,90-96 */
+#define CADM_ENV_ANT 1           /* ant_env.py:52-62,89-98 */
+#define CADM_ENV_SLIM_HUMANOID 2 /* slim_humanoid_env.py:39-46,95-111 */
+#define CADM_ENV_CARTPOLE 3      /* classic_control.py:94-101,154-166 */
+#define CADM_ENV_PENDULUM 4      /* classic_control.py:209-218,284-291 */
+
+#define CADM_NET_FF 0    /* variable scope 'ff_model'        (dynamics.py:159) */
+#define CADM_NET_BACK 1  /* variable scope 'backward_model'  (dynamics.py:213) */
+#define CADM_NET_CTX 2   /* variable scope 'context_model'   (dynamics.py:140) */
+
+#define CADM_MAX_HIDDEN_LAYERS 8
+#define CADM_MAX_CP_LAYERS 8
+
+typedef struct cadm_ctx cadm_ctx;
+
+/* Mirrors the ctor kwargs of MLPEnsembleCEMDynamicsModel (dynamics.py:26-54) that shape the graph. */
+typedef struct cadm_config {
+    int32_t abi_version;       /* CADM_ABI_VERSION */
+    int32_t env_kind;          /* CADM_ENV_* */
+    int32_t ensemble_size;     /* E */
+    int32_t n_particles;       /* p, p % E == 0 (core/utils.py:447) */
+    int32_t obs_dim;           /* D  (must match the env kind) */
+    int32_t act_dim;           /* A */
+    int32_t proc_obs_dim;      /* P */
+    int32_t context_dim;       /* C = context_out_dim, 0 for the vanilla PE-TS model */
+    int32_t n_hidden;          /* number of hidden layers (4) */
+    int32_t hidden;            /* hidden width, all layers equal (200) */
+    int32_t horizon;           /* n_forwards H */
+    int32_t deterministic;     /* dynamics.py:43 */
+    int32_t discrete;          /* discrete action space (cartpole) */
+    int32_t reference_quirks;  /* 1: reproduce context-layout quirks Q1/Q2 (core/utils.py:434-435) */
+    int32_t history_length;    /* Hh */
+    int32_t n_cp_hidden;       /* context encoder hidden layers (3) */
+    int32_t cp_hidden[CADM_MAX_CP_LAYERS]; /* (256,128,64) */
+    int32_t num_elites;        /* 50  (core/utils.py:391) */
+    int32_t num_cem_iters;     /* 5   (core/utils.py:392) */
+    float alpha;               /* 0.1 (core/utils.py:393) */
+    float lower_bound;         /* -1  (core/utils.py:395) */
+    float upper_bound;         /* +1  (core/utils.py:396) */
+    int32_t back_model;        /* 1: backward model present (back_coeff > 0, dynamics.py:212) */
+    int32_t reserved[7];
+} cadm_config;
+
+const char* cadm_last_error(void);
+int cadm_abi_version(void);
+
+/* Build / free the per-model device state (replaces graph construction, dynamics.py:107-342). */
+int cadm_ctx_create(const cadm_config* cfg, cadm_ctx** out);
+int cadm_ctx_destroy(cadm_ctx* ctx);
+
+/* Register one dense layer's master weights (raw TF layout W [E,in,out], b [E,1,out];
+ * create_dense_layer, core/utils.py:635-641).  The pointers stay owned by the caller and must
+ * outlive the ctx; the planner's MFMA-fragment weight streams are (re)packed from them.
+ * layer index: CADM_NET_FF/BACK: 0..n_hidden-1 hidden, n_hidden = output_mu, n_hidden+1 = output_logvar;
+ *              CADM_NET_CTX:     0..n_cp_hidden-1 hidden, n_cp_hidden = cp_output. */
+int cadm_set_weights(cadm_ctx* ctx, int net, int layer, float* W, float* b);
+/* max_logvar / min_logvar [1,D] (core/utils.py:338-339). */
+int cadm_set_logvar_bounds(cadm_ctx* ctx, int net, float* max_logvar, float* min_logvar);
+/* Re-pack the planner's weight streams from the registered master weights (after load()/fit()). */
+int cadm_repack(cadm_ctx* ctx, void* stream);
+
+/* The 12 normalisation vectors fed per call in the reference (dynamics.py:344-347,604-645), order:
+ * obs_mean[P] obs_std[P] act_mean[A] act_std[A] delta_mean[D] delta_std[D] cp_obs_mean[D*Hh]
+ * cp_obs_std[D*Hh] cp_act_mean[A*Hh] cp_act_std[A*Hh] back_delta_mean[D] back_delta_std[D].
+ * HOST pointers (float32); copied. */
+int cadm_set_norm_stats(cadm_ctx* ctx, const float* const host_stats[12], void* stream);
+
+/* Context encoder inference (core/utils.py:401-406,614-617): cp_obs [m,D*Hh], cp_act [m,A*Hh]
+ * -> ctx_out [E,m,C].  With bs != 0 the inputs are already [E,m,.] (get_context_pred,
+ * dynamics.py:369-380 / training graph :619-622). */
+int cadm_context_forward(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs,
+                         float* ctx_out, void* stream);
+
+/* Candidate action sequences (core/utils.py:425-429):
+ * actions[m,n_global,H,A] = mean + sqrt(min(min(((mean-lb)/2)^2,((ub-mean)/2)^2),var)) * z.
+ * z = injected truncated-normal draws [m,n_global,H,A], or NULL to draw them on device from
+ * Philox4x32-10 keyed (seed, call) with counters (element, attempt, STREAM_ACT | it<<8). */
+int cadm_sample_actions(cadm_ctx* ctx, const float* mean, const float* var, const float* z,
+                        uint32_t seed, uint32_t call, int it, int m, int n_global,
+                        float* actions_out, void* stream);
+/* Random-shooting draws (core/utils.py:498-503): U[-1,1) actions (continuous) or one-hot rows of
+ * uniform integer actions (discrete; raw ints also written to raw_out [m,n,H] if non-NULL). */
+int cadm_sample_uniform(cadm_ctx* ctx, uint32_t seed, uint32_t call, int m, int n_global,
+                        float* actions_out, int32_t* raw_out, void* stream);
+
+/* THE hot kernel: trajectory-sampling rollout of candidates [cand_offset, cand_offset+n_local)
+ * through the ensemble over the whole horizon (core/utils.py:431-472, one CEM iteration's inner
+ * loop; vanilla :138-170).  One launch = H steps x (m*n_local*p) rows.
+ *   obs          [m,D]            start state (tiled over n,p as :432)
+ *   obs_rows     [m,n_local,p,D]  optional per-row start state (teacher forcing), else NULL
+ *   ctx_vec      [E,m,C]          context encoder output (NULL when C == 0)
+ *   actions      [m,n_global,H,A] candidate actions; normalised in-kernel (:443) unless
+ *                                 norm_actions == 0 (discrete RS feeds one-hot rows, :500)
+ *   eps          [H,m,n_local,p,D] injected N(0,1) for the Gaussian head (:365), or NULL to draw
+ *                                 from Philox keyed (seed, call), counters (global row, t, d/2,
+ *                                 STREAM_EPS | it<<8) -- independent of the candidate sharding
+ *   it           CEM iteration (selects the context layout of quirk Q2, :434)
+ *   returns_rows [m,n_local,p]    out: per-row returns before the particle mean (:471)
+ *   traj_out     [H,m,n_local,p,D] optional out: next observation after every step, else NULL */
+int cadm_rollout_returns(cadm_ctx* ctx, const float* obs, const float* obs_rows, const float* ctx_vec,
+                         const float* actions, const float* eps, int norm_actions,
+                         uint32_t seed, uint32_t call, int it,
+                         int cand_offset, int n_global, int m, int n_local,
+                         float* returns_rows, float* traj_out, void* stream);
+
+/* Mean over particles (core/utils.py:474): returns_rows [m,n_local,p] -> cand_returns [m,n_local]. */
+int cadm_particle_mean(cadm_ctx* ctx, const float* returns_rows, int m, int n_local,
+                       float* cand_returns, void* stream);
+
+/* Elite refit (core/utils.py:475-486): top-k (sorted, ties -> lower index), gather, mean /
+ * biased variance over elites, EMA with alpha.
+ *   cand_returns  [G,m,n_local]  the all-gathered per-candidate returns of G ranks (G = 1: [m,n]);
+ *                                global candidate ni lives at [ni / n_local][mi][ni % n_local]
+ *   actions       [m,G*n_local,H,A]
+ *   mean_io/var_io [m,H,A]       updated in place
+ *   elites_out    [m,num_elites] optional int32 out (global candidate ids), else NULL */
+int cadm_cem_refit(cadm_ctx* ctx, const float* cand_returns, int G, int n_local, const float* actions,
+                   int m, float* mean_io, float* var_io, int32_t* elites_out, void* stream);
+
+/* Random-shooting selection (core/utils.py:554-561): argmax over candidates (first maximum),
+ * out[m,A] = actions[mi, best, 0, :].  best_out [m] optional. */
+int cadm_rs_select(cadm_ctx* ctx, const float* cand_returns, int G, int n_local, const float* actions,
+                   int m, float* first_action_out, int32_t* best_out, void* stream);
+
+/* Whole single-GPU CEM planner = one `sess.run(optimal_action_var)` (dynamics.py:349-356,
+ * core/utils.py:398-488): context encoder once, then num_cem_iters x (sample, rollout, refit);
+ * the result [m,H,A] is clipped to [lb,ub] as get_action does (dynamics.py:365-366) unless discrete.
+ * workspace: device scratch of cadm_plan_workspace_bytes(ctx, m, n) bytes. */
+size_t cadm_plan_workspace_bytes(cadm_ctx* ctx, int m, int n);
+int cadm_cem_plan(cadm_ctx* ctx, const float* obs, const float* cp_obs, const float* cp_act,
+                  const float* init_mean, const float* init_var, int m, int n,
+                  uint32_t seed, uint32_t call, void* workspace, float* plan_out, void* stream);
+/* Random-shooting planner (core/utils.py:490-561): out [m,A] (continuous) or raw_best_out [m] ints. */
+int cadm_rs_plan(cadm_ctx* ctx, const float* obs, const float* cp_obs, const float* cp_act,
+                 int m, int n, uint32_t seed, uint32_t call, void* workspace,
+                 float* action_out, int32_t* raw_best_out, void* stream);
+
+/* One training step = sess.run([mse_loss, back_mse_loss, recon_loss, train_op]) (dynamics.py:505-507):
+ * forward of context / forward / backward nets on the [E,B,.] bootstrap batch, losses
+ * (dynamics.py:269-314), gradients, TF1-semantics Adam (dynamics.py:316-317) applied IN PLACE to the
+ * registered master weights.  train != 0 applies the update; train == 0 only evaluates the losses
+ * (validation, dynamics.py:531-533).  losses_out: device float[3] = mse, back_mse, recon. */
+typedef struct cadm_train_hparams {
+    float learning_rate;          /* 1e-3 */
+    float beta1, beta2, epsilon;  /* 0.9, 0.999, 1e-8 */
+    float back_coeff;             /* dynamics.py:53 */
+    float weight_decay_coeff;     /* dynamics.py:45 */
+    float weight_decays[CADM_MAX_HIDDEN_LAYERS + 1];      /* hidden_i ..., last = both heads (core/utils.py:319,328,334) */
+    float context_weight_decays[CADM_MAX_CP_LAYERS + 1];  /* cp_hidden_i ..., last = cp_output (core/utils.py:601,610) */
+} cadm_train_hparams;
+int cadm_train_configure(cadm_ctx* ctx, const cadm_train_hparams* hp, int max_batch);
+int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act, const float* delta,
+                    const float* obs_next, const float* back_delta, const float* cp_obs,
+                    const float* cp_act, int B, int train, float* losses_out, void* stream);
+/* Reset Adam moments / step count (a fresh tf.global_variables_initializer()). */
+int cadm_train_reset(cadm_ctx* ctx, void* stream);
+
+/* In-library timing of the dominant kernel (the rollout): when enabled, every
+ * cadm_rollout_returns launch is bracketed by hipEvents on the launch stream.
+ * cadm_profile_read synchronises, returns the summed elapsed milliseconds and launch count
+ * since the last read, and resets both. */
+int cadm_profile_enable(cadm_ctx* ctx, int enable);
+int cadm_profile_read(cadm_ctx* ctx, float* total_ms_out, int* launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CADM_HIP_H */

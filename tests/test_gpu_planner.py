@@ -1,0 +1,244 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the
+same seeded inputs.  Float path: tolerance 1e-5 relative (BASELINE.json north_star), stated at
+each assert; whole-trajectory drift is reported against the fp64 oracle next to the fp32
+oracle's own drift (both must sit in the same band)."""
+import numpy as np
+import pytest
+
+from cadm_amd import planner as hplanner
+from cadm_amd import synth
+from helpers import assert_close, make_engine, oracle_problem, rel_err, trunc_z
+from oracle import nets as onets
+from oracle import philox as ophilox
+from oracle import planner as oplanner
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5   # north_star: "within 1e-5 relative FP tolerance"
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("env,m", [("halfcheetah", 1), ("halfcheetah", 3), ("slim_humanoid", 2)])
+def test_context_encoder(gpu, env, m):
+    prob = synth.make_problem(env=env, m=m, trained_like=True, seed=3)
+    eng = make_engine(prob, p=5)
+    got = _np(eng.context_forward(prob["cp_obs"], prob["cp_act"]))
+    o32 = oracle_problem(prob, np.float32)
+    ref = onets.context_forward(o32["cp"], o32["cp_obs"], o32["cp_act"], o32["st"])
+    assert got.shape == (prob["E"], m, prob["C"])
+    assert_close(got, ref, RTOL, "context encoder vs fp32 oracle")
+    # training-graph form: inputs already [E,m,.]
+    bo = np.tile(prob["cp_obs"][None], (prob["E"], 1, 1))
+    ba = np.tile(prob["cp_act"][None], (prob["E"], 1, 1))
+    got_bs = _np(eng.context_forward(bo, ba, bs=True))
+    np.testing.assert_array_equal(got_bs, got)
+
+
+CASES = [  # env, context, E, p, m, n, deterministic
+    ("halfcheetah", True, 5, 20, 1, 12, False),
+    ("halfcheetah", True, 5, 10, 3, 7, False),      # ragged: rows/member = 42 (tail tile), m > 1
+    ("halfcheetah", False, 1, 1, 1, 50, True),      # cfg1-shaped vanilla deterministic
+    ("halfcheetah", False, 5, 5, 2, 9, False),      # vanilla PE-TS
+    ("slim_humanoid", True, 5, 20, 1, 6, False),
+    ("ant", True, 5, 5, 2, 11, False),
+    ("pendulum", True, 5, 5, 2, 8, False),
+    ("cartpole", True, 5, 5, 1, 9, False),
+    ("cripple_halfcheetah", True, 5, 5, 1, 5, False),
+]
+
+
+@pytest.mark.parametrize("env,context,E,p,m,n,det", CASES)
+def test_one_step_teacher_forced(gpu, env, context, E, p, m, n, det):
+    """Per-step parity: every row starts from its own random state, one step, compare the
+    next observation and the reward with the oracle (<= 1e-5 relative)."""
+    prob = synth.make_problem(env=env, context=context, E=E, m=m, H=1, trained_like=True, seed=11)
+    eng = make_engine(prob, p=p, H=1, deterministic=det)
+    rng = np.random.default_rng(5)
+    D, A = prob["D"], prob["A"]
+    obs_rows = rng.standard_normal((m, n, p, D))
+    actions = rng.uniform(-1, 1, (m, n, 1, A))
+    eps = rng.standard_normal((1, m, n, p, D))
+    ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"]) if context else None
+    rows, traj = eng.rollout_returns(prob["obs"], ctx, actions, eps=eps, obs_rows=obs_rows, want_traj=True)
+    for dt, tol in ((np.float32, RTOL), (np.float64, 4 * RTOL)):
+        o = oracle_problem(prob, dt)
+        T = None
+        if context:
+            octx = onets.context_forward(o["cp"], o["cp_obs"], o["cp_act"], o["st"])
+            T = oplanner.context_table_indexed(octx, 0)
+        r_ref, t_ref = oplanner.rollout_indexed(o["env"], o["ff"], o["st"], o["obs"], T, actions.astype(dt),
+                                                eps.astype(dt), E, p, det, obs_rows=obs_rows.astype(dt),
+                                                return_traj=True)
+        assert_close(_np(traj), t_ref, tol, "next obs vs %s oracle" % dt.__name__)
+        assert_close(_np(rows), r_ref, tol, "reward vs %s oracle" % dt.__name__)
+
+
+@pytest.mark.parametrize("env,context,E,p,m,n,det", CASES[:5])
+def test_horizon_rollout(gpu, env, context, E, p, m, n, det):
+    """Whole-horizon recurrence with injected noise: returns and the full trajectory against
+    the fp32 oracle, and drift against fp64 truth in the same band as the fp32 oracle's own."""
+    H = 30
+    prob = synth.make_problem(env=env, context=context, E=E, m=m, H=H, seed=2)
+    eng = make_engine(prob, p=p, deterministic=det)
+    rng = np.random.default_rng(9)
+    actions = rng.uniform(-1, 1, (m, n, H, prob["A"]))
+    eps = rng.standard_normal((H, m, n, p, prob["D"]))
+    ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"]) if context else None
+    for it in (0, 1):   # odd iteration exercises quirk Q2 when m > 1
+        rows, traj = eng.rollout_returns(prob["obs"], ctx, actions, eps=eps, it=it, want_traj=True)
+        res = {}
+        for dt in (np.float32, np.float64):
+            o = oracle_problem(prob, dt)
+            T = None
+            if context:
+                octx = onets.context_forward(o["cp"], o["cp_obs"], o["cp_act"], o["st"])
+                T = oplanner.context_table_indexed(octx, it)
+            res[dt] = oplanner.rollout_indexed(o["env"], o["ff"], o["st"], o["obs"], T, actions.astype(dt),
+                                               eps.astype(dt), E, p, det, return_traj=True)
+        e_hip = rel_err(_np(traj), res[np.float64][1])
+        e_o32 = rel_err(res[np.float32][1], res[np.float64][1])
+        print("\n[%s it=%d] trajectory drift vs fp64: hip %.2e, fp32 oracle %.2e; returns: hip %.2e, fp32 oracle %.2e"
+              % (env, it, e_hip, e_o32, rel_err(_np(rows), res[np.float64][0]),
+                 rel_err(res[np.float32][0], res[np.float64][0])))
+        assert e_hip <= max(8 * e_o32, 2e-5), "HIP drift %.2e outside the fp32 band (oracle32 %.2e)" % (e_hip, e_o32)
+        assert rel_err(_np(rows), res[np.float32][0]) <= max(8 * e_o32, 2e-5)
+
+
+def test_quirks_off_uses_own_member_context(gpu):
+    prob = synth.make_problem(env="halfcheetah", E=5, m=2, H=3, trained_like=True, seed=4)
+    p, n = 10, 6
+    eng = make_engine(prob, p=p, quirks=False)
+    rng = np.random.default_rng(1)
+    actions = rng.uniform(-1, 1, (2, n, 3, 6))
+    eps = rng.standard_normal((3, 2, n, p, 18))
+    ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"])
+    rows = eng.rollout_returns(prob["obs"], ctx, actions, eps=eps, it=1)
+    o = oracle_problem(prob, np.float32)
+    octx = onets.context_forward(o["cp"], o["cp_obs"], o["cp_act"], o["st"])
+    ref = oplanner.rollout_indexed(o["env"], o["ff"], o["st"], o["obs"], None, actions.astype(np.float32),
+                                   eps.astype(np.float32), 5, p, False,
+                                   ctx_rows=oplanner.context_rows_fixed(octx, p))
+    assert_close(_np(rows), ref, 4 * RTOL, "quirk-free context layout")
+
+
+def test_sample_and_refit(gpu):
+    prob = synth.make_problem(env="halfcheetah", m=2, H=30, seed=6)
+    eng = make_engine(prob, p=5)
+    rng = np.random.default_rng(3)
+    m, n, H, A = 2, 200, 30, 6
+    mean = rng.uniform(-0.9, 0.9, (m, H, A)).astype(np.float32)
+    var = rng.uniform(0.01, 0.3, (m, H, A)).astype(np.float32)
+    z = trunc_z(rng, (m, n, H, A)).astype(np.float32)
+    acts = eng.sample_actions(mean, var, n, z=z)
+    ref = oplanner.sample_actions(mean, var, z)
+    assert_close(_np(acts), ref, 1e-6, "sample_actions")
+    cand = rng.standard_normal((m, n)).astype(np.float32)
+    cand[0, 17] = cand[0, 3]          # exact ties: lower index first
+    cand[1, 150] = cand[1, 20] = cand[1, 99]
+    mean_t, var_t = eng._t(mean).clone(), eng._t(var).clone()
+    el = eng.cem_refit(eng._t(cand), eng._t(ref), mean_t, var_t, want_elites=True)
+    rm, rv, ridx = oplanner.elite_refit(mean, var, ref, cand)
+    np.testing.assert_array_equal(_np(el), ridx)       # integer/index work: bit exact
+    assert_close(_np(mean_t), rm, 1e-6, "refit mean")
+    assert_close(_np(var_t), rv, 1e-5, "refit var")
+    pm = eng.particle_mean(eng._t(rng.standard_normal((m, n, 5)).astype(np.float32)))
+    assert pm.shape == (m, n)
+
+
+def test_cem_plan_injected(gpu):
+    """Full CEM (5 iterations) with injected z / eps at m = 2 (exercises Q1 and Q2) against the
+    fp32 oracle."""
+    E, p, m, n, H = 5, 10, 2, 64, 8
+    prob = synth.make_problem(env="halfcheetah", E=E, m=m, H=H, seed=8)
+    eng = make_engine(prob, p=p)
+    rng = np.random.default_rng(12)
+    z = trunc_z(rng, (5, m, n, H, 6)).astype(np.float32)
+    eps = rng.standard_normal((5, H, m, n, p, 18)).astype(np.float32)
+    plan, info, ctx = hplanner.cem_plan(eng, prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"],
+                                        prob["init_var"], n, z=eng._t(z), eps=eng._t(eps), return_info=True)
+    o = oracle_problem(prob, np.float32)
+    ref, rinfo, rctx = oplanner.cem_plan(o["env"], o["ff"], o["cp"], o["st"], o["obs"], o["cp_obs"], o["cp_act"],
+                                         o["init_mean"], o["init_var"], z, eps, E, p, formulation="literal",
+                                         return_info=True)
+    assert_close(_np(ctx), rctx, RTOL, "context")
+    for it in range(5):
+        np.testing.assert_array_equal(np.sort(_np(info[it]["elites"]), axis=1), np.sort(rinfo[it]["elites"], axis=1),
+                                      err_msg="elite set differs at CEM iteration %d" % it)
+        assert_close(_np(info[it]["cand"])[0], rinfo[it]["cand_returns"], 1e-4, "candidate returns it=%d" % it)
+    assert_close(_np(plan), oplanner.get_action_clip(ref), 1e-4, "final CEM plan")
+
+
+def test_device_rng_matches_oracle_streams(gpu):
+    """On-device Philox draws equal the oracle's stream layout (integers bit-exact by
+    construction; Box-Muller transcendental ulps allowed: 2e-6 absolute on |z| <= ~5)."""
+    prob = synth.make_problem(env="halfcheetah", m=2, H=5, seed=1)
+    p, n = 5, 33
+    eng = make_engine(prob, p=p, H=5)
+    mean = np.zeros((2, 5, 6), np.float32)
+    var = np.ones((2, 5, 6), np.float32)   # constrained var = 0.25 -> actions = 0.5 z
+    acts = _np(eng.sample_actions(mean, var, n, seed=123, call=7, it=3))
+    zref = ophilox.truncated_normals(123, 7, 3, 2, n, 5, 6)
+    assert np.abs(acts / 0.5).max() < 2.0
+    np.testing.assert_allclose(acts / 0.5, zref, rtol=0, atol=4e-6)
+    # Gaussian-head noise: device-drawn vs injected oracle stream, incl. a candidate shard
+    ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"])
+    a = np.random.default_rng(0).uniform(-1, 1, (2, n, 5, 6))
+    for lo, hi in ((0, n), (11, 22)):
+        eps = ophilox.eps_normals(123, 7, 2, 2, n, p, 5, 18, cand_lo=lo, cand_hi=hi)
+        r_dev = eng.rollout_returns(prob["obs"], ctx, a, seed=123, call=7, it=2, cand_offset=lo, n_local=hi - lo)
+        r_inj = eng.rollout_returns(prob["obs"], ctx, a, eps=eps, it=2, cand_offset=lo, n_local=hi - lo)
+        assert_close(_np(r_dev), _np(r_inj), 1e-4, "device eps vs injected oracle eps [%d,%d)" % (lo, hi))
+
+
+def test_fused_plan_equals_stepwise(gpu):
+    """cadm_cem_plan (one C call) == the per-iteration python orchestration, bit for bit."""
+    prob = synth.make_problem(env="halfcheetah", m=2, H=10, seed=5)
+    eng = make_engine(prob, p=10, H=10)
+    a = eng.cem_plan(prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], 100, seed=9, call=4)
+    b = hplanner.cem_plan(eng, prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], 100,
+                          seed=9, call=4)
+    np.testing.assert_array_equal(_np(a), _np(b))
+    assert np.abs(_np(a)).max() <= 1.0
+
+
+def test_random_shooting(gpu):
+    E, p, m, n, H = 5, 5, 2, 40, 6
+    prob = synth.make_problem(env="halfcheetah", E=E, m=m, H=H, seed=13)
+    eng = make_engine(prob, p=p)
+    rng = np.random.default_rng(2)
+    acts = rng.uniform(-1, 1, (m, n, H, 6)).astype(np.float32)
+    eps = rng.standard_normal((H, m, n, p, 18)).astype(np.float32)
+    first, cand = hplanner.rs_plan(eng, prob["obs"], prob["cp_obs"], prob["cp_act"], n, actions=acts, eps=eng._t(eps))
+    o = oracle_problem(prob, np.float32)
+    rfirst, rcand = oplanner.rs_plan(o["env"], o["ff"], o["cp"], o["st"], o["obs"], o["cp_obs"], o["cp_act"], acts, eps, E, p)
+    assert_close(_np(cand)[0], rcand, 1e-4, "RS candidate returns")
+    np.testing.assert_array_equal(_np(first), np.clip(rfirst, -1, 1))
+    # device-drawn RS stays in range and is reproducible
+    a1 = _np(eng.rs_plan(prob["obs"], prob["cp_obs"], prob["cp_act"], n, seed=1, call=1))
+    a2 = _np(eng.rs_plan(prob["obs"], prob["cp_obs"], prob["cp_act"], n, seed=1, call=1))
+    np.testing.assert_array_equal(a1, a2)
+    assert a1.shape == (m, 6) and np.abs(a1).max() <= 1.0
+    u = _np(eng.sample_uniform(m, n, seed=4, call=2)[0])
+    np.testing.assert_allclose(u, ophilox.rs_uniforms(4, 2, m, n, H, 6), rtol=0, atol=1e-7)
+
+
+def test_random_shooting_discrete(gpu):
+    E, p, m, n, H = 5, 5, 2, 30, 5
+    prob = synth.make_problem(env="cartpole", E=E, m=m, H=H, seed=3, trained_like=True)
+    eng = make_engine(prob, p=p)
+    rng = np.random.default_rng(4)
+    raw = rng.integers(0, 2, (m, n, H))
+    onehot = np.eye(2, dtype=np.float32)[raw]
+    eps = rng.standard_normal((H, m, n, p, 4)).astype(np.float32)
+    best_a, cand = hplanner.rs_plan(eng, prob["obs"], prob["cp_obs"], prob["cp_act"], n, actions=onehot, raw=raw,
+                                    eps=eng._t(eps))
+    o = oracle_problem(prob, np.float32)
+    rbest, rcand = oplanner.rs_plan(o["env"], o["ff"], o["cp"], o["st"], o["obs"], o["cp_obs"], o["cp_act"], onehot,
+                                    eps, E, p, raw_actions=raw)
+    assert_close(_np(cand)[0], rcand, 1e-4, "discrete RS candidate returns")
+    np.testing.assert_array_equal(_np(best_a), rbest)
+    out = _np(eng.rs_plan(prob["obs"], prob["cp_obs"], prob["cp_act"], n, seed=2, call=3))
+    assert out.shape == (m,) and set(np.unique(out)) <= {0, 1}
