@@ -31,10 +31,33 @@ def flops_per_row_step(K0, hid, D, n_hidden):
     return 2 * (K0 * hid + (n_hidden - 1) * hid * hid + hid * 2 * D)
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the host's cores, which oversubscribes a quota-limited container)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = float(txt[0])
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(prob, n, p, budget_s=20.0):
     """Op-for-op torch-CPU restatement of the TF1.15 graph on this node's host cores."""
     from oracle import torch_baseline as tb
-    cores = os.cpu_count() or 1
+    cores = min(usable_cores(), 64)   # [5,800,200] batched matmuls stop scaling long before 64 threads
     torch.set_num_threads(cores)
     tp = tb.prepare(prob)
     torch.manual_seed(0)

@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcadm_hip.so")
+LIB_PATH = os.environ.get("CADM_HIP_LIB") or os.path.join(_HERE, "libcadm_hip.so")   # env override: developer builds (timing)
 CSRC = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 1
@@ -76,6 +76,7 @@ SIGNATURES = {
     "cadm_train_reset": (_i, [_P, _P]),
     "cadm_profile_enable": (_i, [_P, _i]),
     "cadm_profile_read": (_i, [_P, C.POINTER(C.c_float), C.POINTER(_i)]),
+    "cadm_debug_set_timing_buffer": (_i, [_P, _P]),
 }
 
 _lib = None

@@ -27,6 +27,9 @@ static LayerGeo make_geo(int K, int ntiles, int head, int nout) {
     g.nso = ntiles % 4;
     g.head = head;
     g.nout = nout;
+    // head layers whose tiles are all K-split use the chunk-split stream (rollout.hip CSPLIT) when the
+    // producer layer has exactly one K-split tile as its last chunk (HID % 64 in (0,16], e.g. 200)
+    g.csplit = (head && g.nfo == 0 && g.nso > 0 && (g.nch % 4) == 1) ? 1 : 0;
     return g;
 }
 
@@ -197,6 +200,12 @@ extern "C" int cadm_rollout_returns(cadm_ctx* ctx, const float* obs, const float
                              n_global, m, n_local, returns_rows, traj_out, (hipStream_t)stream);
     if (ctx->prof && rc == CADM_OK) CADM_CHECK_HIP(hipEventRecord(e1, (hipStream_t)stream));
     return rc;
+}
+
+extern "C" int cadm_debug_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf) {
+    CADM_REQUIRE(ctx, "cadm_debug_set_timing_buffer: null ctx");
+    ctx->tbuf = (unsigned long long*)dev_u64_buf;
+    return CADM_OK;
 }
 
 extern "C" int cadm_profile_enable(cadm_ctx* ctx, int enable) {

@@ -60,8 +60,10 @@ struct LayerGeo {
     int nfo, nso; // full tiles per wave / split tiles
     int head;     // 0: hidden-type outputs (HID units), 1: (mu,logvar) head tiles of 8 dims
     int nout;     // HID or D
-    size_t slot_floats() const { return (size_t)(nfo * 4 + nso) * 64; }
-    size_t wave_floats() const { return slot_floats() * nch; }
+    int csplit;   // 1: all tiles K-split by CHUNK (wave w owns chunks w, w+4, ..; float4 blocks), nfo == 0
+    int nslots() const { return csplit ? (nch + 3) / 4 : nch; }                 // chunk slots per wave
+    size_t slot_floats() const { return csplit ? (size_t)nso * 256 : (size_t)(nfo * 4 + nso) * 64; }
+    size_t wave_floats() const { return slot_floats() * nslots(); }
     size_t layer_floats() const { return wave_floats() * 4; }
     size_t bias_floats() const { return (size_t)ntiles * 256; }
 };
@@ -103,6 +105,7 @@ struct cadm_ctx {
     bool prof = false;
     std::vector<hipEvent_t> prof_ev;   // start/stop pairs
     size_t prof_used = 0;
+    unsigned long long* tbuf = nullptr;   // cadm_debug_set_timing_buffer
 };
 
 // kernels' host launchers (one per translation unit)
@@ -138,12 +141,10 @@ __device__ __forceinline__ float u01(uint32_t x) {
 }
 
 __device__ __forceinline__ void box_muller(float u1, float u2, float& z0, float& z1) {
-    const float r = sqrtf(-2.0f * logf(u1));
-    const float th = 6.283185307179586f * u2;
-    float s, c;
-    sincosf(th, &s, &c);
-    z0 = r * c;
-    z1 = r * s;
+    // hardware transcendentals: v_log_f32, v_sqrt_f32, v_cos_f32 / v_sin_f32 (argument in revolutions)
+    const float r = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1));
+    z0 = r * __builtin_amdgcn_cosf(u2);
+    z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
 // tf.nn.softplus (TF 1.15 Eigen functor): threshold = log(eps) + 2
@@ -158,5 +159,5 @@ __device__ __forceinline__ float tf_softplus(float x) {
 // swish(x) = x * sigmoid(x) (dynamics.py:23); v_exp_f32 / v_rcp_f32 based, ~3 ulp
 __device__ __forceinline__ float swish_f(float x) {
     const float e = __expf(-x);
-    return x * __frcp_rn(1.0f + e);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }

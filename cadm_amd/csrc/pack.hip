@@ -22,9 +22,10 @@ __device__ __forceinline__ int out_unit(int head, int tile, int i, int nout, int
 // one thread per stream float of one layer (all members)
 __global__ void pack_layer_kernel(const float* __restrict__ W, const float* __restrict__ W2,
                                   float* __restrict__ dst, size_t dst_member_stride, int E, int K,
-                                  int nout, int nch, int nfo, int nso, int head) {
-    const size_t slot = (size_t)(nfo * 4 + nso) * 64;
-    const size_t wavef = slot * nch;
+                                  int nout, int nch, int nfo, int nso, int head, int csplit) {
+    const int nslots = csplit ? (nch + 3) / 4 : nch;
+    const size_t slot = csplit ? (size_t)nso * 256 : (size_t)(nfo * 4 + nso) * 64;
+    const size_t wavef = slot * nslots;
     const size_t layerf = wavef * 4;
     const size_t total = layerf * E;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total;
@@ -33,10 +34,15 @@ __global__ void pack_layer_kernel(const float* __restrict__ W, const float* __re
         size_t rem = idx % layerf;
         const int w = rem / wavef;
         rem %= wavef;
-        const int c = rem / slot;
+        int c = rem / slot;
         rem %= slot;
         int tile, lane, r;
-        if (rem < (size_t)nfo * 256) {
+        if (csplit) {                      // slot j of wave w = chunk w + 4j, float4 blocks per tile
+            c = w + 4 * c;
+            tile = rem / 256;
+            lane = (rem % 256) / 4;
+            r = rem % 4;
+        } else if (rem < (size_t)nfo * 256) {
             const int blk = rem / 256;
             lane = (rem % 256) / 4;
             r = rem % 4;
@@ -52,7 +58,7 @@ __global__ void pack_layer_kernel(const float* __restrict__ W, const float* __re
         int is_lv;
         const int u = out_unit(head, tile, lane & 15, nout, &is_lv);
         float v = 0.0f;
-        if (fin < K && u >= 0) {
+        if (c < nch && fin < K && u >= 0) {
             const float* src = is_lv ? W2 : W;
             v = src[((size_t)e * K + fin) * nout + u];
         }
@@ -100,7 +106,7 @@ int cadm_pack_streams(cadm_ctx* ctx, hipStream_t s) {
         const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(pack_layer_kernel, dim3(grid), dim3(256), 0, s, a.W, a2 ? a2->W : nullptr,
                            ctx->wstream + woff, ctx->wstream_member_floats, E, g.K, g.nout, g.nch,
-                           g.nfo, g.nso, g.head);
+                           g.nfo, g.nso, g.head, g.csplit);
         const size_t btotal = g.bias_floats() * E;
         const int bgrid = (int)((btotal + 255) / 256);
         hipLaunchKernelGGL(pack_bias_kernel, dim3(bgrid), dim3(256), 0, s, a.b, a2 ? a2->b : nullptr,

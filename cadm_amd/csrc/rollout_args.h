@@ -1,0 +1,19 @@
+// Argument block of the rollout kernel (shared by the host launcher and the kernel TUs).
+#pragma once
+#include "common.h"
+
+struct RolloutArgs {
+    const float *wstream, *bstream;
+    unsigned wbytes;                  // size of the whole weight stream buffer (all members)
+    unsigned wmember_b;               // bytes per member
+    unsigned w_l0_b, w_lh_b, w_lo_b;  // layer stream sizes (bytes): L0, hidden, OUT
+    size_t bmember;                   // bias floats per member
+    size_t b_l0, b_lh;                // bias tile sizes (floats): L0/hidden, (OUT follows)
+    const float *obs, *obs_rows, *ctx_vec, *actions, *eps;
+    const float *obs_mean, *obs_std, *act_mean, *act_std, *delta_mean, *delta_std, *maxlv, *minlv;
+    float *returns_rows, *traj;
+    int m, n_local, n_global, cand_offset, E, p, PE, H, NH, it, quirks, deterministic, norm_actions;
+    uint32_t seed, call;
+    int wgs_per_member, rows_per_member;
+    unsigned long long* tbuf;   // CADM_PHASE_TIMING builds only
+};

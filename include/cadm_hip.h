@@ -200,6 +200,10 @@ int cadm_train_reset(cadm_ctx* ctx, void* stream);
  * since the last read, and resets both. */
 int cadm_profile_enable(cadm_ctx* ctx, int enable);
 int cadm_profile_read(cadm_ctx* ctx, float* total_ms_out, int* launches_out);
+/* Developer aid: device buffer of 4*24 uint64 that the CADM_PHASE_TIMING build of the rollout
+ * kernel (make -C cadm_amd/csrc timing) fills with per-phase s_memtime sums of workgroup 0.
+ * Ignored by the production build. */
+int cadm_debug_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of the rollout kernel (workgroup 0) using the CADM_PHASE_TIMING build.
+   make -C cadm_amd/csrc timing && CADM_HIP_LIB=cadm_amd/libcadm_hip_timing.so python tools/phase_timing.py [cfg]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ctypes as ct
+
+import numpy as np
+import torch
+
+from cadm_amd import synth
+from cadm_amd._lib import check
+from helpers import make_engine
+
+NAMES = ["assembly", "bar0", "L0 mfma", "L0 epi", "bar1", "hid rebuild", "hid mfma", "hid epi", "hid bar",
+         "out noise", "out rebuild", "out mfma", "out part wr", "bar5", "head epi", "bar6"]
+
+
+def main():
+    cfgname = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+    cfg = synth.CONFIGS[cfgname]
+    prob = synth.make_problem(env=cfg["env"], context=cfg["context"], E=cfg["E"], m=1, H=cfg["H"], seed=0)
+    eng = make_engine(prob, p=cfg["p"], deterministic=cfg["deterministic"])
+    tbuf = torch.zeros(4 * 24, dtype=torch.int64, device=eng.device)
+    check(eng.lib.cadm_debug_set_timing_buffer(eng._ctx, ct.c_void_p(tbuf.data_ptr())))
+    n = cfg["n"]
+    mean, var = eng._t(prob["init_mean"]), eng._t(prob["init_var"])
+    ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"]) if cfg["context"] else None
+    acts = eng.sample_actions(mean, var, n, seed=1, call=1, it=0)
+    for _ in range(3):
+        eng.rollout_returns(prob["obs"], ctx, acts, seed=1, call=1)
+    torch.cuda.synchronize()
+    t = tbuf.cpu().numpy().reshape(4, 24)[:, :len(NAMES)].astype(np.float64) / cfg["H"]
+    print("cycles per step (s_memtime ticks), workgroup 0, per wave:")
+    print("%-14s %9s %9s %9s %9s" % ("phase", "wave0", "wave1", "wave2", "wave3"))
+    for i, nm in enumerate(NAMES):
+        print("%-14s %9.0f %9.0f %9.0f %9.0f" % (nm, *t[:, i]))
+    print("%-14s %9.0f %9.0f %9.0f %9.0f" % ("TOTAL", *t.sum(1)))
+
+
+if __name__ == "__main__":
+    main()
