@@ -120,9 +120,27 @@ template <int ENV> __device__ __forceinline__ float reward_part(int dp, float o0
 // ---------------------------------------------------------------------------------------------
 // fast scalar math for the per-row head (absolute error ~1e-7 on logvar, see DESIGN.md numerics)
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sincos_cw(float x, float* sn, float* cs) {
+    const float k = rintf(x * 0.63661977236758134f);                       // x / (pi/2)
+    float r = fmaf(-k, 1.5707962513e+00f, x);                              // pi/2 split in three parts
+    r = fmaf(-k, 7.5497894159e-08f, r);
+    r = fmaf(-k, 5.3903029534e-15f, r);
+    const float z = r * r;                                                 // cephes sinf / cosf minimax on [-pi/4, pi/4]
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    ps = fmaf(ps * z, r, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    pc = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k;
+    const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+    *sn = (q & 2) ? -s0 : s0;
+    *cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
 __device__ __forceinline__ float softplus_fast(float x) {     // tf.nn.softplus thresholds (+-13.94)
     const float ex = __expf(fminf(x, 20.0f));
-    const float mid = __logf(1.0f + ex);
+    const float mid = __builtin_amdgcn_logf(1.0f + ex) * 0.69314718055994531f;   // v_log_f32 is log2
     const float lo = x < -13.942385f ? ex : mid;
     return x > 13.942385f ? x : lo;
 }
@@ -327,8 +345,10 @@ template <int R0, int R1>
 __device__ __forceinline__ void philox_rounds(uint32_t (&c)[4], uint32_t (&k)[2]) {
 #pragma unroll
     for (int r = R0; r < R1; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c[1] ^ k[0], n2 = hi0 ^ c[3] ^ k[1];
         c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
         k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
@@ -533,7 +553,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
                         for (int h = 0; h < 2; ++h) {
                             float sn = 0.0f, cs = 0.0f;
                             if constexpr (ENV == CADM_ENV_HALFCHEETAH) {                 // the one trig pair (obs dim 2)
-                                if (fx_op[pi][h][0] != 0) sincosf(po[mt][pi][h], &sn, &cs);
+                                if (fx_op[pi][h][0] != 0) sincos_cw(po[mt][pi][h], &sn, &cs);
                             }
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {
@@ -603,51 +623,54 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
         // producer's K-split tiles: sum the 4 partials, activate.  Loads are issued one chunk before the
         // arithmetic; the per-wave k-step select is a masked sum (branch-free, weaves into the MFMA shadow).
         floatx4 rb[MT][cmax(NS, 1)][4];
-        auto rebuild_load = [&]() {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-#pragma unroll
-                    for (int w = 0; w < 4; ++w)
-                        rb[mt][s][w] = *reinterpret_cast<const floatx4*>(part_in + (((mt * NS + s) * 4 + w) * 64 + lane) * 4);
-        };
-        auto rebuild_finish = [&]() {
+        floatx4 rv[MT][cmax(NS, 1)];
+        auto rebuild_step = [&](int part) {     // 0: issue LDS reads, 1: sum, 2: activate r=0,1, 3: r=2,3, 4: k-step select
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    floatx4 v = ((rb[mt][s][0] + rb[mt][s][1]) + rb[mt][s][2]) + rb[mt][s][3];
+                    if (part == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = swish_f(v[r]);
-                    bsplit[mt][s] = v;
-                    bsplit_sel[mt][s] = ((v[0] * wsel[0] + v[1] * wsel[1]) + v[2] * wsel[2]) + v[3] * wsel[3];
+                        for (int w = 0; w < 4; ++w)
+                            rb[mt][s][w] = *reinterpret_cast<const floatx4*>(part_in + (((mt * NS + s) * 4 + w) * 64 + lane) * 4);
+                    } else if (part == 1) {
+                        rv[mt][s] = ((rb[mt][s][0] + rb[mt][s][1]) + rb[mt][s][2]) + rb[mt][s][3];
+                    } else if (part == 2) {
+                        rv[mt][s][0] = swish_f(rv[mt][s][0]);
+                        rv[mt][s][1] = swish_f(rv[mt][s][1]);
+                    } else if (part == 3) {
+                        rv[mt][s][2] = swish_f(rv[mt][s][2]);
+                        rv[mt][s][3] = swish_f(rv[mt][s][3]);
+                        bsplit[mt][s] = rv[mt][s];
+                    } else {
+                        const floatx4 v = rv[mt][s];
+                        bsplit_sel[mt][s] = ((v[0] * wsel[0] + v[1] * wsel[1]) + v[2] * wsel[2]) + v[3] * wsel[3];
+                    }
                 }
         };
         // Gaussian-head noise of THIS step for this thread's pairs, generated in the MFMA shadow of
-        // the head pass (Philox4x32-10 in two halves + Box-Muller), or fetched from the injected eps.
+        // the head pass (Philox4x32-10 round by round + Box-Muller), or fetched from the injected eps.
         uint32_t pc[MT][NPI][4], pk[MT][NPI][2];
-        auto noise_part = [&](int part) {
+        auto noise_part = [&](auto part_c) {    // 0: setup + load (inject), 1..10: one Philox round each, 11: Box-Muller
+            constexpr int part = decltype(part_c)::value;
             if constexpr (NOISE == CADM_NOISE_NONE) return;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int pi = 0; pi < NPI; ++pi) {
                     const int dp = fg + 16 * pi;
-                    const bool on = dp < NP;
                     if constexpr (NOISE == CADM_NOISE_INJECT) {
-                        if (part == 0 && on) {
+                        if (part == 0 && dp < NP) {
                             const float* ep = a.eps + ((size_t)t * a.m * a.n_local * a.p + lr[mt]) * D + 2 * dp;
                             pz[mt][pi][0] = ep[0];
                             pz[mt][pi][1] = (2 * dp + 1 < D) ? ep[1] : 0.0f;
                         }
-                    } else if (part == 0) {             // branch-free: idle slots draw a value nobody reads
+                    } else if constexpr (part == 0) {   // branch-free: idle slots draw a value nobody reads
                         pc[mt][pi][0] = grow[mt]; pc[mt][pi][1] = (uint32_t)t; pc[mt][pi][2] = (uint32_t)dp;
                         pc[mt][pi][3] = CADM_STREAM_EPS | ((uint32_t)a.it << 8);
                         pk[mt][pi][0] = a.seed; pk[mt][pi][1] = a.call;
-                        philox_rounds<0, 5>(pc[mt][pi], pk[mt][pi]);
-                    } else if (part == 1) {
-                        philox_rounds<5, 10>(pc[mt][pi], pk[mt][pi]);
+                    } else if constexpr (part <= 10) {
+                        philox_rounds<part - 1, part>(pc[mt][pi], pk[mt][pi]);
                     } else {
                         box_muller(u01(pc[mt][pi][0]), u01(pc[mt][pi][1]), pz[mt][pi][0], pz[mt][pi][1]);
                     }
@@ -680,17 +703,17 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
             load_bias(bmem + a.b_l0 + (size_t)(l - 1) * a.b_lh);
             auto side = [&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                if constexpr (j == 0) rebuild_load();
-                if constexpr (j == 1) rebuild_finish();
+                if constexpr (j == 0) rebuild_step(0);
+                if constexpr (j == 1) { rebuild_step(1); rebuild_step(2); rebuild_step(3); rebuild_step(4); }
             };
             TS(5)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) { zero_acc(accF[mt]); zero_acc(accS[mt]); }
             if constexpr (!LAST) {
-                mfma_pass<G, NT, G::KSLH, NF, NS, NT, NF, NS, NS, 2u>(ring, rsrc, wc, wc + a.w_lh_b, act_in, bsplit, bsplit_sel,
+                mfma_pass<G, NT, G::KSLH, NF, NS, NT, NF, NS, NS, 0x2u>(ring, rsrc, wc, wc + a.w_lh_b, act_in, bsplit, bsplit_sel,
                                                                      accF, accS, wave, lane, side);
             } else {
-                mfma_pass<G, NT, G::KSLH, NF, NS, G::OX_NCH, G::OX_NFO, G::OX_NSO, NS, 2u>(ring, rsrc, wc, wo, act_in, bsplit,
+                mfma_pass<G, NT, G::KSLH, NF, NS, G::OX_NCH, G::OX_NFO, G::OX_NSO, NS, 0x2u>(ring, rsrc, wc, wo, act_in, bsplit,
                                                                                           bsplit_sel, accF, accS, wave, lane, side);
             }
             TS(6)
@@ -719,18 +742,21 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
         if constexpr (G::OCS) {
             auto side = [&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                if constexpr (j == 0) { rebuild_load(); rebuild_finish(); }
-                if constexpr (j >= 1 && j <= 3) noise_part(j - 1);
+                auto np = [&](auto... ps) { (noise_part(std::integral_constant<int, decltype(ps)::value>{}), ...); };
+                using std::integral_constant;
+                if constexpr (j == 0) { rebuild_step(0); np(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{}); }
+                if constexpr (j == 1) { rebuild_step(1); rebuild_step(2); rebuild_step(3); np(integral_constant<int, 4>{}, integral_constant<int, 5>{}, integral_constant<int, 6>{}); }
+                if constexpr (j == 2) np(integral_constant<int, 7>{}, integral_constant<int, 8>{}, integral_constant<int, 9>{}, integral_constant<int, 10>{});
+                if constexpr (j == 3) np(integral_constant<int, 11>{});
             };
             head_pass_csplit<G, NC0, NF, NS, 0xFu>(ring, rsrc, wo, w0, act_in, bsplit, hS, wave, lane, side);
         } else {
             auto side = [&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                if constexpr (j == 0) rebuild_load();
-                if constexpr (j == 1) rebuild_finish();
-                if constexpr (j == 3 || j == 5 || j == 7) noise_part((j - 3) / 2);
+                if constexpr (j <= 4) rebuild_step(j);
+                if constexpr (j >= 1 && j <= 12) noise_part(std::integral_constant<int, j - 1>{});
             };
-            mfma_pass<G, NT, G::KSLH, NFO, NSO, NC0, NF, NS, NS, 0xAAu>(ring, rsrc, wo, w0, act_in, bsplit, bsplit_sel, hF, hS, wave,
+            mfma_pass<G, NT, G::KSLH, NFO, NSO, NC0, NF, NS, NS, 0x1FFEu>(ring, rsrc, wo, w0, act_in, bsplit, bsplit_sel, hF, hS, wave,
                                                                  lane, side);
         }
         TS(11)
