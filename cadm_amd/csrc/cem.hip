@@ -110,10 +110,25 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, int G, int n_lo
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);
     const int mi = blockIdx.x;
     const int n = G * n_local;
-    for (int i = threadIdx.x; i < npow2; i += blockDim.x)
-        keys[i] = i < n ? make_key(cand_at(cand, G, n_local, m, mi, i), (uint32_t)i) : ~0ull;
-    __syncthreads();
-    bitonic_sort_lds(keys, npow2);                                                 // tf.nn.top_k, :475
+    if (n <= 2048) {
+        // small n: every candidate's rank by counting (keys are unique: index in the low word); the K best
+        // land sorted in keys[0..K) with one barrier instead of the O(log^2 n) barriers of the bitonic sort
+        uint64_t* raw = keys + npow2;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) raw[i] = make_key(cand_at(cand, G, n_local, m, mi, i), (uint32_t)i);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint64_t ki = raw[i];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += raw[j] < ki ? 1 : 0;
+            if (rank < K) keys[rank] = ki;
+        }
+        __syncthreads();
+    } else {
+        for (int i = threadIdx.x; i < npow2; i += blockDim.x)
+            keys[i] = i < n ? make_key(cand_at(cand, G, n_local, m, mi, i), (uint32_t)i) : ~0ull;
+        __syncthreads();
+        bitonic_sort_lds(keys, npow2);                                             // tf.nn.top_k, :475
+    }
     if (elites_out)
         for (int k = threadIdx.x; k < K; k += blockDim.x) elites_out[(size_t)mi * K + k] = (int32_t)(keys[k] & 0xFFFFFFFFu);
     const int HA = H * A;
@@ -223,7 +238,7 @@ extern "C" int cadm_cem_refit(cadm_ctx* ctx, const float* cand_returns, int G, i
                  n, ctx->cfg.num_elites);
     int npow2 = 1;
     while (npow2 < n) npow2 <<= 1;
-    const size_t lds = (size_t)npow2 * sizeof(uint64_t);
+    const size_t lds = (size_t)npow2 * sizeof(uint64_t) * (n <= 2048 ? 2 : 1);
     CADM_REQUIRE(lds <= 128 * 1024, "cadm_cem_refit: n_candidates %d exceeds the in-LDS sort capacity (16384)", n);
     static bool attr_set = false;
     if (!attr_set) {

@@ -36,20 +36,53 @@ __global__ __launch_bounds__(256) void context_kernel(const CpArgs a) {
         const int K = a.dims[l], N = a.dims[l + 1];
         const float* W = a.W[l] + (size_t)e * K * N;
         const float* b = a.b[l] + (size_t)e * N;
-        // thread (kq = tid>>6, lane = tid&63): columns lane, lane+64, ...; K range split in 4 contiguous quarters
+        // thread (kq = tid >> 6, lane = tid & 63): 4 consecutive columns per lane (float4 weight loads when
+        // N % 4 == 0), K split in 4 contiguous quarters across the waves, partials reduced through LDS.
         const int kq = tid >> 6, lane = tid & 63;
         const int k0 = (K * kq) / 4, k1 = (K * (kq + 1)) / 4;
-        for (int nb = 0; nb < N; nb += 64) {
-            const int n = nb + lane;
-            float acc = 0.0f;
-            if (n < N)
-                for (int k = k0; k < k1; ++k) acc = fmaf(xin[k], W[(size_t)k * N + n], acc);
-            red[kq][lane] = acc;
+        const bool vec = (N & 3) == 0;
+        for (int nb = 0; nb < N; nb += 256) {
+            const int n = nb + lane * 4;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (n < N) {
+                if (vec) {
+                    int k = k0;
+                    for (; k + 8 <= k1; k += 8) {
+                        floatx4 w[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const floatx4*>(W + (size_t)(k + u) * N + n);
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const float xv = xin[k + u];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[c] = fmaf(xv, w[u][c], acc[c]);
+                        }
+                    }
+                    for (; k < k1; ++k) {
+                        const floatx4 w = *reinterpret_cast<const floatx4*>(W + (size_t)k * N + n);
+                        const float xv = xin[k];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[c] = fmaf(xv, w[c], acc[c]);
+                    }
+                } else {
+                    for (int k = k0; k < k1; ++k) {
+                        const float xv = xin[k];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (n + c < N) acc[c] = fmaf(xv, W[(size_t)k * N + n + c], acc[c]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[kq][lane * 4 + c] = acc[c];
             __syncthreads();
-            if (kq == 0 && n < N) {
-                float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane] + b[n];
-                if (l + 1 < a.nlayers) v = fmaxf(v, 0.0f);   // ReLU hidden (layers.py:34), identity output
-                xout[n] = v;
+            {
+                const int nn = nb + tid;
+                if (nn < N) {
+                    float v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid] + b[nn];
+                    if (l + 1 < a.nlayers) v = fmaxf(v, 0.0f);   // ReLU hidden (layers.py:34), identity output
+                    xout[nn] = v;
+                }
             }
             __syncthreads();
         }
