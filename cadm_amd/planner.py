@@ -39,9 +39,10 @@ def gather_cand_returns(cand_local, shard):
     if shard.world == 1:
         return cand_local.unsqueeze(0)
     import torch.distributed as dist
-    out = torch.empty((shard.world,) + tuple(cand_local.shape), dtype=cand_local.dtype, device=cand_local.device)
+    m, nl = cand_local.shape
+    out = torch.empty((shard.world * m, nl), dtype=cand_local.dtype, device=cand_local.device)   # concatenated layout
     dist.all_gather_into_tensor(out, cand_local.contiguous(), group=shard.group)
-    return out
+    return out.view(shard.world, m, nl)
 
 
 def cem_plan(engine, obs, cp_obs, cp_act, init_mean, init_var, n, seed=0, call=0, z=None, eps=None,

@@ -1,0 +1,81 @@
+"""CPU, world_size 2, gloo: the candidate-sharded planner (one all-gather of per-candidate returns per
+CEM iteration) equals the unsharded planner exactly; exercised through cadm_amd.planner with the
+oracle-backed engine stand-in (the HIP engine needs a GPU)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cadm_amd import planner as hplanner
+    from cadm_amd import synth
+    from helpers import oracle_problem
+    from oracle_engine import OracleEngine
+    torch.set_num_threads(1)
+    E, p, m, n, H = 5, 5, 2, 64, 4
+    prob = synth.make_problem(env="halfcheetah", E=E, m=m, H=H, seed=7)
+    eng = OracleEngine(oracle_problem(prob, np.float32), prob, p, H, num_elites=16)
+    shard = hplanner.Shard.from_dist(n)
+    assert (shard.world, shard.rank, shard.n_local, shard.offset) == (world, rank, n // world, rank * (n // world))
+    plan = hplanner.cem_plan(eng, prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], n,
+                             seed=11, call=3, shard=shard)
+    first, cand = hplanner.rs_plan(eng, prob["obs"], prob["cp_obs"], prob["cp_act"], n, seed=11, call=4, shard=shard)
+    np.save(os.path.join(out_dir, "plan_%d.npy" % rank), plan.numpy())
+    np.save(os.path.join(out_dir, "rs_%d.npy" % rank), first.numpy())
+    np.save(os.path.join(out_dir, "cand_%d.npy" % rank), cand.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_cem_equals_single_rank(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    # single-rank reference in this process
+    sys.path.insert(0, HERE)
+    from cadm_amd import planner as hplanner
+    from cadm_amd import synth
+    from helpers import oracle_problem
+    from oracle_engine import OracleEngine
+    E, p, m, n, H = 5, 5, 2, 64, 4
+    prob = synth.make_problem(env="halfcheetah", E=E, m=m, H=H, seed=7)
+    eng = OracleEngine(oracle_problem(prob, np.float32), prob, p, H, num_elites=16)
+    ref = hplanner.cem_plan(eng, prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], n,
+                            seed=11, call=3).numpy()
+    rs_ref, cand_ref = hplanner.rs_plan(eng, prob["obs"], prob["cp_obs"], prob["cp_act"], n, seed=11, call=4)
+    p0, p1 = np.load(tmp_path / "plan_0.npy"), np.load(tmp_path / "plan_1.npy")
+    np.testing.assert_array_equal(p0, p1)            # every rank ends with the identical plan
+    np.testing.assert_array_equal(p0, ref)           # and it equals the unsharded planner bit for bit
+    np.testing.assert_array_equal(np.load(tmp_path / "rs_0.npy"), rs_ref.numpy())
+    np.testing.assert_array_equal(np.load(tmp_path / "rs_1.npy"), rs_ref.numpy())
+    c0 = np.load(tmp_path / "cand_0.npy")            # gathered layout [G, m, n_local]
+    assert c0.shape == (2, m, n // 2)
+    np.testing.assert_array_equal(np.concatenate([c0[0], c0[1]], axis=1), cand_ref.numpy()[0])
+
+
+def test_shard_validation():
+    from cadm_amd.planner import Shard
+    with pytest.raises(ValueError):
+        Shard(10, 0, 4)
+    s = Shard(12, 2, 4)
+    assert s.n_local == 3 and s.offset == 6
