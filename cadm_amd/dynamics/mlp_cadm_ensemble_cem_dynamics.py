@@ -294,8 +294,12 @@ class MLPEnsembleCEMDynamicsModel(object):
         D, A, Hh, F = self.obs_space_dims, self.action_space_dims, self.history_length, self.future_length
         fb = future_bool.reshape(-1) > 0
         rows = lambda x, w: x.reshape((-1, w))[fb]
-        _cp_obs = np.tile(cp_obs, (1, F)).reshape((-1, D * Hh))[fb]
-        _cp_act = np.tile(cp_act, (1, F)).reshape((-1, A * Hh))[fb]
+        if Hh > 0:
+            _cp_obs = np.tile(cp_obs, (1, F)).reshape((-1, D * Hh))[fb]
+            _cp_act = np.tile(cp_act, (1, F)).reshape((-1, A * Hh))[fb]
+        else:       # vanilla model: no history window
+            _cp_obs = np.zeros((int(fb.sum()), 0))
+            _cp_act = np.zeros((int(fb.sum()), 0))
         return (rows(obs, D), rows(act, A), rows(delta, D), rows(obs_next, D), rows(back_delta, D), _cp_obs, _cp_act)
 
     # ------------------------------------------------------------------ checkpoint

@@ -242,3 +242,44 @@ def test_random_shooting_discrete(gpu):
     np.testing.assert_array_equal(_np(best_a), rbest)
     out = _np(eng.rs_plan(prob["obs"], prob["cp_obs"], prob["cp_act"], n, seed=2, call=3))
     assert out.shape == (m,) and set(np.unique(out)) <= {0, 1}
+
+
+def test_candidate_shards_compose(gpu):
+    """Two candidate shards rolled out separately (cand_offset / n_local, as two ranks would) and refit
+    through the gathered [G, m, n_local] layout equal the unsharded planner bit for bit."""
+    E, p, m, n, H = 5, 10, 2, 96, 6
+    prob = synth.make_problem(env="halfcheetah", E=E, m=m, H=H, seed=14)
+    eng = make_engine(prob, p=p)
+    ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"])
+    mean, var = eng._t(prob["init_mean"]).clone(), eng._t(prob["init_var"]).clone()
+    acts = eng.sample_actions(mean, var, n, seed=5, call=2, it=1)
+    full = eng.particle_mean(eng.rollout_returns(prob["obs"], ctx, acts, seed=5, call=2, it=1))
+    G, nl = 3, n // 3
+    parts = [eng.particle_mean(eng.rollout_returns(prob["obs"], ctx, acts, seed=5, call=2, it=1, cand_offset=g * nl, n_local=nl))
+             for g in range(G)]
+    import torch
+    gathered = torch.stack(parts)                    # [G, m, n_local] -- what the all-gather produces
+    np.testing.assert_array_equal(_np(torch.cat(parts, dim=1)), _np(full))
+    m1, v1 = mean.clone(), var.clone()
+    e1 = eng.cem_refit(full.unsqueeze(0), acts, m1, v1, G=1, want_elites=True)
+    m2, v2 = mean.clone(), var.clone()
+    e2 = eng.cem_refit(gathered.contiguous(), acts, m2, v2, G=G, want_elites=True)
+    np.testing.assert_array_equal(_np(e1), _np(e2))
+    np.testing.assert_array_equal(_np(m1), _np(m2))
+    np.testing.assert_array_equal(_np(v1), _np(v2))
+
+
+def test_refit_large_n_bitonic_path(gpu):
+    prob = synth.make_problem(env="halfcheetah", m=2, H=4, seed=6)
+    eng = make_engine(prob, p=5, H=4)
+    rng = np.random.default_rng(3)
+    m, n = 2, 3000                                   # > 2048 -> bitonic sort path
+    acts = rng.uniform(-1, 1, (m, n, 4, 6)).astype(np.float32)
+    cand = rng.standard_normal((m, n)).astype(np.float32)
+    cand[0, 2999] = cand[0, 5] = cand.max() + 1.0    # tie at the top: lower index first
+    mean = np.zeros((m, 4, 6), np.float32); var = np.full((m, 4, 6), 0.25, np.float32)
+    mt, vt = eng._t(mean).clone(), eng._t(var).clone()
+    el = eng.cem_refit(eng._t(cand), eng._t(acts), mt, vt, want_elites=True)
+    rm, rv, ridx = oplanner.elite_refit(mean, var, acts, cand)
+    np.testing.assert_array_equal(_np(el), ridx)
+    assert_close(_np(mt), rm, 1e-6, "refit mean (bitonic)")
