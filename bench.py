@@ -146,6 +146,15 @@ def main():
     rows_per_launch = shard.n_local * p * H
     kern_avg_s = kern_ms / 1e3 / max(kern_launches, 1)
     achieved = rows_per_launch * fl / kern_avg_s / 1e12
+    # HBM/fabric traffic of the dominant kernel: PMC counters cannot be read from inside this process; they are
+    # collected by separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of THIS command and committed
+    # under profiles/ (KB per launch).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide
+    # coalesced reads at half their bytes -> doubled.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.config)
+    if world == 1 and args.cand_per_gpu is None and os.path.exists(tpath):
+        raw = json.load(open(tpath))
+        traffic = (2.0 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"]) * 1024.0
     out = {
         "metric": "CEM rollout row-steps/s (cand x part x horizon x 5 CEM iters per get_action; ens=%d members)" % E,
         "value": value, "unit": "row-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -155,7 +164,8 @@ def main():
                                % (args.config, cfg["env"], E, p, n, n_per_gpu, H),
                    "global_candidates": n, "parallelism": "candidate-shard x%d" % world},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE from profiles/pmc_traffic_%s.json)" % args.config,
                      "kernel": "rollout_kernel", "avg_launch_ms": kern_avg_s * 1e3, "launches": kern_launches,
                      "flops_per_row_step": fl, "row_steps_per_launch": rows_per_launch},
     }
