@@ -111,9 +111,22 @@ def main():
     obs, cp_obs, cp_act = eng._t(prob["obs"]), eng._t(prob["cp_obs"]), eng._t(prob["cp_act"])
     init_mean, init_var = eng._t(prob["init_mean"]), eng._t(prob["init_var"])
     shard = hplanner.Shard(n, rank, world)
+    collective = "none"
+    if world > 1:
+        try:        # RCCL communicator inside libcadm_hip.so: one ncclAllGather per CEM iteration, all on-stream
+            eng.dist_init()
+            collective = "rccl all-gather in libcadm_hip.so"
+        except Exception as exc:
+            collective = "torch.distributed all_gather (in-library RCCL init failed: %s)" % exc
+        flag = torch.tensor([1.0 if eng.dist_world == world else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks must agree on the path
+        if flag.item() < 1.0 and eng.dist_world == world:
+            collective = "torch.distributed all_gather (a peer failed in-library RCCL init)"
+            eng.dist_world = 1
+    fused = world == 1 or eng.dist_world == world
 
     def step(call):
-        if world == 1:
+        if fused:
             return eng.cem_plan(obs, cp_obs, cp_act, init_mean, init_var, n, seed=0, call=call)
         return hplanner.cem_plan(eng, obs, cp_obs, cp_act, init_mean, init_var, n, seed=0, call=call, shard=shard)
 
@@ -162,7 +175,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %s PE-TS+CaDM get_action, ens=%d part=%d cand=%d (%d/GPU) H=%d m=1, random-init weights"
                                % (args.config, cfg["env"], E, p, n, n_per_gpu, H),
-                   "global_candidates": n, "parallelism": "candidate-shard x%d" % world},
+                   "global_candidates": n, "parallelism": "candidate-shard x%d" % world, "collective": collective},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "bytes/launch (2*FETCH_SIZE + WRITE_SIZE from profiles/pmc_traffic_%s.json)" % args.config,

@@ -95,6 +95,7 @@ extern "C" int cadm_ctx_create(const cadm_config* cfg, cadm_ctx** out) {
 extern "C" int cadm_ctx_destroy(cadm_ctx* ctx) {
     if (!ctx) return CADM_OK;
     cadm_train_free(ctx);
+    cadm_dist_destroy(ctx);
     if (ctx->wstream) (void)hipFree(ctx->wstream);
     if (ctx->bstream) (void)hipFree(ctx->bstream);
     if (ctx->st.buf) (void)hipFree(ctx->st.buf);
@@ -234,7 +235,7 @@ extern "C" int cadm_profile_read(cadm_ctx* ctx, float* total_ms_out, int* launch
 // fused single-GPU planners
 // ---------------------------------------------------------------------------------------------
 struct PlanWs {
-    float *ctxv, *actions, *rows, *cand, *mean, *var;
+    float *ctxv, *actions, *rows, *cand, *gath, *mean, *var;
     int32_t* raw;
 };
 
@@ -247,10 +248,11 @@ static size_t carve(cadm_ctx* ctx, int m, int n, char* base, PlanWs* w) {
     float* actions = (float*)take((size_t)m * n * ctx->H * ctx->A * 4);
     float* rows = (float*)take((size_t)m * n * ctx->p * 4);
     float* cand = (float*)take((size_t)m * n * 4);
+    float* gath = (float*)take((size_t)m * n * 4);
     float* mean = (float*)take((size_t)m * ctx->H * ctx->A * 4);
     float* var = (float*)take((size_t)m * ctx->H * ctx->A * 4);
     int32_t* raw = (int32_t*)take((size_t)m * n * ctx->H * 4);
-    if (w) { w->ctxv = ctxv; w->actions = actions; w->rows = rows; w->cand = cand; w->mean = mean; w->var = var; w->raw = raw; }
+    if (w) { w->ctxv = ctxv; w->actions = actions; w->rows = rows; w->cand = cand; w->gath = gath; w->mean = mean; w->var = var; w->raw = raw; }
     return off;
 }
 
@@ -273,12 +275,21 @@ extern "C" int cadm_cem_plan(cadm_ctx* ctx, const float* obs, const float* cp_ob
     const size_t mv = (size_t)m * ctx->H * ctx->A * sizeof(float);
     CADM_CHECK_HIP(hipMemcpyAsync(w.mean, init_mean, mv, hipMemcpyDeviceToDevice, s));
     CADM_CHECK_HIP(hipMemcpyAsync(w.var, init_var, mv, hipMemcpyDeviceToDevice, s));
+    const int G = ctx->comm ? ctx->nranks : 1;
+    CADM_REQUIRE(n % G == 0, "cadm_cem_plan: n_candidates %d not divisible by %d ranks", n, G);
+    const int nl = n / G, off = (ctx->comm ? ctx->rank : 0) * nl;
     for (int it = 0; it < ctx->cfg.num_cem_iters; ++it) {
+        // every rank draws ALL n candidates (counter-based RNG keyed by global candidate id): elites need no exchange
         if ((rc = cadm_sample_actions(ctx, w.mean, w.var, nullptr, seed, call, it, m, n, w.actions, stream))) return rc;
         if ((rc = cadm_rollout_returns(ctx, obs, nullptr, ctx->C > 0 ? w.ctxv : nullptr, w.actions, nullptr, 1, seed,
-                                       call, it, 0, n, m, n, w.rows, nullptr, stream))) return rc;
-        if ((rc = cadm_particle_mean(ctx, w.rows, m, n, w.cand, stream))) return rc;
-        if ((rc = cadm_cem_refit(ctx, w.cand, 1, n, w.actions, m, w.mean, w.var, nullptr, stream))) return rc;
+                                       call, it, off, n, m, nl, w.rows, nullptr, stream))) return rc;
+        if ((rc = cadm_particle_mean(ctx, w.rows, m, nl, w.cand, stream))) return rc;
+        const float* cand = w.cand;
+        if (G > 1) {   // the one collective of the path: [m, n/G] per rank -> [G, m, n/G] everywhere
+            if ((rc = cadm_dist_allgather(ctx, w.cand, w.gath, (size_t)m * nl, s))) return rc;
+            cand = w.gath;
+        }
+        if ((rc = cadm_cem_refit(ctx, cand, G, nl, w.actions, m, w.mean, w.var, nullptr, stream))) return rc;
     }
     return cadm_launch_clip(w.mean, plan_out, m * ctx->H * ctx->A, ctx->cfg.lower_bound, ctx->cfg.upper_bound,
                             !ctx->cfg.discrete, s);
@@ -302,11 +313,19 @@ extern "C" int cadm_rs_plan(cadm_ctx* ctx, const float* obs, const float* cp_obs
     if (ctx->C > 0 && (rc = cadm_context_forward(ctx, cp_obs, cp_act, m, 0, w.ctxv, stream))) return rc;
     if ((rc = cadm_sample_uniform(ctx, seed, call, m, n, w.actions, w.raw, stream))) return rc;
     // it = 0: the RS graph transposes the context tensor once (core/utils.py:513) -> the even-iteration layout
+    const int G = ctx->comm ? ctx->nranks : 1;
+    CADM_REQUIRE(n % G == 0, "cadm_rs_plan: n_candidates %d not divisible by %d ranks", n, G);
+    const int nl = n / G, off = (ctx->comm ? ctx->rank : 0) * nl;
     if ((rc = cadm_rollout_returns(ctx, obs, nullptr, ctx->C > 0 ? w.ctxv : nullptr, w.actions, nullptr,
-                                   ctx->cfg.discrete ? 0 : 1, seed, call, 0, 0, n, m, n, w.rows, nullptr, stream))) return rc;
-    if ((rc = cadm_particle_mean(ctx, w.rows, m, n, w.cand, stream))) return rc;
+                                   ctx->cfg.discrete ? 0 : 1, seed, call, 0, off, n, m, nl, w.rows, nullptr, stream))) return rc;
+    if ((rc = cadm_particle_mean(ctx, w.rows, m, nl, w.cand, stream))) return rc;
+    const float* cand = w.cand;
+    if (G > 1) {
+        if ((rc = cadm_dist_allgather(ctx, w.cand, w.gath, (size_t)m * nl, s))) return rc;
+        cand = w.gath;
+    }
     int32_t* best = (int32_t*)w.mean;  // scratch reuse: m ints
-    if ((rc = cadm_rs_select(ctx, w.cand, 1, n, w.actions, m, action_out, best, stream))) return rc;
+    if ((rc = cadm_rs_select(ctx, cand, G, nl, w.actions, m, action_out, best, stream))) return rc;
     if (ctx->cfg.discrete) {
         hipLaunchKernelGGL(gather_raw_first_kernel, dim3((m + 63) / 64), dim3(64), 0, s, w.raw, best, m, n, ctx->H, raw_best_out);
         CADM_CHECK_HIP(hipGetLastError());

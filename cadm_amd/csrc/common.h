@@ -106,6 +106,9 @@ struct cadm_ctx {
     std::vector<hipEvent_t> prof_ev;   // start/stop pairs
     size_t prof_used = 0;
     unsigned long long* tbuf = nullptr;   // cadm_debug_set_timing_buffer
+    // RCCL communicator for candidate-sharded planning (dist.hip)
+    void* comm = nullptr;
+    int nranks = 1, rank = 0;
 };
 
 // kernels' host launchers (one per translation unit)
@@ -117,6 +120,7 @@ int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, 
 int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs,
                         float* out, hipStream_t s);
 void cadm_train_free(cadm_ctx* ctx);
+int cadm_dist_allgather(cadm_ctx* ctx, const float* send, float* recv, size_t count, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // device helpers

@@ -1,0 +1,91 @@
+// RCCL glue for candidate-sharded planning: one ncclAllGather of per-candidate returns per CEM iteration
+// over xGMI.  librccl is dlopen'ed lazily (it resolves to the copy PyTorch already loaded when there is one),
+// so single-GPU use has no RCCL dependency.
+#include <dlfcn.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+struct IdBlob { char b[128]; };     // ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+typedef int (*fn_get_id)(void*);
+typedef int (*fn_init_rank2)(void**, int, IdBlob, int);
+typedef int (*fn_destroy)(void*);
+typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef const char* (*fn_errstr)(int);
+
+struct Rccl {
+    void* h = nullptr;
+    fn_get_id get_id = nullptr;
+    fn_init_rank2 init_rank = nullptr;
+    fn_destroy destroy = nullptr;
+    fn_allgather allgather = nullptr;
+    fn_errstr errstr = nullptr;
+} g_rccl;
+
+int load_rccl() {
+    if (g_rccl.h) return CADM_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) { cadm_set_error("cannot dlopen librccl: %s", dlerror()); return CADM_EINVAL; }
+    g_rccl.get_id = (fn_get_id)dlsym(h, "ncclGetUniqueId");
+    g_rccl.init_rank = (fn_init_rank2)dlsym(h, "ncclCommInitRank");
+    g_rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
+    g_rccl.allgather = (fn_allgather)dlsym(h, "ncclAllGather");
+    g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.get_id || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allgather) {
+        cadm_set_error("librccl lacks the expected nccl* symbols");
+        return CADM_EINVAL;
+    }
+    g_rccl.h = h;
+    return CADM_OK;
+}
+
+int check_nccl(int rc, const char* what) {
+    if (rc == 0) return CADM_OK;
+    cadm_set_error("%s failed: %s (ncclResult %d)", what, g_rccl.errstr ? g_rccl.errstr(rc) : "?", rc);
+    return CADM_EHIP;
+}
+}  // namespace
+
+extern "C" int cadm_dist_unique_id(char out_id[128]) {
+    CADM_REQUIRE(out_id, "cadm_dist_unique_id: null argument");
+    int rc = load_rccl();
+    if (rc) return rc;
+    return check_nccl(g_rccl.get_id(out_id), "ncclGetUniqueId");
+}
+
+extern "C" int cadm_dist_init(cadm_ctx* ctx, const char id[128], int nranks, int rank) {
+    CADM_REQUIRE(ctx && id && nranks >= 1 && rank >= 0 && rank < nranks, "cadm_dist_init: bad arguments");
+    CADM_REQUIRE(!ctx->comm, "cadm_dist_init: communicator already initialised");
+    int rc = load_rccl();
+    if (rc) return rc;
+    CADM_CHECK_HIP(hipSetDevice(ctx->device));
+    IdBlob blob;
+    memcpy(blob.b, id, 128);
+    void* comm = nullptr;
+    if ((rc = check_nccl(g_rccl.init_rank(&comm, nranks, blob, rank), "ncclCommInitRank"))) return rc;
+    ctx->comm = comm;
+    ctx->nranks = nranks;
+    ctx->rank = rank;
+    return CADM_OK;
+}
+
+extern "C" int cadm_dist_destroy(cadm_ctx* ctx) {
+    if (!ctx || !ctx->comm) return CADM_OK;
+    g_rccl.destroy(ctx->comm);
+    ctx->comm = nullptr;
+    ctx->nranks = 1;
+    ctx->rank = 0;
+    return CADM_OK;
+}
+
+// [count] floats per rank -> [nranks * count] on every rank (ncclFloat32 = 7)
+int cadm_dist_allgather(cadm_ctx* ctx, const float* send, float* recv, size_t count, hipStream_t s) {
+    if (!ctx->comm) { cadm_set_error("cadm_dist_allgather: no communicator"); return CADM_ESTATE; }
+    return check_nccl(g_rccl.allgather(send, recv, count, 7, ctx->comm, s), "ncclAllGather");
+}

@@ -132,6 +132,7 @@ class MLPEnsembleCEMDynamicsModel(object):
         self.engine.init_weights(np.random.default_rng(self.seed))
         self._train_ready = False
         self._stats_dirty = True
+        self._dist_failed = False
 
     # ------------------------------------------------------------------ planning
     def _push_stats(self):
@@ -151,15 +152,22 @@ class MLPEnsembleCEMDynamicsModel(object):
         self._push_stats()
         call = self._next_call()
         shard = _planner.Shard.from_dist(self.n_candidates, self._group)
+        if shard.world > 1 and self.engine.dist_world == 1 and not self._dist_failed:
+            try:       # in-library RCCL communicator: the whole sharded planner stays on the stream
+                self.engine.dist_init(self._group)
+            except Exception as exc:   # fall back to torch.distributed collectives between the kernel calls
+                self._dist_failed = True
+                logger.log("cadm_amd: in-library RCCL init failed (%s); using torch.distributed all_gather" % exc)
+        fused = shard.world == 1 or self.engine.dist_world == shard.world
         if cem_init_mean is not None:
-            if shard.world == 1:
+            if fused:
                 action = self.engine.cem_plan(obs, cp_obs, cp_act, cem_init_mean, cem_init_var, self.n_candidates,
                                               seed=self.seed, call=call)
             else:
                 action = _planner.cem_plan(self.engine, obs, cp_obs, cp_act, cem_init_mean, cem_init_var,
                                            self.n_candidates, seed=self.seed, call=call, shard=shard)
         else:
-            if shard.world == 1:
+            if fused:
                 action = self.engine.rs_plan(obs, cp_obs, cp_act, self.n_candidates, seed=self.seed, call=call)
             else:
                 action, _ = _planner.rs_plan(self.engine, obs, cp_obs, cp_act, self.n_candidates, seed=self.seed,

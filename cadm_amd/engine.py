@@ -81,6 +81,7 @@ class HipEngine:
         self._ws = None
         self._ws_key = None
         self._train_B = 0
+        self.dist_world, self.dist_rank = 1, 0
 
     # ------------------------------------------------------------------ lifecycle
     def close(self):
@@ -349,6 +350,23 @@ class HipEngine:
                                        g("cp_obs"), g("cp_act"), B, int(train), ptr(losses), self.stream),
               "cadm_train_step")
         return losses
+
+    # ------------------------------------------------------------------ multi-GPU (RCCL communicator owned by the ctx)
+    def dist_init(self, group=None):
+        """Create the ctx's RCCL communicator over the ranks of a torch.distributed group (the group is only
+        used to broadcast the 128-byte ncclUniqueId).  Afterwards cem_plan / rs_plan take the GLOBAL candidate
+        count and run the sharded planner entirely on the stream, one ncclAllGather per CEM iteration."""
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        buf = ct.create_string_buffer(128)
+        if rank == 0:
+            check(self.lib.cadm_dist_unique_id(buf), "cadm_dist_unique_id")
+        t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=self.device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = bytes(t.cpu().tolist())
+        with torch.cuda.device(self.device):
+            check(self.lib.cadm_dist_init(self._ctx, ident, world, rank), "cadm_dist_init")
+        self.dist_world, self.dist_rank = world, rank
 
     # ------------------------------------------------------------------ in-library kernel timing
     def profile_enable(self, on=True):

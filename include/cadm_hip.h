@@ -194,6 +194,18 @@ int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act, const flo
 /* Reset Adam moments / step count (a fresh tf.global_variables_initializer()). */
 int cadm_train_reset(cadm_ctx* ctx, void* stream);
 
+/* Multi-GPU planning: candidates shard contiguously over the ranks of an RCCL communicator owned by the
+ * ctx (one process per GPU).  The reference is single-device (cadm/trainers/mb_trainer.py:103-107); this
+ * adds exactly one collective per CEM iteration -- ncclAllGather of the per-candidate returns
+ * ([m, n/G] floats per rank) -- between core/utils.py:474 and :475.  RCCL is dlopen'ed on first use.
+ *   cadm_dist_unique_id  rank 0: fill a 128-byte ncclUniqueId, to be broadcast by the host to every rank
+ *   cadm_dist_init       every rank: ncclCommInitRank on the ctx's device
+ * Once initialised, cadm_cem_plan / cadm_rs_plan take n = GLOBAL candidate count (divisible by nranks),
+ * roll out candidates [rank*n/G, (rank+1)*n/G) and return the identical plan on every rank. */
+int cadm_dist_unique_id(char out_id[128]);
+int cadm_dist_init(cadm_ctx* ctx, const char id[128], int nranks, int rank);
+int cadm_dist_destroy(cadm_ctx* ctx);
+
 /* In-library timing of the dominant kernel (the rollout): when enabled, every
  * cadm_rollout_returns launch is bracketed by hipEvents on the launch stream.
  * cadm_profile_read synchronises, returns the summed elapsed milliseconds and launch count

@@ -283,3 +283,27 @@ def test_refit_large_n_bitonic_path(gpu):
     rm, rv, ridx = oplanner.elite_refit(mean, var, acts, cand)
     np.testing.assert_array_equal(_np(el), ridx)
     assert_close(_np(mt), rm, 1e-6, "refit mean (bitonic)")
+
+
+def test_in_library_rccl_path_single_rank(gpu):
+    """The in-library RCCL communicator (dlopen, ncclCommInitRank) on a 1-rank group: the sharded planner code
+    path (G = 1) returns exactly what the plain path returns.  (G > 1 needs a multi-GPU node: covered by the
+    shard-composition test above and the gloo world-size-2 test on CPU.)"""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    own = not dist.is_initialized()
+    if own:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        prob = synth.make_problem(env="halfcheetah", m=2, H=6, seed=17)
+        eng = make_engine(prob, p=10, H=6)
+        a = _np(eng.cem_plan(prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], 64, seed=3, call=9))
+        eng.dist_init()
+        assert eng.dist_world == 1
+        b = _np(eng.cem_plan(prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], 64, seed=3, call=9))
+        np.testing.assert_array_equal(a, b)
+    finally:
+        if own:
+            dist.destroy_process_group()
