@@ -157,7 +157,10 @@ struct RC {
     static constexpr int NF = NT / 4, NS = NT % 4;                     // full tiles per wave / split tiles
     static constexpr int NTO = (D + 7) / 8;                            // head tiles (8 dims: mu|lv)
     static constexpr int NFO = NTO / 4, NSO = NTO % 4;
-    static constexpr int PF = 3;                                       // weight ring depth (chunks)
+#ifndef CADM_PF
+#define CADM_PF 3
+#endif
+    static constexpr int PF = CADM_PF;                                 // weight ring depth (chunks)
     // head layer with only K-split tiles: split K by CHUNK instead of by k-step (see head_pass_csplit);
     // must match make_geo() in capi.hip
     static constexpr bool OCS = NFO == 0 && NSO > 0 && NS == 1;
@@ -243,10 +246,7 @@ __device__ __forceinline__ void mfma_pass(Ring<G>& ring, __amdgpu_buffer_rsrc_t 
         constexpr int slot = j % PF;
         if constexpr (j < NCH) {
             constexpr int nk = (j == NCH - 1) ? KSL : 4;
-            if constexpr (j + 1 < NCH) {
-                load_b(std::integral_constant<int, j + 1>{});
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            if constexpr (j + 1 < NCH) load_b(std::integral_constant<int, j + 1>{});
             side(jc);
 #pragma unroll
             for (int r = 0; r < nk; ++r)
@@ -262,19 +262,27 @@ __device__ __forceinline__ void mfma_pass(Ring<G>& ring, __amdgpu_buffer_rsrc_t 
                 for (int mt = 0; mt < MT; ++mt)
                     accS[mt][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring.s[slot][s], bs[j & 1][mt],
                                                                        accS[mt][s], 0, 0, 0);
-            if constexpr ((SIDE_MASK >> j) & 1u) {      // weave the side work's VALU into the MFMA shadow
-#pragma unroll
-                for (int i = 0; i < (nk * NFO + NSO) * MT; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // up to 4 VALU
-                }
-            }
         }
         constexpr int jj = j + PF;
         if constexpr (jj < NCH) {
             ring_load<slot, NFO, NSO>(ring, rsrc, wcur + jj * SLOTB, lane);
         } else if constexpr (jj >= NCHPAD && (jj - NCHPAD) < NX_NCH) {
             ring_load<slot, NX_NFO, NX_NSO>(ring, rsrc, wnext + (jj - NCHPAD) * NX_SLOTB, lane);
+        }
+        if constexpr (j < NCH) {
+            // issue order inside the chunk: every MFMA gap carries at most one memory instruction (the ring loads
+            // of chunk j+PF, then the LDS reads of chunk j+1) plus, on side-work chunks, a few VALU -- so the
+            // matrix pipe never waits behind a cluster of other instructions
+            constexpr int nk2 = (j == NCH - 1) ? KSL : 4;
+            constexpr int NM = (nk2 * NFO + NSO) * MT;
+            constexpr bool has_side = (SIDE_MASK >> j) & 1u;
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // 1 MFMA
+                if (i < NFO + NSO + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+                else if (i < NFO + NSO + 2 + 2 * MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+                if (has_side) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);        // up to 4 VALU
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     });
