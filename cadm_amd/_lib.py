@@ -74,6 +74,7 @@ SIGNATURES = {
     "cadm_train_configure": (_i, [_P, C.POINTER(TrainHParams), _i]),
     "cadm_train_step": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _P, _P]),
     "cadm_train_reset": (_i, [_P, _P]),
+    "cadm_predict": (_i, [_P, _P, _P, _P, _P, _i, _P, _P, _P]),
     "cadm_profile_enable": (_i, [_P, _i]),
     "cadm_profile_read": (_i, [_P, C.POINTER(C.c_float), C.POINTER(_i)]),
     "cadm_debug_set_timing_buffer": (_i, [_P, _P]),

@@ -408,17 +408,21 @@ static int ensure_workspace(cadm_ctx* ctx, int B) {
     return CADM_OK;
 }
 
+static int ensure_state(cadm_ctx* ctx) {
+    if (ctx->train) return CADM_OK;
+    ctx->train = new (std::nothrow) TrainState();
+    if (!ctx->train) { cadm_set_error("out of host memory"); return CADM_ENOMEM; }
+    return CADM_OK;
+}
+
 extern "C" int cadm_train_configure(cadm_ctx* ctx, const cadm_train_hparams* hp, int max_batch) {
     CADM_REQUIRE(ctx && hp, "cadm_train_configure: null argument");
     for (auto& d : ctx->ff) CADM_REQUIRE(d.W && d.b, "cadm_train_configure: ff_model weights not registered");
     if (ctx->cfg.back_model) for (auto& d : ctx->back) CADM_REQUIRE(d.W && d.b, "cadm_train_configure: backward_model weights not registered");
     if (ctx->C > 0) for (auto& d : ctx->cp) CADM_REQUIRE(d.W && d.b, "cadm_train_configure: context_model weights not registered");
-    if (!ctx->train) {
-        ctx->train = new (std::nothrow) TrainState();
-        if (!ctx->train) { cadm_set_error("cadm_train_configure: out of host memory"); return CADM_ENOMEM; }
-        int rc = alloc_adam(ctx);
-        if (rc) return rc;
-    }
+    int rc0 = ensure_state(ctx);
+    if (rc0) return rc0;
+    if (!ctx->train->adam_buf && (rc0 = alloc_adam(ctx))) return rc0;
     ctx->train->hp = *hp;
     ctx->train->configured = true;
     if (max_batch > 0) return ensure_workspace(ctx, max_batch);
@@ -496,27 +500,17 @@ int adam_elem(float* w, AdamSlot& a, const float* gsrc, float gscale, float gcon
 
 }  // namespace
 
-extern "C" int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act, const float* delta,
-                               const float* obs_next, const float* back_delta, const float* cp_obs,
-                               const float* cp_act, int B, int train, float* losses_out, void* stream) {
-    CADM_REQUIRE(ctx && obs && act && delta && losses_out && B > 0, "cadm_train_step: bad arguments");
-    CADM_REQUIRE(ctx->train && ctx->train->configured, "cadm_train_step: call cadm_train_configure first");
-    CADM_REQUIRE(ctx->st.set, "cadm_train_step: normalisation stats not set");
-    const bool has_back = ctx->cfg.back_model != 0, has_cp = ctx->C > 0, det = ctx->cfg.deterministic != 0;
-    CADM_REQUIRE(!has_back || (obs_next && back_delta), "cadm_train_step: obs_next / back_delta required (backward model)");
-    CADM_REQUIRE(!has_cp || (cp_obs && cp_act), "cadm_train_step: cp_obs / cp_act required (context model)");
-    CADM_REQUIRE(ctx->ff_maxlv && ctx->ff_minlv, "cadm_train_step: logvar bounds not registered");
-    hipStream_t s = (hipStream_t)stream;
-    int rc = ensure_workspace(ctx, B);
-    if (rc) return rc;
+namespace {
+// forward of the context / forward (/ backward) nets on one [E,B,.] batch into the workspace
+int forward_nets(cadm_ctx* ctx, const float* obs, const float* act, const float* obs_next, const float* cp_obs,
+                 const float* cp_act, int B, bool has_back, hipStream_t s) {
     TrainState* t = ctx->train;
-    const cadm_train_hparams& hp = t->hp;
+    const bool has_cp = ctx->C > 0, det = ctx->cfg.deterministic != 0;
     const int E = ctx->E, NH = ctx->NH, HID = ctx->HID, D = ctx->D, K0 = ctx->K0, C = ctx->C, PA = ctx->P + ctx->A;
     const int ncp = has_cp ? ctx->cfg.n_cp_hidden : 0;
     const int cpin = (ctx->D + ctx->A) * ctx->cfg.history_length;
     const long R = (long)E * B;
-
-    // ---- forward ----
+    int rc;
     AsmP ap{};
     ap.obs = obs; ap.obs_next = obs_next; ap.act = act; ap.cp_obs = cp_obs; ap.cp_act = cp_act;
     ap.obs_mean = ctx->st.obs_mean; ap.obs_std = ctx->st.obs_std; ap.act_mean = ctx->st.act_mean; ap.act_std = ctx->st.act_std;
@@ -558,6 +552,40 @@ extern "C" int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act
     };
     if ((rc = net_fwd(ctx->ff, t->Xff, t->ff, !det))) return rc;
     if (has_back && (rc = net_fwd(ctx->back, t->Xbk, t->bk, false))) return rc;
+
+    return CADM_OK;
+}
+
+__global__ void clamp_logvar_kernel(const float* lv, const float* maxlv, const float* minlv, float* out, long n, int D) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int d = (int)(i % D);
+    const float u = maxlv[d] - tf_softplus(maxlv[d] - lv[i]);      // core/utils.py:356
+    out[i] = minlv[d] + tf_softplus(u - minlv[d]);                 // core/utils.py:357
+}
+}  // namespace
+
+extern "C" int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act, const float* delta,
+                               const float* obs_next, const float* back_delta, const float* cp_obs,
+                               const float* cp_act, int B, int train, float* losses_out, void* stream) {
+    CADM_REQUIRE(ctx && obs && act && delta && losses_out && B > 0, "cadm_train_step: bad arguments");
+    CADM_REQUIRE(ctx->train && ctx->train->configured, "cadm_train_step: call cadm_train_configure first");
+    CADM_REQUIRE(ctx->st.set, "cadm_train_step: normalisation stats not set");
+    const bool has_back = ctx->cfg.back_model != 0, has_cp = ctx->C > 0, det = ctx->cfg.deterministic != 0;
+    CADM_REQUIRE(!has_back || (obs_next && back_delta), "cadm_train_step: obs_next / back_delta required (backward model)");
+    CADM_REQUIRE(!has_cp || (cp_obs && cp_act), "cadm_train_step: cp_obs / cp_act required (context model)");
+    CADM_REQUIRE(ctx->ff_maxlv && ctx->ff_minlv, "cadm_train_step: logvar bounds not registered");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_workspace(ctx, B);
+    if (rc) return rc;
+    TrainState* t = ctx->train;
+    const cadm_train_hparams& hp = t->hp;
+    const int E = ctx->E, NH = ctx->NH, HID = ctx->HID, D = ctx->D, K0 = ctx->K0, C = ctx->C, PA = ctx->P + ctx->A;
+    const int ncp = has_cp ? ctx->cfg.n_cp_hidden : 0;
+    const int cpin = (ctx->D + ctx->A) * ctx->cfg.history_length;
+    const long R = (long)E * B;
+
+    if ((rc = forward_nets(ctx, obs, act, obs_next, cp_obs, cp_act, B, has_back, s))) return rc;
 
     // ---- losses + head gradients ----
     LossP lp{};
@@ -638,5 +666,31 @@ extern "C" int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act
         }
     }
     ctx->packed = false;   // planner streams are stale until cadm_repack
+    return CADM_OK;
+}
+
+// One-step prediction heads of every member on an [E,B,.] batch (the vanilla reference's `_get_pred`,
+// mlp_ensemble_cem_dynamics.py:185-189: [mlp.mu, mlp.logvar]): normalised mean and clamped log-variance.
+extern "C" int cadm_predict(cadm_ctx* ctx, const float* obs, const float* act, const float* cp_obs, const float* cp_act,
+                            int B, float* mu_out, float* logvar_out, void* stream) {
+    CADM_REQUIRE(ctx && obs && act && mu_out && B > 0, "cadm_predict: bad arguments");
+    CADM_REQUIRE(ctx->st.set, "cadm_predict: normalisation stats not set");
+    CADM_REQUIRE(ctx->C == 0 || (cp_obs && cp_act), "cadm_predict: cp_obs / cp_act required (context model)");
+    for (auto& d : ctx->ff) CADM_REQUIRE(d.W && d.b, "cadm_predict: ff_model weights not registered");
+    if (ctx->C > 0) for (auto& d : ctx->cp) CADM_REQUIRE(d.W && d.b, "cadm_predict: context_model weights not registered");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_state(ctx);
+    if (rc) return rc;
+    if ((rc = ensure_workspace(ctx, B))) return rc;
+    if ((rc = forward_nets(ctx, obs, act, nullptr, cp_obs, cp_act, B, false, s))) return rc;
+    TrainState* t = ctx->train;
+    const long n = (long)ctx->E * B * ctx->D;
+    CADM_CHECK_HIP(hipMemcpyAsync(mu_out, t->ff.mu, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (logvar_out) {
+        CADM_REQUIRE(!ctx->cfg.deterministic, "cadm_predict: a deterministic model has no log-variance head output");
+        hipLaunchKernelGGL(clamp_logvar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, t->ff.lv, ctx->ff_maxlv,
+                           ctx->ff_minlv, logvar_out, n, ctx->D);
+        CADM_CHECK_HIP(hipGetLastError());
+    }
     return CADM_OK;
 }

@@ -182,11 +182,23 @@ class MLPEnsembleCEMDynamicsModel(object):
         self._push_stats()
         return self.engine.context_forward(cp_obs, cp_act).cpu().numpy()
 
-    def predict(self, obs, act, cp_obs, cp_act):
-        """One-step MEAN next-state prediction of every member, [E,m,D] (no reference twin).
-        Implemented as a 1-step deterministic rollout trajectory is NOT exposed here; it uses the
-        planner kernel with teacher-forced rows so it shares the parity-tested path."""
-        raise NotImplementedError("predict() lands with the training step (round 2)")
+    def predict(self, obs, act, cp_obs=None, cp_act=None, return_std=False):
+        """One-step prediction of every ensemble member (no reference twin; the north-star's `predict()`):
+        obs [m,D], act [m,A] (+ history for the CaDM model) -> mean next observation [E,m,D]
+        (`obs_postproc(obs, denormalize(mu))`), optionally with the predictive std of the delta [E,m,D]."""
+        self._push_stats()
+        E = self.ensemble_size
+        tile = lambda x: None if x is None else np.tile(np.asarray(x, dtype=np.float32)[None], (E, 1, 1))
+        mu, lv = self.engine.predict_heads(tile(obs), tile(act), tile(cp_obs), tile(cp_act))
+        stats = self.get_normalization_stats()
+        dmean, dstd = np.asarray(stats[4], np.float32), np.asarray(stats[5], np.float32)
+        delta = mu.cpu().numpy() * (dstd + 1e-10) + dmean
+        nxt = self.env.obs_postproc(np.broadcast_to(np.asarray(obs, np.float32)[None], delta.shape), delta)
+        if return_std:
+            if lv is None:
+                raise ValueError("a deterministic model has no predictive variance")
+            return nxt, np.exp((lv.cpu().numpy() + 2.0 * np.log(dstd)) / 2.0)
+        return nxt
 
     # ------------------------------------------------------------------ training
     def _ensure_train(self):

@@ -30,6 +30,9 @@ class MLPEnsembleCEMDynamicsModel(_CaDMModel):
     def get_action(self, obs, cem_init_mean=None, cem_init_var=None):
         return super().get_action(obs, None, None, cem_init_mean, cem_init_var)
 
+    def predict(self, obs, act, return_std=False):
+        return super().predict(obs, act, None, None, return_std=return_std)
+
     def get_context_pred(self, *a, **k):
         raise AttributeError("the vanilla model has no context encoder")
 

@@ -378,6 +378,18 @@ class HipEngine:
         check(self.lib.cadm_profile_read(self._ctx, ct.byref(ms), ct.byref(cnt)), "cadm_profile_read")
         return float(ms.value), int(cnt.value)
 
+    def predict_heads(self, obs, act, cp_obs=None, cp_act=None):
+        """[E,B,.] inputs -> (mu [E,B,D] normalised, logvar [E,B,D] clamped or None)."""
+        obs, act = self._t(obs), self._t(act)
+        cp_obs = None if cp_obs is None else self._t(cp_obs)
+        cp_act = None if cp_act is None else self._t(cp_act)
+        B = obs.shape[1]
+        mu = torch.empty((self.E, B, self.D), dtype=torch.float32, device=self.device)
+        lv = None if self.deterministic else torch.empty_like(mu)
+        check(self.lib.cadm_predict(self._ctx, ptr(obs), ptr(act), ptr(cp_obs), ptr(cp_act), B, ptr(mu), ptr(lv), self.stream),
+              "cadm_predict")
+        return mu, lv
+
     def train_reset(self):
         check(self.lib.cadm_train_reset(self._ctx, self.stream), "cadm_train_reset")
 

@@ -191,6 +191,11 @@ int cadm_train_configure(cadm_ctx* ctx, const cadm_train_hparams* hp, int max_ba
 int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act, const float* delta,
                     const float* obs_next, const float* back_delta, const float* cp_obs,
                     const float* cp_act, int B, int train, float* losses_out, void* stream);
+/* One-step prediction heads of every member on an [E,B,.] batch: normalised mean mu [E,B,D] and (optional,
+ * probabilistic models) soft-clamped log-variance [E,B,D] -- the vanilla reference's `_get_pred`
+ * (mlp_ensemble_cem_dynamics.py:185-189 -> [mlp.mu, mlp.logvar]); backs the public predict(). */
+int cadm_predict(cadm_ctx* ctx, const float* obs, const float* act, const float* cp_obs, const float* cp_act,
+                 int B, float* mu_out, float* logvar_out, void* stream);
 /* Reset Adam moments / step count (a fresh tf.global_variables_initializer()). */
 int cadm_train_reset(cadm_ctx* ctx, void* stream);
 

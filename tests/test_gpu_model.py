@@ -132,3 +132,31 @@ def test_discrete_cartpole_model(gpu):
     rng = np.random.default_rng(6)
     a = model.get_action(rng.standard_normal((3, 4)), np.zeros((3, 40)), np.zeros((3, 20)))
     assert a.shape == (3,) and set(np.unique(a)) <= {0, 1}
+
+
+def test_predict_matches_oracle_one_step(gpu):
+    """predict(): one-step mean next state of every member == oracle forward with eps = 0."""
+    from helpers import assert_close, oracle_problem
+    from oracle import nets as onets
+    prob = synth.make_problem(env="halfcheetah", E=5, m=7, trained_like=True, seed=40)
+    model = CaDMModel(**_cadm_kwargs(normalize_input=True))
+    model.engine.set_net("context_model", prob["cp"])
+    model.engine.set_net("ff_model", prob["ff"])
+    st = prob["stats"]
+    model.set_normalization({"obs": (st["obs_mean"], st["obs_std"]), "delta": (st["delta_mean"], st["delta_std"]),
+                             "act": (st["act_mean"], st["act_std"]), "cp_obs": (st["cp_obs_mean"], st["cp_obs_std"]),
+                             "cp_act": (st["cp_act_mean"], st["cp_act_std"]),
+                             "back_delta": (st["back_delta_mean"], st["back_delta_std"])})
+    rng = np.random.default_rng(1)
+    act = rng.uniform(-1, 1, (7, 6))
+    nxt, std = model.predict(prob["obs"], act, prob["cp_obs"], prob["cp_act"], return_std=True)
+    assert nxt.shape == (5, 7, 18) and std.shape == (5, 7, 18) and (std > 0).all()
+    o = oracle_problem(prob, np.float32)
+    ctx = onets.context_forward(o["cp"], o["cp_obs"], o["cp_act"], o["st"])          # [E,m,C]
+    nobs = onets.normalize(o["env"].obs_preproc(o["obs"]), o["st"]["obs_mean"], o["st"]["obs_std"])
+    nact = onets.normalize(act.astype(np.float32), o["st"]["act_mean"], o["st"]["act_std"])
+    x = np.concatenate([np.tile(nobs[None], (5, 1, 1)), np.tile(nact[None], (5, 1, 1)), ctx], -1)
+    delta, mu, lv = onets.dynamics_forward(o["ff"], x, o["st"]["delta_mean"], o["st"]["delta_std"], np.zeros((5, 7, 18), np.float32), False)
+    ref = o["env"].obs_postproc(np.broadcast_to(o["obs"][None], delta.shape), delta)
+    assert_close(nxt, ref, 2e-5, "predict() mean next state")
+    assert_close(std, np.exp((lv + 2 * np.log(o["st"]["delta_std"])) / 2), 2e-5, "predict() std")
