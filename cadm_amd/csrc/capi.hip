@@ -5,6 +5,8 @@
 #include "common.h"
 
 int cadm_launch_clip(const float* in, float* out, int total, float lo, float hi, int do_clip, hipStream_t s);
+int cadm_launch_refit(cadm_ctx* ctx, const float* cand_returns, const float* rows, int G, int n_local, const float* actions,
+                      int m, float* mean_io, float* var_io, int32_t* elites_out, hipStream_t stream);
 
 static thread_local char g_err[1024] = "";
 
@@ -283,13 +285,13 @@ extern "C" int cadm_cem_plan(cadm_ctx* ctx, const float* obs, const float* cp_ob
         if ((rc = cadm_sample_actions(ctx, w.mean, w.var, nullptr, seed, call, it, m, n, w.actions, stream))) return rc;
         if ((rc = cadm_rollout_returns(ctx, obs, nullptr, ctx->C > 0 ? w.ctxv : nullptr, w.actions, nullptr, 1, seed,
                                        call, it, off, n, m, nl, w.rows, nullptr, stream))) return rc;
-        if ((rc = cadm_particle_mean(ctx, w.rows, m, nl, w.cand, stream))) return rc;
-        const float* cand = w.cand;
         if (G > 1) {   // the one collective of the path: [m, n/G] per rank -> [G, m, n/G] everywhere
+            if ((rc = cadm_particle_mean(ctx, w.rows, m, nl, w.cand, stream))) return rc;
             if ((rc = cadm_dist_allgather(ctx, w.cand, w.gath, (size_t)m * nl, s))) return rc;
-            cand = w.gath;
+            if ((rc = cadm_launch_refit(ctx, w.gath, nullptr, G, nl, w.actions, m, w.mean, w.var, nullptr, s))) return rc;
+        } else {       // single rank: the particle mean is taken inside the refit kernel
+            if ((rc = cadm_launch_refit(ctx, nullptr, w.rows, 1, nl, w.actions, m, w.mean, w.var, nullptr, s))) return rc;
         }
-        if ((rc = cadm_cem_refit(ctx, cand, G, nl, w.actions, m, w.mean, w.var, nullptr, stream))) return rc;
     }
     return cadm_launch_clip(w.mean, plan_out, m * ctx->H * ctx->A, ctx->cfg.lower_bound, ctx->cfg.upper_bound,
                             !ctx->cfg.discrete, s);

@@ -87,6 +87,16 @@ __device__ __forceinline__ float cand_at(const float* cand, int G, int n_local, 
     return cand[((size_t)(ni / n_local) * m + mi) * n_local + (ni % n_local)];
 }
 
+// candidate return: from the gathered per-candidate means, or (single-rank fused path) the particle mean
+// (core/utils.py:474) taken on the fly from the row returns [m, n, p]
+__device__ __forceinline__ float cand_value(const float* cand, const float* rows, int p, int G, int n_local, int m, int mi, int ni) {
+    if (!rows) return cand_at(cand, G, n_local, m, mi, ni);
+    const float* r = rows + ((size_t)mi * n_local + ni) * p;
+    float s = 0.0f;
+    for (int j = 0; j < p; ++j) s += r[j];
+    return s / (float)p;
+}
+
 __device__ void bitonic_sort_lds(uint64_t* keys, int npow2) {
     for (int k = 2; k <= npow2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -103,7 +113,8 @@ __device__ void bitonic_sort_lds(uint64_t* keys, int npow2) {
     }
 }
 
-__global__ void cem_refit_kernel(const float* __restrict__ cand, int G, int n_local, const float* __restrict__ actions,
+__global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __restrict__ rows, int p, int G, int n_local,
+                                 const float* __restrict__ actions,
                                  int m, int H, int A, int K, float alpha, int npow2, float* __restrict__ mean_io,
                                  float* __restrict__ var_io, int32_t* __restrict__ elites_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -114,7 +125,7 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, int G, int n_lo
         // small n: every candidate's rank by counting (keys are unique: index in the low word); the K best
         // land sorted in keys[0..K) with one barrier instead of the O(log^2 n) barriers of the bitonic sort
         uint64_t* raw = keys + npow2;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) raw[i] = make_key(cand_at(cand, G, n_local, m, mi, i), (uint32_t)i);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) raw[i] = make_key(cand_value(cand, rows, p, G, n_local, m, mi, i), (uint32_t)i);
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const uint64_t ki = raw[i];
@@ -125,7 +136,7 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, int G, int n_lo
         __syncthreads();
     } else {
         for (int i = threadIdx.x; i < npow2; i += blockDim.x)
-            keys[i] = i < n ? make_key(cand_at(cand, G, n_local, m, mi, i), (uint32_t)i) : ~0ull;
+            keys[i] = i < n ? make_key(cand_value(cand, rows, p, G, n_local, m, mi, i), (uint32_t)i) : ~0ull;
         __syncthreads();
         bitonic_sort_lds(keys, npow2);                                             // tf.nn.top_k, :475
     }
@@ -229,10 +240,8 @@ extern "C" int cadm_particle_mean(cadm_ctx* ctx, const float* returns_rows, int 
     return CADM_OK;
 }
 
-extern "C" int cadm_cem_refit(cadm_ctx* ctx, const float* cand_returns, int G, int n_local, const float* actions,
-                              int m, float* mean_io, float* var_io, int32_t* elites_out, void* stream) {
-    CADM_REQUIRE(ctx && cand_returns && actions && mean_io && var_io && G > 0 && n_local > 0 && m > 0,
-                 "cadm_cem_refit: bad arguments");
+int cadm_launch_refit(cadm_ctx* ctx, const float* cand_returns, const float* rows, int G, int n_local, const float* actions,
+                      int m, float* mean_io, float* var_io, int32_t* elites_out, hipStream_t stream) {
     const int n = G * n_local;
     CADM_REQUIRE(n >= ctx->cfg.num_elites, "cadm_cem_refit: n_candidates %d < num_elites %d (tf.nn.top_k would fail)",
                  n, ctx->cfg.num_elites);
@@ -246,10 +255,17 @@ extern "C" int cadm_cem_refit(cadm_ctx* ctx, const float* cand_returns, int G, i
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(cem_refit_kernel, dim3(m), dim3(1024), lds, (hipStream_t)stream, cand_returns, G, n_local, actions,
+    hipLaunchKernelGGL(cem_refit_kernel, dim3(m), dim3(1024), lds, stream, cand_returns, rows, ctx->p, G, n_local, actions,
                        m, ctx->H, ctx->A, ctx->cfg.num_elites, ctx->cfg.alpha, npow2, mean_io, var_io, elites_out);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
+}
+
+extern "C" int cadm_cem_refit(cadm_ctx* ctx, const float* cand_returns, int G, int n_local, const float* actions,
+                              int m, float* mean_io, float* var_io, int32_t* elites_out, void* stream) {
+    CADM_REQUIRE(ctx && cand_returns && actions && mean_io && var_io && G > 0 && n_local > 0 && m > 0,
+                 "cadm_cem_refit: bad arguments");
+    return cadm_launch_refit(ctx, cand_returns, nullptr, G, n_local, actions, m, mean_io, var_io, elites_out, (hipStream_t)stream);
 }
 
 extern "C" int cadm_rs_select(cadm_ctx* ctx, const float* cand_returns, int G, int n_local, const float* actions,

@@ -3,7 +3,7 @@
 // nets on one [E,B,.] bootstrap batch, the losses, hand-written backward GEMMs and TF1-semantics Adam.
 //
 // One batched fp32-MFMA GEMM kernel (v_mfma_f32_16x16x4_f32, 64x64 tile per workgroup, LDS-staged
-// 16-deep K slabs) serves all three products through strides, with the layer's pointwise work fused
+// 32-deep K slabs) serves all three products through strides, with the layer's pointwise work fused
 // into its epilogue:
 //   FWD  H = act(X W + b)            stores z (pre-activation) and h
 //   DX   dZ_prev = (dZ W^T) * act'(z_prev)   (optionally accumulating: the context vector feeds 2 nets)
@@ -63,12 +63,13 @@ __device__ __forceinline__ void adam_update(float& w, float& m, float& v, float 
 
 #define TM 64
 #define TN 64
-#define TK 16
+#define TK 32
 #define LDS_LD (TM + 4)
 
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
-    __shared__ float As[TK][LDS_LD];
-    __shared__ float Bs[TK][LDS_LD];
+    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
+    float (*As)[LDS_LD] = reinterpret_cast<float (*)[LDS_LD]>(gemm_smem);
+    float (*Bs)[LDS_LD] = reinterpret_cast<float (*)[LDS_LD]>(gemm_smem + TK * LDS_LD);
     const int e = blockIdx.z;
     const int mb = blockIdx.y * TM, nb = blockIdx.x * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -82,21 +83,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
         for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
     float colsum = 0.0f;                                // DW: bias gradient (threads < 64 of the m-tile-0 blocks)
 
-    for (int k0 = 0; k0 < p.K; k0 += TK) {
-        // ---- stage the A (TM x TK) and B (TK x TN) slabs, zero padded ----
+    // Software pipeline: the global loads of slab k+1 are in flight (registers) while slab k is consumed from LDS.
+    constexpr int NLD = TM * TK / 256;   // elements per thread per slab
+    float ra[NLD], rb[NLD];
+    // per-thread element bases are fixed across slabs: hoist the row/column part of the address and the bounds test
+    const float* pa[NLD];
+    const float* pb[NLD];
+    int ka[NLD], kb[NLD], la[NLD], lb[NLD];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = tid + it * 256;
-            int am, ak;
-            if (p.a_mcontig) { am = idx & 63; ak = idx >> 6; } else { ak = idx & 15; am = idx >> 4; }
-            const int gm = mb + am, gk = k0 + ak;
-            As[ak][am] = (gm < p.M && gk < p.K) ? A[(long)gm * p.sam + (long)gk * p.sak] : 0.0f;
-            int bn, bk;
-            if (p.sbn == 1) { bn = idx & 63; bk = idx >> 6; } else { bk = idx & 15; bn = idx >> 4; }
-            const int gn = nb + bn, gk2 = k0 + bk;
-            Bs[bk][bn] = (gn < p.N && gk2 < p.K) ? B[(long)gk2 * p.sbk + (long)gn * p.sbn] : 0.0f;
+    for (int it = 0; it < NLD; ++it) {
+        const int idx = tid + it * 256;
+        int am, ak;
+        if (p.a_mcontig) { am = idx & 63; ak = idx >> 6; } else { ak = idx & (TK - 1); am = idx / TK; }
+        ka[it] = ak; la[it] = ak * LDS_LD + am;
+        pa[it] = (mb + am < p.M) ? A + (long)(mb + am) * p.sam + (long)ak * p.sak : nullptr;
+        int bn, bk;
+        if (p.sbn == 1) { bn = idx & 63; bk = idx >> 6; } else { bk = idx & (TK - 1); bn = idx / TK; }
+        kb[it] = bk; lb[it] = bk * LDS_LD + bn;
+        pb[it] = (nb + bn < p.N) ? B + (long)bk * p.sbk + (long)(nb + bn) * p.sbn : nullptr;
+    }
+    const long stepa = (long)TK * p.sak, stepb = (long)TK * p.sbk;
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            ra[it] = (pa[it] && k0 + ka[it] < p.K) ? *pa[it] : 0.0f;
+            rb[it] = (pb[it] && k0 + kb[it] < p.K) ? *pb[it] : 0.0f;
+            if (pa[it]) pa[it] += stepa;
+            if (pb[it]) pb[it] += stepb;
         }
+    };
+    auto stash = [&]() {
+        float* as = &As[0][0];
+        float* bs = &Bs[0][0];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            as[la[it]] = ra[it];
+            bs[lb[it]] = rb[it];
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < p.K; k0 += TK) {
+        stash();                                   // slab k0 (zero padded) -> LDS
         __syncthreads();
+        if (k0 + TK < p.K) fetch(k0 + TK);         // next slab's loads overlap this slab's MFMAs
         if (p.mode == MODE_DW && p.bW && blockIdx.y == 0 && tid < TN) {
 #pragma unroll
             for (int kk = 0; kk < TK; ++kk) colsum += Bs[kk][tid];
@@ -444,7 +473,13 @@ namespace {
 
 int launch_gemm(const GemmP& p, hipStream_t s) {
     dim3 grid((p.N + TN - 1) / TN, (p.M + TM - 1) / TM, p.E);
-    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, p);
+    const size_t lds = 2 * (size_t)TK * LDS_LD * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), lds, s, p);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
 }
