@@ -199,6 +199,19 @@ int cadm_predict(cadm_ctx* ctx, const float* obs, const float* act, const float*
 /* Reset Adam moments / step count (a fresh tf.global_variables_initializer()). */
 int cadm_train_reset(cadm_ctx* ctx, void* stream);
 
+/* Caller-side planner state on the device (no host round trips between env steps):
+ * cadm_warm_start_shift: the samplers' CEM warm start (cadm/samplers/sampler.py:118-120):
+ *   prev_sol[:, :-1] = plan[:, 1:]; prev_sol[:, -1] = 0; action = plan[:, 0]     (plan/prev_sol [m,H,A], action [m,A])
+ * cadm_history_update: the history ring buffer behind cp_obs / cp_act (sampler.py:165-178,193-202):
+ *   per env: entry = (state_diff ? next_obs - obs : obs, action) written at slot count (< Hh) or, once full,
+ *   after shifting the window left by one entry; count += 1; done[mi] != 0 instead zeroes the window, the count
+ *   and (if given) that env's prev_sol (reset_cem).  done may be NULL.  action is the [m,A] vector fed to the
+ *   model (one-hot for discrete envs, sampler.py:148-149). */
+int cadm_warm_start_shift(cadm_ctx* ctx, const float* plan, int m, float* prev_sol_io, float* action_out, void* stream);
+int cadm_history_update(cadm_ctx* ctx, const float* obs, const float* next_obs, const float* action,
+                        const int32_t* done, int m, int state_diff, int32_t* counts_io, float* hist_obs_io,
+                        float* hist_act_io, float* prev_sol_io, void* stream);
+
 /* Multi-GPU planning: candidates shard contiguously over the ranks of an RCCL communicator owned by the
  * ctx (one process per GPU).  The reference is single-device (cadm/trainers/mb_trainer.py:103-107); this
  * adds exactly one collective per CEM iteration -- ncclAllGather of the per-candidate returns

@@ -160,3 +160,33 @@ def test_predict_matches_oracle_one_step(gpu):
     ref = o["env"].obs_postproc(np.broadcast_to(o["obs"][None], delta.shape), delta)
     assert_close(nxt, ref, 2e-5, "predict() mean next state")
     assert_close(std, np.exp((lv + 2 * np.log(o["st"]["delta_std"])) / 2), 2e-5, "predict() std")
+
+
+def test_device_planner_state_matches_sampler_bookkeeping(gpu):
+    """Device-resident warm start + history ring buffer == the reference samplers' numpy bookkeeping,
+    over 14 steps (> history_length, so the shift path runs) with episode ends in between."""
+    from cadm_amd.caller import DevicePlannerState
+    from oracle.caller import SamplerState
+    m, H = 3, 8
+    model = CaDMModel(**_cadm_kwargs(normalize_input=False, n_candidates=64))
+    dev = DevicePlannerState(model, m)
+    ref = SamplerState(m, H, 18, 6, 10, state_diff=1)
+    rng = np.random.default_rng(0)
+    obs = rng.standard_normal((m, 18)).astype(np.float32)
+    for step in range(14):
+        np.testing.assert_array_equal(dev.hist_obs.cpu().numpy(), ref.history_state.astype(np.float32))
+        np.testing.assert_array_equal(dev.hist_act.cpu().numpy(), ref.history_act.astype(np.float32))
+        np.testing.assert_array_equal(dev.prev_sol.cpu().numpy(), ref.prev_sol.astype(np.float32))
+        # same planner call through the class API (host state) and through the device state: same seed/call -> same plan
+        call_before = model._call
+        plan_ref = model.get_action(obs, ref.history_state, ref.history_act, ref.prev_sol, ref.init_var)
+        model._call = call_before
+        act_dev = dev.act(obs).cpu().numpy()
+        act_ref = ref.after_plan(plan_ref)
+        np.testing.assert_array_equal(act_dev, act_ref.astype(np.float32))
+        nxt = (obs + 0.1 * rng.standard_normal((m, 18))).astype(np.float32)
+        done = np.array([step == 5, False, step in (3, 11)])
+        dev.observe(obs, act_dev, nxt, done)
+        ref.after_step(obs, act_ref.astype(np.float32), nxt, done)
+        obs = nxt
+    np.testing.assert_array_equal(dev.counts.cpu().numpy(), np.array(ref.state_counts, dtype=np.int32))
