@@ -54,25 +54,42 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(prob, n, p, budget_s=20.0):
-    """Op-for-op torch-CPU restatement of the TF1.15 graph on this node's host cores."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(prob, n, p, budget_s=15.0):
+    """Op-for-op torch-CPU restatement of the TF1.15 graph on this node's host cores (baseline only)."""
     from oracle import torch_baseline as tb
     cores = min(usable_cores(), 64)   # [5,800,200] batched matmuls stop scaling long before 64 threads
-    torch.set_num_threads(cores)
     tp = tb.prepare(prob)
     torch.manual_seed(0)
-    tb.cem_get_action(tp, n, p)               # warm-up
+    rs = prob["m"] * n * p * prob["H"] * 5
+    torch.set_num_threads(1)
+    t0 = time.time()
+    tb.cem_get_action(tp, n, p)               # doubles as warm-up; single-thread figure
+    single = time.time() - t0
+    torch.set_num_threads(cores)
+    tb.cem_get_action(tp, n, p)
     times = []
     t_start = time.time()
-    while len(times) < 5 and (time.time() - t_start) < budget_s:
+    while len(times) < 30 and (time.time() - t_start) < budget_s:
         t0 = time.time()
         tb.cem_get_action(tp, n, p)
         times.append(time.time() - t0)
     med = float(np.median(times))
-    rs = prob["m"] * n * p * prob["H"] * 5
     return dict(value=rs / med, unit="row-steps/s", cores=cores, kind="port",
-                sample="%d full cfg2 get_action calls (m=1,n=%d,p=%d,H=%d, 5 CEM iters), median %.3f s; "
-                       "torch-CPU fp32 restatement of the TF1.15 graph, torch %s" % (len(times), n, p, prob["H"], med, torch.__version__))
+                single_thread_value=rs / single, cpu_model=_cpu_model(),
+                sample="%d full %s get_action calls (m=1,n=%d,p=%d,H=%d, 5 CEM iters = %d row-steps each), median %.3f s "
+                       "on %d threads (+1 single-thread call: %.2f s); torch-CPU fp32 restatement of the TF1.15 graph with "
+                       "materialised tile/transpose/reshape, torch %s" % (len(times), prob["env"], n, p, prob["H"], rs, med, cores,
+                                                                          single, torch.__version__))
 
 
 def main():
@@ -171,7 +188,8 @@ def main():
     out = {
         "metric": "CEM rollout row-steps/s (cand x part x horizon x 5 CEM iters per get_action; ens=%d members)" % E,
         "value": value, "unit": "row-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "get_action_latency_ms": elapsed / args.steps * 1e3,
+        "plans_per_s": args.steps / elapsed, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %s PE-TS+CaDM get_action, ens=%d part=%d cand=%d (%d/GPU) H=%d m=1, random-init weights"
                                % (args.config, cfg["env"], E, p, n, n_per_gpu, H),

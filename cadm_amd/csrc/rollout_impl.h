@@ -194,6 +194,9 @@ struct Ring {
 // one chunk of this wave's stream: NFO float4 blocks + NSO dword blocks, lane-linear
 template <int SLOT, int NFO, int NSO, class G>
 __device__ __forceinline__ void ring_load(Ring<G>& ring, __amdgpu_buffer_rsrc_t rsrc, unsigned soff, int lane) {
+#ifdef CADM_ABLATE_SAME_LINES
+    soff = 0;      // developer ablation: every ring load re-reads the same few KB (L1 hits): issue cost without memory time
+#endif
 #pragma unroll
     for (int i = 0; i < NFO; ++i)
         ring.f[SLOT][i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16 + i * 1024, soff, 0));
