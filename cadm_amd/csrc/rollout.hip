@@ -45,10 +45,6 @@ int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, 
         return CADM_EINVAL;
     }
     const int rpm = m * n_local * a.PE;
-    if (ctx->HID != 200) {
-        cadm_set_error("rollout: hidden width %d not compiled in (supported: 200)", ctx->HID);
-        return CADM_EINVAL;
-    }
     switch (ctx->cfg.env_kind) {
         case CADM_ENV_HALFCHEETAH: return cadm_rollout_env_halfcheetah(ctx, a, rpm, s);
         case CADM_ENV_ANT: return cadm_rollout_env_ant(ctx, a, rpm, s);

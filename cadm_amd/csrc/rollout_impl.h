@@ -840,5 +840,20 @@ int dispatch_ctx(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) {
 
 }  // namespace
 
+// Hidden widths compiled in (all hidden layers equal).  200 is the reference default (`--hidden_size`,
+// run_cadm_pets.py:129); override with  make HIDS="128 200 256"  (each width is one more instantiation per env).
+#ifndef CADM_HID_LIST
+#define CADM_HID_LIST 200
+#endif
+#define CADM_STR2(...) #__VA_ARGS__
+#define CADM_STR(...) CADM_STR2(__VA_ARGS__)
+template <int ENV, int... HIDS>
+int dispatch_hid(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) {
+    int rc = CADM_EINVAL;
+    bool hit = false;
+    ((ctx->HID == HIDS ? (hit = true, rc = dispatch_ctx<ENV, HIDS>(ctx, a, rpm, s), 0) : 0), ...);
+    if (!hit) cadm_set_error("rollout: hidden width %d not compiled in (built with HIDS = " CADM_STR(CADM_HID_LIST) ")", ctx->HID);
+    return rc;
+}
 #define CADM_ROLLOUT_ENV(NAME, ENV) \
-    int cadm_rollout_env_##NAME(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) { return dispatch_ctx<ENV, 200>(ctx, a, rpm, s); }
+    int cadm_rollout_env_##NAME(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) { return dispatch_hid<ENV, CADM_HID_LIST>(ctx, a, rpm, s); }

@@ -307,3 +307,26 @@ def test_in_library_rccl_path_single_rank(gpu):
     finally:
         if own:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("hid", [128, 256, 512])
+def test_other_hidden_widths(gpu, hid):
+    """Hidden widths other than the reference default 200 (`--hidden_size`): tile counts 8 / 16 / 32 exercise the
+    no-K-split layer path and the k-step-split head pass."""
+    E, p, m, n, H = 5, 10, 2, 9, 5
+    prob = synth.make_problem(env="halfcheetah", E=E, m=m, H=H, hidden_sizes=(hid,) * 4, trained_like=True, seed=50 + hid)
+    eng = make_engine(prob, p=p)
+    rng = np.random.default_rng(hid)
+    actions = rng.uniform(-1, 1, (m, n, H, 6))
+    eps = rng.standard_normal((H, m, n, p, 18))
+    ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"])
+    rows, traj = eng.rollout_returns(prob["obs"], ctx, actions, eps=eps, it=1, want_traj=True)
+    o = oracle_problem(prob, np.float32)
+    T = oplanner.context_table_indexed(onets.context_forward(o["cp"], o["cp_obs"], o["cp_act"], o["st"]), 1)
+    r_ref, t_ref = oplanner.rollout_indexed(o["env"], o["ff"], o["st"], o["obs"], T, actions.astype(np.float32),
+                                            eps.astype(np.float32), E, p, False, return_traj=True)
+    assert_close(_np(traj)[0], t_ref[0], RTOL, "first step, hidden=%d" % hid)
+    assert_close(_np(traj), t_ref, 2e-4, "5-step trajectory, hidden=%d" % hid)
+    assert_close(_np(rows), r_ref, 2e-4, "returns, hidden=%d" % hid)
+    plan = eng.cem_plan(prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], 64, seed=1, call=1)
+    assert np.isfinite(_np(plan)).all()
