@@ -61,99 +61,123 @@ __device__ __forceinline__ void adam_update(float& w, float& m, float& v, float 
     w -= lr_t * m / (sqrtf(v) + eps);
 }
 
-#define TM 64
 #define TN 64
 #define TK 32
-#define LDS_LD (TM + 4)
+#define NSLAB 8                    // slabs per K panel: the whole panel (256 deep) is in flight at once
+#define LDB (TN + 4)
 
+// These GEMMs are tiny (<= 0.1 GFLOP over <= 160 workgroups): a launch is bound by the serial
+// load -> LDS -> MFMA latency chain of one workgroup, not by throughput.  So a workgroup issues the
+// global loads of a whole 256-deep K panel up front (registers), and then walks the panel slab by
+// slab -- stash slab s into its own LDS region as its loads land (the compiler's vmcnt ladder),
+// barrier, 32-deep MFMA sweep -- so the only exposed memory latency is the first slab's.
+// TM = 32*MI rows x 64 columns per workgroup; 2 x 2 waves, each (16*MI) x 32.
+template <int MI>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
+    constexpr int TM = 32 * MI;
+    constexpr int LDA = TM + 4;
     extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
-    float (*As)[LDS_LD] = reinterpret_cast<float (*)[LDS_LD]>(gemm_smem);
-    float (*Bs)[LDS_LD] = reinterpret_cast<float (*)[LDS_LD]>(gemm_smem + TK * LDS_LD);
+    float* const As = gemm_smem;                          // [NSLAB*TK][LDA]
+    float* const Bs = gemm_smem + NSLAB * TK * LDA;       // [NSLAB*TK][LDB]
     const int e = blockIdx.z;
     const int mb = blockIdx.y * TM, nb = blockIdx.x * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;            // 2 x 2 waves, each a 32 x 32 sub-tile
+    const int wm = wave >> 1, wn = wave & 1;
     const float* A = p.A + (long)e * p.sAe;
     const float* B = p.B + (long)e * p.sBe;
-    floatx4 acc[2][2];
+    floatx4 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
     float colsum = 0.0f;                                // DW: bias gradient (threads < 64 of the m-tile-0 blocks)
 
-    // Software pipeline: the global loads of slab k+1 are in flight (registers) while slab k is consumed from LDS.
-    constexpr int NLD = TM * TK / 256;   // elements per thread per slab
-    float ra[NLD], rb[NLD];
-    // per-thread element bases are fixed across slabs: hoist the row/column part of the address and the bounds test
-    const float* pa[NLD];
-    const float* pb[NLD];
-    int ka[NLD], kb[NLD], la[NLD], lb[NLD];
+    constexpr int NLA = TM * TK / 256, NLB = TN * TK / 256;   // elements per thread per slab
+    float ra[NSLAB][NLA], rb[NSLAB][NLB];
+    // Per-thread element bases are fixed across slabs.  Loads are UNCONDITIONAL (addresses clamped into the matrix,
+    // out-of-range elements zeroed afterwards): a `cond ? *p : 0` select makes hipcc branch around every load and
+    // wait for each one in turn (cdna_hip_programming.md, "three .s-level traps" (c)).
+    const float* pa[NLA];
+    const float* pb[NLB];
+    int ka[NLA], kb[NLB], la[NLA], lb[NLB];
+    bool va[NLA], vb[NLB];
 #pragma unroll
-    for (int it = 0; it < NLD; ++it) {
+    for (int it = 0; it < NLA; ++it) {
         const int idx = tid + it * 256;
         int am, ak;
-        if (p.a_mcontig) { am = idx & 63; ak = idx >> 6; } else { ak = idx & (TK - 1); am = idx / TK; }
-        ka[it] = ak; la[it] = ak * LDS_LD + am;
-        pa[it] = (mb + am < p.M) ? A + (long)(mb + am) * p.sam + (long)ak * p.sak : nullptr;
-        int bn, bk;
-        if (p.sbn == 1) { bn = idx & 63; bk = idx >> 6; } else { bk = idx & (TK - 1); bn = idx / TK; }
-        kb[it] = bk; lb[it] = bk * LDS_LD + bn;
-        pb[it] = (nb + bn < p.N) ? B + (long)bk * p.sbk + (long)(nb + bn) * p.sbn : nullptr;
+        if (p.a_mcontig) { am = idx & (TM - 1); ak = idx / TM; } else { ak = idx & (TK - 1); am = idx / TK; }
+        ka[it] = ak; la[it] = ak * LDA + am;
+        va[it] = mb + am < p.M;
+        pa[it] = A + (long)(va[it] ? mb + am : 0) * p.sam;
     }
-    const long stepa = (long)TK * p.sak, stepb = (long)TK * p.sbk;
-    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            ra[it] = (pa[it] && k0 + ka[it] < p.K) ? *pa[it] : 0.0f;
-            rb[it] = (pb[it] && k0 + kb[it] < p.K) ? *pb[it] : 0.0f;
-            if (pa[it]) pa[it] += stepa;
-            if (pb[it]) pb[it] += stepb;
+    for (int it = 0; it < NLB; ++it) {
+        const int idx = tid + it * 256;
+        int bn, bk;
+        if (p.sbn == 1) { bn = idx & (TN - 1); bk = idx / TN; } else { bk = idx & (TK - 1); bn = idx / TK; }
+        kb[it] = bk; lb[it] = bk * LDB + bn;
+        vb[it] = nb + bn < p.N;
+        pb[it] = B + (long)(vb[it] ? nb + bn : 0) * p.sbn;
+    }
+    const int kmax = p.K - 1;
+    const bool do_colsum = p.mode == MODE_DW && p.bW && blockIdx.y == 0 && tid < TN;
+
+    for (int kp = 0; kp < p.K; kp += NSLAB * TK) {
+        if (kp > 0) __syncthreads();               // previous panel fully consumed before its LDS is overwritten
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s) {
+            const int k0 = kp + s * TK;
+#pragma unroll
+            for (int it = 0; it < NLA; ++it) {
+                const int k = k0 + ka[it];
+                ra[s][it] = pa[it][(long)(k < kmax ? k : kmax) * p.sak];
+            }
+#pragma unroll
+            for (int it = 0; it < NLB; ++it) {
+                const int k = k0 + kb[it];
+                rb[s][it] = pb[it][(long)(k < kmax ? k : kmax) * p.sbk];
+            }
         }
-    };
-    auto stash = [&]() {
-        float* as = &As[0][0];
-        float* bs = &Bs[0][0];
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            as[la[it]] = ra[it];
-            bs[lb[it]] = rb[it];
+        for (int s = 0; s < NSLAB; ++s) {
+            const int k0 = kp + s * TK;
+            if (k0 >= p.K) break;
+            float* as = As + s * TK * LDA;
+            float* bs = Bs + s * TK * LDB;
+#pragma unroll
+            for (int it = 0; it < NLA; ++it) as[la[it]] = (va[it] && k0 + ka[it] <= kmax) ? ra[s][it] : 0.0f;
+#pragma unroll
+            for (int it = 0; it < NLB; ++it) bs[lb[it]] = (vb[it] && k0 + kb[it] <= kmax) ? rb[s][it] : 0.0f;
+            __syncthreads();
+            if (do_colsum) {
+#pragma unroll
+                for (int kk = 0; kk < TK; ++kk) colsum += bs[kk * LDB + tid];
+            }
+#pragma unroll
+            for (int ks = 0; ks < TK / 4; ++ks) {
+                float a[MI], b[2];
+                const int kr = ks * 4 + (lane >> 4);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = as[kr * LDA + wm * (16 * MI) + i * 16 + (lane & 15)];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = bs[kr * LDB + wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
-    };
-    fetch(0);
-    for (int k0 = 0; k0 < p.K; k0 += TK) {
-        stash();                                   // slab k0 (zero padded) -> LDS
-        __syncthreads();
-        if (k0 + TK < p.K) fetch(k0 + TK);         // next slab's loads overlap this slab's MFMAs
-        if (p.mode == MODE_DW && p.bW && blockIdx.y == 0 && tid < TN) {
-#pragma unroll
-            for (int kk = 0; kk < TK; ++kk) colsum += Bs[kk][tid];
-        }
-#pragma unroll
-        for (int ks = 0; ks < TK / 4; ++ks) {
-            float a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[ks * 4 + (lane >> 4)][wm * 32 + i * 16 + (lane & 15)];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[ks * 4 + (lane >> 4)][wn * 32 + j * 16 + (lane & 15)];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
     }
 
     // ---- epilogue: D layout col = lane & 15 -> n, row = (lane >> 4) * 4 + r -> m ----
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = mb + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+                const int m = mb + wm * (16 * MI) + i * 16 + (lane >> 4) * 4 + r;
                 const int n = nb + wn * 32 + j * 16 + (lane & 15);
                 if (m >= p.M || n >= p.N) continue;
                 const float c = acc[i][j][r];
@@ -174,7 +198,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
                     p.W[o] = w; p.Mw[o] = mo; p.Vw[o] = vo;
                 }
             }
-    if (p.mode == MODE_DW && p.bW && blockIdx.y == 0 && tid < TN && nb + tid < p.N) {
+    if (do_colsum && nb + tid < p.N) {
         const long o = (long)e * p.sbWe + nb + tid;
         float w = p.bW[o], mo = p.bM[o], vo = p.bV[o];
         adam_update(w, mo, vo, colsum, p.lr_t, p.b1, p.b2, p.eps);
@@ -471,17 +495,25 @@ extern "C" int cadm_train_reset(cadm_ctx* ctx, void* stream) {
 
 namespace {
 
-int launch_gemm(const GemmP& p, hipStream_t s) {
+template <int MI>
+int launch_gemm_t(const GemmP& p, hipStream_t s) {
+    constexpr int TM = 32 * MI;
     dim3 grid((p.N + TN - 1) / TN, (p.M + TM - 1) / TM, p.E);
-    const size_t lds = 2 * (size_t)TK * LDS_LD * sizeof(float);
+    const size_t lds = (size_t)NSLAB * TK * ((TM + 4) + LDB) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(gemm_kernel<MI>, grid, dim3(256), lds, s, p);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
+}
+
+int launch_gemm(const GemmP& p, hipStream_t s) {
+    // 32-row tiles while they still leave the 256 CUs under-subscribed (more, shorter latency chains), else 64-row tiles
+    const long wg32 = (long)((p.N + TN - 1) / TN) * ((p.M + 31) / 32) * p.E;
+    return wg32 <= 1024 ? launch_gemm_t<1>(p, s) : launch_gemm_t<2>(p, s);
 }
 
 // H = act(X W + b): X [E,B,ldx] (first K columns used), W [E,K,N]
