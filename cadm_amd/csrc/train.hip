@@ -1,16 +1,24 @@
 // Training step of the ensemble (reference cadm/dynamics/mlp_cadm_ensemble_cem_dynamics.py:269-317;
 // vanilla twin mlp_ensemble_cem_dynamics.py:148-170): forward of the context / forward / backward
-// nets on one [E,B,.] bootstrap batch, the losses, hand-written backward GEMMs and TF1-semantics Adam.
+// nets on one [E,B,.] bootstrap batch, the losses, hand-written backward and TF1-semantics Adam.
 //
-// One batched fp32-MFMA GEMM kernel (v_mfma_f32_16x16x4_f32, 64x64 tile per workgroup, LDS-staged
-// 32-deep K slabs) serves all three products through strides, with the layer's pointwise work fused
-// into its epilogue:
-//   FWD  H = act(X W + b)            stores z (pre-activation) and h
-//   DX   dZ_prev = (dZ W^T) * act'(z_prev)   (optionally accumulating: the context vector feeds 2 nets)
-//   DW   W <- Adam(W, X^T dZ + c*wd*W), b <- Adam(b, colsum dZ)   -- the gradient never touches HBM
-// Everything is launch-ordered on one stream: a layer's DX (which reads W) runs before its DW (which
-// overwrites W).
+// The batch is tiny (B = 256 rows x 5 members, < 3 GFLOP per step), so a step is bound by dependent-
+// launch overhead (~4.5 us per kernel on this part) and by per-workgroup latency chains, not by
+// throughput.  The step is therefore built from THREE fat kernels instead of one GEMM per layer:
+//   chain_kernel (forward)   a workgroup owns 16 batch rows of one member of one net and walks the whole
+//                            layer chain (context encoder -> dynamics net -> heads) with the activations
+//                            resident in LDS; weights stream from L2 straight into the MFMA B operand
+//                            through a register ring (no LDS staging: a weight is used by exactly one
+//                            wave).  z / h of every layer are stored for the backward pass.
+//   chain_kernel (backward)  same kernel, transposed weight indexing: dZ_{l-1} = (dZ_l W_l^T) * act'(z_{l-1})
+//                            down the chain; once for the forward+backward nets, once for the context net.
+//   dw_adam_kernel           every layer's W <- Adam(W, X^T dZ + c*wd*W), b <- Adam(b, colsum dZ) as ONE
+//                            grouped launch over a tile table (the gradient never touches HBM).
+// A chain is described by a small stage table in device memory (LOAD / GEMM stages, rebuilt only when
+// a pointer changes).  Everything is launch-ordered on one stream: the backward chains (which read W)
+// run before the grouped DW launch (which overwrites W).
 #include <math.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -18,26 +26,6 @@ namespace {
 
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
 enum { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
-
-struct GemmP {
-    const float *A, *B;
-    long sAe, sBe;                 // member strides (elements)
-    int M, N, K, E;                // C[e] is M x N, reduction over K
-    long sam, sak, sbk, sbn;       // A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
-    int a_mcontig;                 // 1: A is contiguous along m (load mapping for coalescing)
-    int mode, act;
-    // FWD
-    const float* bias; long sbe;   // bias[e][n]
-    float* Zout; float* Hout; long ldo, sOe;   // z / h outputs [E][M][ldo] (+ column offset baked into the pointer)
-    // DX
-    const float* Zprev; long ldzp, sZpe;       // pre-activation of the producing layer [E][M][ldzp]
-    float* DXout; long lddx, sDXe; int accumulate;
-    // DW (+ Adam)
-    float *W, *Mw, *Vw; long ldw, sWe;         // W[e][M][N] row-major (ldw = N)
-    float *bW, *bM, *bV; long sbWe;            // bias[e][N] (null: no bias update)
-    float wdc;                                 // weight_decay_coeff * wd (d l2 / dW = wdc * W)
-    float lr_t, b1, b2, eps;
-};
 
 __device__ __forceinline__ float act_fwd(int act, float z) {
     if (act == ACT_SWISH) return z * (1.0f / (1.0f + expf(-z)));
@@ -61,42 +49,216 @@ __device__ __forceinline__ void adam_update(float& w, float& m, float& v, float 
     w -= lr_t * m / (sqrtf(v) + eps);
 }
 
-#define TN 64
-#define TK 32
-#define NSLAB 8                    // slabs per K panel: the whole panel (256 deep) is in flight at once
-#define LDB (TN + 4)
+// ---------------------------------------------------------------------------------------------
+// chain kernel: a list of LOAD / GEMM stages over a 16-row batch tile held in LDS
+// ---------------------------------------------------------------------------------------------
+enum { ST_LOAD = 0, ST_GEMM = 1 };
+#define CH_ROWS 16
+#define CH_PF 8            // k-steps of weights in flight per wave (register ring)
+#define CH_MAXSTAGE 20
 
-// These GEMMs are tiny (<= 0.1 GFLOP over <= 160 workgroups): a launch is bound by the serial
-// load -> LDS -> MFMA latency chain of one workgroup, not by throughput.  So a workgroup issues the
-// global loads of a whole 256-deep K panel up front (registers), and then walks the panel slab by
-// slab -- stash slab s into its own LDS region as its loads land (the compiler's vmcnt ladder),
-// barrier, 32-deep MFMA sweep -- so the only exposed memory latency is the first slab's.
-// TM = 32*MI rows x 64 columns per workgroup; 2 x 2 waves, each (16*MI) x 32.
-template <int MI>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
-    constexpr int TM = 32 * MI;
-    constexpr int LDA = TM + 4;
-    extern __shared__ __attribute__((aligned(16))) float gemm_smem[];
-    float* const As = gemm_smem;                          // [NSLAB*TK][LDA]
-    float* const Bs = gemm_smem + NSLAB * TK * LDA;       // [NSLAB*TK][LDB]
-    const int e = blockIdx.z;
-    const int mb = blockIdx.y * TM, nb = blockIdx.x * TN;
+struct ChainPart {         // one product term of a GEMM stage: acc += src[16 x K] * Bop[K x N]
+    const float* W;        // [E][.][ldw]
+    long sWe;              // member stride (elements)
+    int ldw;               // row stride of W
+    int wt;                // 0: Bop(k,n) = W[k][n]   1: Bop(k,n) = W[row0 + n][k]  (backward: dZ W^T)
+    int row0, K, src, pad;
+};
+struct ChainStage {
+    int kind, N, nparts, act_d, act_o, dst, dk0, K;      // K, ld_in: LOAD only
+    ChainPart part[2];
+    const float *bias, *zprev, *g0, *g1;                 // g0 (+ g1): LOAD sources [E][B][ld_in]
+    float *out0, *out1, *gsum;                           // out0: value before act_o, out1: after; gsum: LOAD echo
+    int ldz, ldo, ld_in, pad;
+};
+struct ChainArgs {
+    const ChainStage* prog;
+    int first[2], count[2];                              // stage range per blockIdx.y
+    int B, bufsz;                                        // rows per member, floats per LDS activation buffer
+};
+
+// acc[j] += src(16 x K) * Bop(K x 16) for the NT column tiles nb + 16 j of this wave.  A comes from the LDS
+// activation buffer (k-major, lds[k * 16 + m]: the A fragment read is lane-linear), B straight from global
+// memory, CH_PF k-steps ahead.  Addresses are clamped, never predicated; steps beyond K multiply A = 0.
+template <int NT>
+__device__ __forceinline__ void chain_kloop(floatx4 (&acc)[4], const ChainPart& pt, const float* __restrict__ src, int e, int nb,
+                                            int N, int lane) {
+    const int c = lane & 15, kq = lane >> 4;
+    const float* Wm = pt.W + (long)e * pt.sWe;
+    const int ks = pt.wt ? 1 : pt.ldw;
+    const int ns = pt.wt ? pt.ldw : 1;
+    const float* pj[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int n = nb + 16 * j + c;
+        n = n < N ? n : N - 1;
+        pj[j] = Wm + (long)(pt.row0 + n) * ns;
+    }
+    const int K = pt.K, kmax = K - 1;
+    const int nsteps = (K + 3) >> 2;
+    float ring[CH_PF][NT];
+#pragma unroll
+    for (int u = 0; u < CH_PF; ++u) {
+        const int k = 4 * u + kq;
+        const int off = (k < kmax ? k : kmax) * ks;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) ring[u][j] = pj[j][off];
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += CH_PF) {
+#pragma unroll
+        for (int u = 0; u < CH_PF; ++u) {
+            const int k = 4 * (s0 + u) + kq;
+            const float a = k < K ? src[k * CH_ROWS + c] : 0.0f;
+            float b[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = ring[u][j];
+            const int kn = k + 4 * CH_PF;
+            const int off = (kn < kmax ? kn : kmax) * ks;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ring[u][j] = pj[j][off];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[j], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float chain_smem[];
+    ChainStage* const stg = reinterpret_cast<ChainStage*>(chain_smem);
+    float* const bufs = chain_smem + (CH_MAXSTAGE * sizeof(ChainStage)) / sizeof(float);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e = blockIdx.z, row0 = blockIdx.x * CH_ROWS, B = a.B;
+    const int nst = a.count[blockIdx.y];
+    {   // stage table of this chain -> LDS (one memory latency instead of one per stage)
+        const int* g = reinterpret_cast<const int*>(a.prog + a.first[blockIdx.y]);
+        int* l = reinterpret_cast<int*>(stg);
+        const int nw = nst * (int)(sizeof(ChainStage) / sizeof(int));
+        for (int i = tid; i < nw; i += 256) l[i] = g[i];
+    }
+    __syncthreads();
+    const int c = lane & 15, q = lane >> 4;
+    for (int si = 0; si < nst; ++si) {
+        const ChainStage& st = stg[si];
+        if (st.kind == ST_LOAD) {
+            float* dst = bufs + st.dst * a.bufsz;
+            const int K = st.K;
+            for (int idx = tid; idx < CH_ROWS * K; idx += 256) {
+                const int m = idx / K, k = idx - m * K;
+                const int row = row0 + m;
+                float v = 0.0f;
+                if (row < B) {
+                    const long o = ((long)e * B + row) * st.ld_in + k;
+                    v = st.g0[o];
+                    if (st.g1) v += st.g1[o];
+                    if (st.gsum) st.gsum[((long)e * B + row) * st.ldo + k] = v;
+                }
+                dst[(st.dk0 + k) * CH_ROWS + m] = v;
+            }
+        } else {
+            const int N = st.N;
+            for (int nb = wave * 64; nb < N; nb += 256) {
+                const int nt = (N - nb + 15) >> 4;
+                floatx4 acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+                // epilogue operands requested before the k loop so that their latency hides under it
+                float zp[4][4], bv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int n = nb + 16 * j + c;
+                    n = n < N ? n : N - 1;
+                    bv[j] = st.bias ? st.bias[(long)e * N + n] : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = row0 + 4 * q + r;
+                        row = row < B ? row : B - 1;
+                        zp[j][r] = st.zprev ? st.zprev[((long)e * B + row) * st.ldz + n] : 0.0f;
+                    }
+                }
+                for (int pi = 0; pi < st.nparts; ++pi) {
+                    const ChainPart& pt = st.part[pi];
+                    const float* src = bufs + pt.src * a.bufsz;
+                    if (nt >= 4) chain_kloop<4>(acc, pt, src, e, nb, N, lane);
+                    else if (nt == 3) chain_kloop<3>(acc, pt, src, e, nb, N, lane);
+                    else if (nt == 2) chain_kloop<2>(acc, pt, src, e, nb, N, lane);
+                    else chain_kloop<1>(acc, pt, src, e, nb, N, lane);
+                }
+                // D layout: col = lane & 15 -> n, row = (lane >> 4) * 4 + r -> batch row
+                float* dst = st.dst >= 0 ? bufs + st.dst * a.bufsz : nullptr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = nb + 16 * j + c;
+                    if (n >= N) continue;
+                    floatx4 w;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = row0 + 4 * q + r;
+                        float v = acc[j][r] + bv[j];
+                        if (st.zprev) v *= act_bwd(st.act_d, zp[j][r]);
+                        const long o = ((long)e * B + row) * st.ldo + n;
+                        if (st.out0 && row < B) st.out0[o] = v;
+                        v = act_fwd(st.act_o, v);
+                        if (st.out1 && row < B) st.out1[o] = v;
+                        w[r] = v;
+                    }
+                    if (dst) *reinterpret_cast<floatx4*>(dst + (st.dk0 + n) * CH_ROWS + 4 * q) = w;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// grouped weight-gradient GEMM with the Adam update fused into its epilogue
+// ---------------------------------------------------------------------------------------------
+struct DwJob {                       // W[e] (M x N) <- Adam(W, X[e]^T dZ[e] + wdc W);  b[e] <- Adam(b, colsum dZ[e])
+    const float *X, *dZ;             // X [E][B][ldx] (first M columns), dZ [E][B][N]
+    float *W, *Mw, *Vw, *bW, *bM, *bV;
+    int ldx, M, N, tile0;            // tile0: first workgroup (blockIdx.x) of this job
+    float wdc;
+    int tn;                          // column tiles
+};
+#define DW_MAXJOBS 20
+struct DwArgs {
+    DwJob job[DW_MAXJOBS];
+    int njobs, B;
+    float lr_t, b1, b2, eps;
+};
+
+#define TN 64
+#define TM 32
+#define TK 32
+#define LDA (TM + 4)
+#define LDB (TN + 4)
+#define DW_NSLAB 4                   // slabs per K panel: the whole panel (128 deep) is in flight at once
+
+// One 32 x 64 tile of one job per workgroup, reduction over the batch.  The global loads of a whole K panel are
+// issued up front (registers) and the panel is then walked slab by slab -- stash slab s into its own LDS
+// region as its loads land, barrier, 32-deep MFMA sweep -- so a panel exposes one memory latency, not one
+// per slab.  2 x 2 waves, each 16 x 32.
+__global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[DW_NSLAB * TK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[DW_NSLAB * TK * LDB];
+    int ji = 0;
+#pragma unroll 1
+    while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].tile0) ++ji;
+    const DwJob& jb = a.job[ji];
+    const int t = blockIdx.x - jb.tile0;
+    const int e = blockIdx.y;
+    const int mb = (t / jb.tn) * TM, nb = (t % jb.tn) * TN;
+    const int M = jb.M, N = jb.N, K = a.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const float* A = p.A + (long)e * p.sAe;
-    const float* B = p.B + (long)e * p.sBe;
-    floatx4 acc[MI][2];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    float colsum = 0.0f;                                // DW: bias gradient (threads < 64 of the m-tile-0 blocks)
-
-    constexpr int NLA = TM * TK / 256, NLB = TN * TK / 256;   // elements per thread per slab
-    float ra[NSLAB][NLA], rb[NSLAB][NLB];
-    // Per-thread element bases are fixed across slabs.  Loads are UNCONDITIONAL (addresses clamped into the matrix,
-    // out-of-range elements zeroed afterwards): a `cond ? *p : 0` select makes hipcc branch around every load and
-    // wait for each one in turn (cdna_hip_programming.md, "three .s-level traps" (c)).
+    const float* A = jb.X + (long)e * K * jb.ldx;       // A(m = k_in, k = b) = X[b][k_in]
+    const float* Bm = jb.dZ + (long)e * K * N;          // B(k = b, n)        = dZ[b][n]
+    floatx4 acc[2];
+    acc[0] = acc[1] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float colsum = 0.0f;                                // bias gradient (threads < 64 of the m-tile-0 blocks)
+    constexpr int NLA = TM * TK / 256, NLB = TN * TK / 256;
+    float ra[DW_NSLAB][NLA], rb[DW_NSLAB][NLB];
+    // Loads are UNCONDITIONAL (addresses clamped into the matrix, out-of-range elements zeroed afterwards): a
+    // `cond ? *p : 0` select makes hipcc branch around every load and wait for each one in turn.
     const float* pa[NLA];
     const float* pb[NLB];
     int ka[NLA], kb[NLB], la[NLA], lb[NLB];
@@ -104,44 +266,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
 #pragma unroll
     for (int it = 0; it < NLA; ++it) {
         const int idx = tid + it * 256;
-        int am, ak;
-        if (p.a_mcontig) { am = idx & (TM - 1); ak = idx / TM; } else { ak = idx & (TK - 1); am = idx / TK; }
+        const int am = idx & (TM - 1), ak = idx / TM;
         ka[it] = ak; la[it] = ak * LDA + am;
-        va[it] = mb + am < p.M;
-        pa[it] = A + (long)(va[it] ? mb + am : 0) * p.sam;
+        va[it] = mb + am < M;
+        pa[it] = A + (va[it] ? mb + am : 0);
     }
 #pragma unroll
     for (int it = 0; it < NLB; ++it) {
         const int idx = tid + it * 256;
-        int bn, bk;
-        if (p.sbn == 1) { bn = idx & (TN - 1); bk = idx / TN; } else { bk = idx & (TK - 1); bn = idx / TK; }
+        const int bn = idx & (TN - 1), bk = idx / TN;
         kb[it] = bk; lb[it] = bk * LDB + bn;
-        vb[it] = nb + bn < p.N;
-        pb[it] = B + (long)(vb[it] ? nb + bn : 0) * p.sbn;
+        vb[it] = nb + bn < N;
+        pb[it] = Bm + (vb[it] ? nb + bn : 0);
     }
-    const int kmax = p.K - 1;
-    const bool do_colsum = p.mode == MODE_DW && p.bW && blockIdx.y == 0 && tid < TN;
+    const int kmax = K - 1;
+    const bool do_colsum = jb.bW && mb == 0 && tid < TN;
 
-    for (int kp = 0; kp < p.K; kp += NSLAB * TK) {
+    for (int kp = 0; kp < K; kp += DW_NSLAB * TK) {
         if (kp > 0) __syncthreads();               // previous panel fully consumed before its LDS is overwritten
 #pragma unroll
-        for (int s = 0; s < NSLAB; ++s) {
+        for (int s = 0; s < DW_NSLAB; ++s) {
             const int k0 = kp + s * TK;
 #pragma unroll
             for (int it = 0; it < NLA; ++it) {
                 const int k = k0 + ka[it];
-                ra[s][it] = pa[it][(long)(k < kmax ? k : kmax) * p.sak];
+                ra[s][it] = pa[it][(long)(k < kmax ? k : kmax) * jb.ldx];
             }
 #pragma unroll
             for (int it = 0; it < NLB; ++it) {
                 const int k = k0 + kb[it];
-                rb[s][it] = pb[it][(long)(k < kmax ? k : kmax) * p.sbk];
+                rb[s][it] = pb[it][(long)(k < kmax ? k : kmax) * N];
             }
         }
 #pragma unroll
-        for (int s = 0; s < NSLAB; ++s) {
+        for (int s = 0; s < DW_NSLAB; ++s) {
             const int k0 = kp + s * TK;
-            if (k0 >= p.K) break;
+            if (k0 >= K) break;
             float* as = As + s * TK * LDA;
             float* bs = Bs + s * TK * LDB;
 #pragma unroll
@@ -155,60 +315,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
             }
 #pragma unroll
             for (int ks = 0; ks < TK / 4; ++ks) {
-                float a[MI], b[2];
                 const int kr = ks * 4 + (lane >> 4);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) a[i] = as[kr * LDA + wm * (16 * MI) + i * 16 + (lane & 15)];
+                const float av = as[kr * LDA + wm * 16 + (lane & 15)];
+                float b[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) b[j] = bs[kr * LDB + wn * 32 + j * 16 + (lane & 15)];
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j], acc[j], 0, 0, 0);
             }
         }
     }
 
     // ---- epilogue: D layout col = lane & 15 -> n, row = (lane >> 4) * 4 + r -> m ----
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = mb + wm * (16 * MI) + i * 16 + (lane >> 4) * 4 + r;
-                const int n = nb + wn * 32 + j * 16 + (lane & 15);
-                if (m >= p.M || n >= p.N) continue;
-                const float c = acc[i][j][r];
-                if (p.mode == MODE_FWD) {
-                    const float z = c + p.bias[(long)e * p.sbe + n];
-                    const long o = (long)e * p.sOe + (long)m * p.ldo + n;
-                    if (p.Zout) p.Zout[o] = z;
-                    p.Hout[o] = act_fwd(p.act, z);
-                } else if (p.mode == MODE_DX) {
-                    float g = c;
-                    if (p.Zprev) g *= act_bwd(p.act, p.Zprev[(long)e * p.sZpe + (long)m * p.ldzp + n]);
-                    const long o = (long)e * p.sDXe + (long)m * p.lddx + n;
-                    p.DXout[o] = p.accumulate ? p.DXout[o] + g : g;
-                } else {
-                    const long o = (long)e * p.sWe + (long)m * p.ldw + n;
-                    float w = p.W[o], mo = p.Mw[o], vo = p.Vw[o];
-                    adam_update(w, mo, vo, c + p.wdc * w, p.lr_t, p.b1, p.b2, p.eps);
-                    p.W[o] = w; p.Mw[o] = mo; p.Vw[o] = vo;
-                }
-            }
-    if (do_colsum && nb + tid < p.N) {
-        const long o = (long)e * p.sbWe + nb + tid;
-        float w = p.bW[o], mo = p.bM[o], vo = p.bV[o];
-        adam_update(w, mo, vo, colsum, p.lr_t, p.b1, p.b2, p.eps);
-        p.bW[o] = w; p.bM[o] = mo; p.bV[o] = vo;
+        for (int r = 0; r < 4; ++r) {
+            const int m = mb + wm * 16 + (lane >> 4) * 4 + r;
+            const int n = nb + wn * 32 + j * 16 + (lane & 15);
+            if (m >= M || n >= N) continue;
+            const long o = ((long)e * M + m) * N + n;
+            float w = jb.W[o], mo = jb.Mw[o], vo = jb.Vw[o];
+            adam_update(w, mo, vo, acc[j][r] + jb.wdc * w, a.lr_t, a.b1, a.b2, a.eps);
+            jb.W[o] = w; jb.Mw[o] = mo; jb.Vw[o] = vo;
+        }
+    if (do_colsum && nb + tid < N) {
+        const long o = (long)e * N + nb + tid;
+        float w = jb.bW[o], mo = jb.bM[o], vo = jb.bV[o];
+        adam_update(w, mo, vo, colsum, a.lr_t, a.b1, a.b2, a.eps);
+        jb.bW[o] = w; jb.bM[o] = mo; jb.bV[o] = vo;
     }
-}
-
-__global__ void mul_actgrad_kernel(float* g, const float* z, long n, int act) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i < n) g[i] *= act_bwd(act, z[i]);
 }
 
 // elementwise Adam for tensors whose gradient is a closed form: g = gscale * gsrc (+ wdc * w)
@@ -266,14 +402,6 @@ __global__ void assemble_kernel(const AsmP p) {
             p.Xcp[(long)row * n + i] = v;
         }
     }
-}
-
-__global__ void copy_cols_kernel(const float* src, long lds_, float* dst, long ldd, int cols, long rows) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= rows * cols) return;
-    const long r = i / cols;
-    const int c = (int)(i % cols);
-    dst[r * ldd + c] = src[r * lds_ + c];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -367,8 +495,9 @@ __global__ void finalize_loss_kernel(const float* red, int det, float back_coeff
 // host side
 // ---------------------------------------------------------------------------------------------
 struct NetBufs {
-    std::vector<float*> z, h;     // per hidden layer [E,B,width]
+    std::vector<float*> z, h, dz;     // per hidden layer [E,B,width]; dz: gradient w.r.t. the pre-activation
     float *mu = nullptr, *lv = nullptr;
+    float* dctx = nullptr;            // this net's gradient w.r.t. its context input columns [E,B,C]
 };
 
 struct AdamSlot { float *m = nullptr, *v = nullptr; size_t n = 0; };
@@ -381,19 +510,25 @@ struct TrainState {
     float* ws = nullptr;          // one workspace allocation
     size_t ws_floats = 0;
     // views
-    float *Xff = nullptr, *Xbk = nullptr, *Xcp = nullptr, *dCtx = nullptr, *ctxo = nullptr;
+    float *Xff = nullptr, *Xbk = nullptr, *Xcp = nullptr, *dCtx = nullptr;
     NetBufs ff, bk, cp;
-    float *dA = nullptr, *dBuf = nullptr, *dMu = nullptr, *dLv = nullptr, *dBmu = nullptr, *terms = nullptr, *red = nullptr;
+    float *dMu = nullptr, *dLv = nullptr, *dBmu = nullptr, *terms = nullptr, *red = nullptr;
     // Adam moments, same order as the registered layers: W then b
     std::vector<AdamSlot> a_ff, a_bk, a_cp;   // 2 per layer
     AdamSlot a_mx, a_mn;
     float* adam_buf = nullptr;
+    // chain programs: [fwd ff | fwd back | bwd ff | bwd back | bwd context]
+    std::vector<ChainStage> prog_host;
+    ChainStage* prog_dev = nullptr;
+    int prog_first[5] = {0, 0, 0, 0, 0}, prog_count[5] = {0, 0, 0, 0, 0};
+    int chain_bufsz = 0;
 };
 
 void cadm_train_free(cadm_ctx* ctx) {
     if (!ctx->train) return;
     if (ctx->train->ws) (void)hipFree(ctx->train->ws);
     if (ctx->train->adam_buf) (void)hipFree(ctx->train->adam_buf);
+    if (ctx->train->prog_dev) (void)hipFree(ctx->train->prog_dev);
     delete ctx->train;
     ctx->train = nullptr;
 }
@@ -435,27 +570,36 @@ static int ensure_workspace(cadm_ctx* ctx, int B) {
     const int NH = ctx->NH, HID = ctx->HID, D = ctx->D, K0 = ctx->K0;
     const int ncp = ctx->C > 0 ? ctx->cfg.n_cp_hidden : 0;
     const int cpin = (ctx->D + ctx->A) * ctx->cfg.history_length;
-    int maxw = HID > K0 ? HID : K0;
-    for (int l = 0; l < ncp; ++l) maxw = ctx->cfg.cp_hidden[l] > maxw ? ctx->cfg.cp_hidden[l] : maxw;
+    const size_t Cw = ctx->C > 0 ? ctx->C : 1;
     size_t total = 0;
     auto need = [&](size_t n) { size_t o = total; total += (n + 63) & ~(size_t)63; return o; };
     const size_t oXff = need(R * K0), oXbk = need(R * K0), oXcp = need(R * (cpin > 0 ? cpin : 1));
-    const size_t odCtx = need(R * (ctx->C > 0 ? ctx->C : 1)), octxo = need(R * (ctx->C > 0 ? ctx->C : 1));
-    std::vector<size_t> oz_ff(NH), oh_ff(NH), oz_bk(NH), oh_bk(NH), oz_cp(ncp), oh_cp(ncp);
-    for (int l = 0; l < NH; ++l) { oz_ff[l] = need(R * HID); oh_ff[l] = need(R * HID); oz_bk[l] = need(R * HID); oh_bk[l] = need(R * HID); }
-    for (int l = 0; l < ncp; ++l) { oz_cp[l] = need(R * ctx->cfg.cp_hidden[l]); oh_cp[l] = need(R * ctx->cfg.cp_hidden[l]); }
+    const size_t odCtx = need(R * Cw), odCff = need(R * Cw), odCbk = need(R * Cw);
+    std::vector<size_t> oz_ff(NH), oh_ff(NH), od_ff(NH), oz_bk(NH), oh_bk(NH), od_bk(NH), oz_cp(ncp), oh_cp(ncp), od_cp(ncp);
+    for (int l = 0; l < NH; ++l) {
+        oz_ff[l] = need(R * HID); oh_ff[l] = need(R * HID); od_ff[l] = need(R * HID);
+        oz_bk[l] = need(R * HID); oh_bk[l] = need(R * HID); od_bk[l] = need(R * HID);
+    }
+    for (int l = 0; l < ncp; ++l) {
+        const size_t w = ctx->cfg.cp_hidden[l];
+        oz_cp[l] = need(R * w); oh_cp[l] = need(R * w); od_cp[l] = need(R * w);
+    }
     const size_t omu = need(R * D), olv = need(R * D), obmu = need(R * D), oblv = need(R * D);
-    const size_t odA = need(R * maxw), odB = need(R * maxw), odMu = need(R * D), odLv = need(R * D), odBmu = need(R * D);
+    const size_t odMu = need(R * D), odLv = need(R * D), odBmu = need(R * D);
     const size_t oterms = need(7 * R * D), ored = need(4 + 2 * (size_t)D + 8);
     CADM_CHECK_HIP(hipMalloc(&t->ws, total * sizeof(float)));
     t->ws_floats = total;
     float* w = t->ws;
-    t->Xff = w + oXff; t->Xbk = w + oXbk; t->Xcp = w + oXcp; t->dCtx = w + odCtx; t->ctxo = w + octxo;
-    t->ff.z.resize(NH); t->ff.h.resize(NH); t->bk.z.resize(NH); t->bk.h.resize(NH); t->cp.z.resize(ncp); t->cp.h.resize(ncp);
-    for (int l = 0; l < NH; ++l) { t->ff.z[l] = w + oz_ff[l]; t->ff.h[l] = w + oh_ff[l]; t->bk.z[l] = w + oz_bk[l]; t->bk.h[l] = w + oh_bk[l]; }
-    for (int l = 0; l < ncp; ++l) { t->cp.z[l] = w + oz_cp[l]; t->cp.h[l] = w + oh_cp[l]; }
+    t->Xff = w + oXff; t->Xbk = w + oXbk; t->Xcp = w + oXcp; t->dCtx = w + odCtx; t->ff.dctx = w + odCff; t->bk.dctx = w + odCbk;
+    for (NetBufs* nb : {&t->ff, &t->bk}) { nb->z.resize(NH); nb->h.resize(NH); nb->dz.resize(NH); }
+    t->cp.z.resize(ncp); t->cp.h.resize(ncp); t->cp.dz.resize(ncp);
+    for (int l = 0; l < NH; ++l) {
+        t->ff.z[l] = w + oz_ff[l]; t->ff.h[l] = w + oh_ff[l]; t->ff.dz[l] = w + od_ff[l];
+        t->bk.z[l] = w + oz_bk[l]; t->bk.h[l] = w + oh_bk[l]; t->bk.dz[l] = w + od_bk[l];
+    }
+    for (int l = 0; l < ncp; ++l) { t->cp.z[l] = w + oz_cp[l]; t->cp.h[l] = w + oh_cp[l]; t->cp.dz[l] = w + od_cp[l]; }
     t->ff.mu = w + omu; t->ff.lv = w + olv; t->bk.mu = w + obmu; t->bk.lv = w + oblv;
-    t->dA = w + odA; t->dBuf = w + odB; t->dMu = w + odMu; t->dLv = w + odLv; t->dBmu = w + odBmu;
+    t->dMu = w + odMu; t->dLv = w + odLv; t->dBmu = w + odBmu;
     t->terms = w + oterms; t->red = w + ored;
     t->B = B;
     return CADM_OK;
@@ -495,66 +639,148 @@ extern "C" int cadm_train_reset(cadm_ctx* ctx, void* stream) {
 
 namespace {
 
-template <int MI>
-int launch_gemm_t(const GemmP& p, hipStream_t s) {
-    constexpr int TM = 32 * MI;
-    dim3 grid((p.N + TN - 1) / TN, (p.M + TM - 1) / TM, p.E);
-    const size_t lds = (size_t)NSLAB * TK * ((TM + 4) + LDB) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+enum { PROG_FWD_FF = 0, PROG_FWD_BK = 1, PROG_BWD_FF = 2, PROG_BWD_BK = 3, PROG_BWD_CP = 4 };
+
+ChainStage load_stage(const float* g0, const float* g1, float* gsum, int ld_in, int ldo, int K, int dst, int dk0) {
+    ChainStage s{};
+    s.kind = ST_LOAD; s.g0 = g0; s.g1 = g1; s.gsum = gsum; s.ld_in = ld_in; s.ldo = ldo; s.K = K; s.dst = dst; s.dk0 = dk0;
+    return s;
+}
+
+ChainPart part_of(const DenseRef& L, int wt, int row0, int K, int src) {
+    ChainPart p{};
+    p.W = L.W; p.sWe = (long)L.din * L.dout; p.ldw = L.dout; p.wt = wt; p.row0 = row0; p.K = K; p.src = src;
+    return p;
+}
+
+// Builds the five stage lists for the current pointers and uploads them if anything changed.
+int sync_programs(cadm_ctx* ctx, hipStream_t s) {
+    TrainState* t = ctx->train;
+    const bool has_back = ctx->cfg.back_model != 0, has_cp = ctx->C > 0, det = ctx->cfg.deterministic != 0;
+    const int NH = ctx->NH, HID = ctx->HID, D = ctx->D, K0 = ctx->K0, C = ctx->C, PA = ctx->P + ctx->A;
+    const int ncp = has_cp ? ctx->cfg.n_cp_hidden : 0;
+    const int cpin = (ctx->D + ctx->A) * ctx->cfg.history_length;
+    std::vector<ChainStage> prog;
+    int first[5], count[5];
+    int maxk = K0 > HID ? K0 : HID;
+    maxk = D > maxk ? D : maxk;
+    if (has_cp) { maxk = cpin > maxk ? cpin : maxk; for (int l = 0; l < ncp; ++l) maxk = ctx->cfg.cp_hidden[l] > maxk ? ctx->cfg.cp_hidden[l] : maxk; }
+
+    auto fwd_prog = [&](const std::vector<DenseRef>& net, float* X, NetBufs& nb, bool store_cp, bool want_lv) {
+        int cur = 0;
+        if (has_cp) {
+            prog.push_back(load_stage(t->Xcp, nullptr, nullptr, cpin, 0, cpin, 0, 0));
+            for (int l = 0; l <= ncp; ++l) {
+                const DenseRef& L = ctx->cp[l];
+                ChainStage g{};
+                g.kind = ST_GEMM; g.N = L.dout; g.nparts = 1; g.part[0] = part_of(L, 0, 0, L.din, cur);
+                g.bias = L.b; g.dst = cur ^ 1;
+                if (l < ncp) {
+                    g.act_o = ACT_RELU; g.ldo = L.dout;
+                    if (store_cp) { g.out0 = t->cp.z[l]; g.out1 = t->cp.h[l]; }
+                } else {   // context vector -> the ctx columns of this net's input (LDS and global)
+                    g.act_o = ACT_NONE; g.out1 = X + PA; g.ldo = K0; g.dk0 = PA;
+                }
+                prog.push_back(g);
+                cur ^= 1;
+            }
+            prog.push_back(load_stage(X, nullptr, nullptr, K0, 0, PA, cur, 0));
+        } else {
+            prog.push_back(load_stage(X, nullptr, nullptr, K0, 0, K0, 0, 0));
+        }
+        for (int l = 0; l < NH; ++l) {
+            ChainStage g{};
+            g.kind = ST_GEMM; g.N = HID; g.nparts = 1; g.part[0] = part_of(net[l], 0, 0, net[l].din, cur);
+            g.bias = net[l].b; g.act_o = ACT_SWISH; g.out0 = nb.z[l]; g.out1 = nb.h[l]; g.ldo = HID; g.dst = cur ^ 1;
+            prog.push_back(g);
+            cur ^= 1;
+        }
+        for (int hd = 0; hd < (want_lv ? 2 : 1); ++hd) {
+            ChainStage g{};
+            g.kind = ST_GEMM; g.N = D; g.nparts = 1; g.part[0] = part_of(net[NH + hd], 0, 0, HID, cur);
+            g.bias = net[NH + hd].b; g.act_o = ACT_NONE; g.out1 = hd ? nb.lv : nb.mu; g.ldo = D; g.dst = -1;
+            prog.push_back(g);
+        }
+    };
+    auto bwd_prog = [&](const std::vector<DenseRef>& net, NetBufs& nb, const float* dMu, const float* dLv) {
+        prog.push_back(load_stage(dMu, nullptr, nullptr, D, 0, D, 0, 0));
+        if (dLv) prog.push_back(load_stage(dLv, nullptr, nullptr, D, 0, D, 1, 0));
+        {   // d z_{NH-1} = (dMu W_mu^T (+ dLv W_lv^T)) * swish'(z_{NH-1})
+            ChainStage g{};
+            g.kind = ST_GEMM; g.N = HID; g.nparts = dLv ? 2 : 1;
+            g.part[0] = part_of(net[NH], 1, 0, D, 0);
+            if (dLv) g.part[1] = part_of(net[NH + 1], 1, 0, D, 1);
+            g.zprev = nb.z[NH - 1]; g.ldz = HID; g.act_d = ACT_SWISH; g.out1 = nb.dz[NH - 1]; g.ldo = HID; g.dst = 2;
+            prog.push_back(g);
+        }
+        int cur = 2;
+        for (int l = NH - 1; l >= 1; --l) {
+            ChainStage g{};
+            g.kind = ST_GEMM; g.N = net[l].din; g.nparts = 1; g.part[0] = part_of(net[l], 1, 0, net[l].dout, cur);
+            g.zprev = nb.z[l - 1]; g.ldz = HID; g.act_d = ACT_SWISH; g.out1 = nb.dz[l - 1]; g.ldo = HID; g.dst = (cur + 1) % 3;
+            prog.push_back(g);
+            cur = (cur + 1) % 3;
+        }
+        if (has_cp) {   // only the context columns of the input carry a gradient
+            ChainStage g{};
+            g.kind = ST_GEMM; g.N = C; g.nparts = 1; g.part[0] = part_of(net[0], 1, PA, net[0].dout, cur);
+            g.out1 = nb.dctx; g.ldo = C; g.dst = -1;
+            prog.push_back(g);
+        }
+    };
+
+    first[PROG_FWD_FF] = (int)prog.size(); fwd_prog(ctx->ff, t->Xff, t->ff, true, !det); count[PROG_FWD_FF] = (int)prog.size() - first[PROG_FWD_FF];
+    first[PROG_FWD_BK] = (int)prog.size(); if (has_back) fwd_prog(ctx->back, t->Xbk, t->bk, false, false); count[PROG_FWD_BK] = (int)prog.size() - first[PROG_FWD_BK];
+    first[PROG_BWD_FF] = (int)prog.size(); bwd_prog(ctx->ff, t->ff, t->dMu, det ? nullptr : t->dLv); count[PROG_BWD_FF] = (int)prog.size() - first[PROG_BWD_FF];
+    first[PROG_BWD_BK] = (int)prog.size(); if (has_back) bwd_prog(ctx->back, t->bk, t->dBmu, nullptr); count[PROG_BWD_BK] = (int)prog.size() - first[PROG_BWD_BK];
+    first[PROG_BWD_CP] = (int)prog.size();
+    if (has_cp) {
+        prog.push_back(load_stage(t->ff.dctx, has_back ? t->bk.dctx : nullptr, t->dCtx, C, C, C, 0, 0));
+        int cur = 0;
+        for (int l = ncp; l >= 1; --l) {
+            const DenseRef& L = ctx->cp[l];
+            ChainStage g{};
+            g.kind = ST_GEMM; g.N = L.din; g.nparts = 1; g.part[0] = part_of(L, 1, 0, L.dout, cur);
+            g.zprev = t->cp.z[l - 1]; g.ldz = L.din; g.act_d = ACT_RELU; g.out1 = t->cp.dz[l - 1]; g.ldo = L.din; g.dst = cur ^ 1;
+            prog.push_back(g);
+            cur ^= 1;
+        }
     }
-    hipLaunchKernelGGL(gemm_kernel<MI>, grid, dim3(256), lds, s, p);
-    CADM_CHECK_HIP(hipGetLastError());
+    count[PROG_BWD_CP] = (int)prog.size() - first[PROG_BWD_CP];
+    for (int i = 0; i < 5; ++i) CADM_REQUIRE(count[i] <= CH_MAXSTAGE, "training chain too long (more than 20 stages): too many layers");
+
+    const bool same = t->prog_dev && prog.size() == t->prog_host.size() &&
+                      memcmp(prog.data(), t->prog_host.data(), prog.size() * sizeof(ChainStage)) == 0;
+    if (!same) {
+        if (t->prog_dev && prog.size() > t->prog_host.size()) { (void)hipFree(t->prog_dev); t->prog_dev = nullptr; }
+        if (!t->prog_dev) CADM_CHECK_HIP(hipMalloc(&t->prog_dev, prog.size() * sizeof(ChainStage)));
+        CADM_CHECK_HIP(hipStreamSynchronize(s));   // nothing in flight may still read the old table
+        CADM_CHECK_HIP(hipMemcpy(t->prog_dev, prog.data(), prog.size() * sizeof(ChainStage), hipMemcpyHostToDevice));
+        t->prog_host = prog;
+    }
+    for (int i = 0; i < 5; ++i) { t->prog_first[i] = first[i]; t->prog_count[i] = count[i]; }
+    t->chain_bufsz = CH_ROWS * ((maxk + 3) & ~3);
     return CADM_OK;
 }
 
-int launch_gemm(const GemmP& p, hipStream_t s) {
-    // 32-row tiles while they still leave the 256 CUs under-subscribed (more, shorter latency chains), else 64-row tiles
-    const long wg32 = (long)((p.N + TN - 1) / TN) * ((p.M + 31) / 32) * p.E;
-    return wg32 <= 1024 ? launch_gemm_t<1>(p, s) : launch_gemm_t<2>(p, s);
-}
-
-// H = act(X W + b): X [E,B,ldx] (first K columns used), W [E,K,N]
-int fwd_layer(cadm_ctx* ctx, int B, const float* X, int ldx, const DenseRef& L, int act, float* Z, float* H, int ldo,
-              hipStream_t s) {
-    GemmP p{};
-    p.A = X; p.sAe = (long)B * ldx; p.sam = ldx; p.sak = 1; p.a_mcontig = 0;
-    p.B = L.W; p.sBe = (long)L.din * L.dout; p.sbk = L.dout; p.sbn = 1;
-    p.M = B; p.N = L.dout; p.K = L.din; p.E = ctx->E;
-    p.mode = MODE_FWD; p.act = act;
-    p.bias = L.b; p.sbe = L.dout;
-    p.Zout = Z; p.Hout = H; p.ldo = ldo; p.sOe = (long)B * ldo;
-    return launch_gemm(p, s);
-}
-
-// dXsub = (dZ W[k0:k0+kn, :]^T) * act'(zprev)
-int dx_layer(cadm_ctx* ctx, int B, const float* dZ, const DenseRef& L, int k0, int kn, const float* Zprev, int act,
-             float* DX, int lddx, int accumulate, hipStream_t s) {
-    GemmP p{};
-    p.A = dZ; p.sAe = (long)B * L.dout; p.sam = L.dout; p.sak = 1; p.a_mcontig = 0;
-    p.B = L.W + (long)k0 * L.dout; p.sBe = (long)L.din * L.dout; p.sbk = 1; p.sbn = L.dout;   // B(k=n_out, n=k_in) = W[k_in][n_out]
-    p.M = B; p.N = kn; p.K = L.dout; p.E = ctx->E;
-    p.mode = MODE_DX; p.act = act;
-    p.Zprev = Zprev; p.ldzp = kn; p.sZpe = (long)B * kn;
-    p.DXout = DX; p.lddx = lddx; p.sDXe = (long)B * lddx; p.accumulate = accumulate;
-    return launch_gemm(p, s);
-}
-
-// W <- Adam(W, X^T dZ + wdc W), b <- Adam(b, colsum dZ)
-int dw_layer(cadm_ctx* ctx, int B, const float* X, int ldx, const float* dZ, const DenseRef& L, float wdc, AdamSlot& aw,
-             AdamSlot& ab, float lr_t, hipStream_t s) {
-    const cadm_train_hparams& hp = ctx->train->hp;
-    GemmP p{};
-    p.A = X; p.sAe = (long)B * ldx; p.sam = 1; p.sak = ldx; p.a_mcontig = 1;      // A(m=k_in, k=b) = X[b][k_in]
-    p.B = dZ; p.sBe = (long)B * L.dout; p.sbk = L.dout; p.sbn = 1;
-    p.M = L.din; p.N = L.dout; p.K = B; p.E = ctx->E;
-    p.mode = MODE_DW;
-    p.W = L.W; p.Mw = aw.m; p.Vw = aw.v; p.ldw = L.dout; p.sWe = (long)L.din * L.dout;
-    p.bW = L.b; p.bM = ab.m; p.bV = ab.v; p.sbWe = L.dout;
-    p.wdc = wdc; p.lr_t = lr_t; p.b1 = hp.beta1; p.b2 = hp.beta2; p.eps = hp.epsilon;
-    return launch_gemm(p, s);
+int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
+    TrainState* t = ctx->train;
+    ChainArgs a{};
+    a.prog = t->prog_dev;
+    a.first[0] = t->prog_first[p0]; a.count[0] = t->prog_count[p0];
+    int ny = 1;
+    if (p1 >= 0 && t->prog_count[p1] > 0) { a.first[1] = t->prog_first[p1]; a.count[1] = t->prog_count[p1]; ny = 2; }
+    a.B = B; a.bufsz = t->chain_bufsz;
+    const size_t lds = CH_MAXSTAGE * sizeof(ChainStage) + 3 * (size_t)t->chain_bufsz * sizeof(float);
+    CADM_REQUIRE(lds <= 160 * 1024, "training chain: layer too wide for the LDS-resident activation tile");
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(chain_kernel, dim3((B + CH_ROWS - 1) / CH_ROWS, ny, ctx->E), dim3(256), lds, s, a);
+    CADM_CHECK_HIP(hipGetLastError());
+    return CADM_OK;
 }
 
 int adam_elem(float* w, AdamSlot& a, const float* gsrc, float gscale, float gconst, float wdc, const cadm_train_hparams& hp,
@@ -565,19 +791,15 @@ int adam_elem(float* w, AdamSlot& a, const float* gsrc, float gscale, float gcon
     return CADM_OK;
 }
 
-}  // namespace
-
-namespace {
 // forward of the context / forward (/ backward) nets on one [E,B,.] batch into the workspace
 int forward_nets(cadm_ctx* ctx, const float* obs, const float* act, const float* obs_next, const float* cp_obs,
                  const float* cp_act, int B, bool has_back, hipStream_t s) {
     TrainState* t = ctx->train;
-    const bool has_cp = ctx->C > 0, det = ctx->cfg.deterministic != 0;
-    const int E = ctx->E, NH = ctx->NH, HID = ctx->HID, D = ctx->D, K0 = ctx->K0, C = ctx->C, PA = ctx->P + ctx->A;
-    const int ncp = has_cp ? ctx->cfg.n_cp_hidden : 0;
-    const int cpin = (ctx->D + ctx->A) * ctx->cfg.history_length;
+    const bool has_cp = ctx->C > 0;
+    const int E = ctx->E, D = ctx->D, K0 = ctx->K0;
     const long R = (long)E * B;
     int rc;
+    if ((rc = sync_programs(ctx, s))) return rc;
     AsmP ap{};
     ap.obs = obs; ap.obs_next = obs_next; ap.act = act; ap.cp_obs = cp_obs; ap.cp_act = cp_act;
     ap.obs_mean = ctx->st.obs_mean; ap.obs_std = ctx->st.obs_std; ap.act_mean = ctx->st.act_mean; ap.act_std = ctx->st.act_std;
@@ -589,38 +811,7 @@ int forward_nets(cadm_ctx* ctx, const float* obs, const float* act, const float*
     ap.env = ctx->cfg.env_kind; ap.has_back = has_back; ap.has_cp = has_cp;
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)R), dim3(64), 0, s, ap);
     CADM_CHECK_HIP(hipGetLastError());
-    if (has_cp) {
-        const float* x = t->Xcp;
-        int ldx = cpin;
-        for (int l = 0; l < ncp; ++l) {
-            if ((rc = fwd_layer(ctx, B, x, ldx, ctx->cp[l], ACT_RELU, t->cp.z[l], t->cp.h[l], ctx->cp[l].dout, s))) return rc;
-            x = t->cp.h[l]; ldx = ctx->cp[l].dout;
-        }
-        // context vector straight into the ctx columns of the forward net's input; copied for the backward net
-        if ((rc = fwd_layer(ctx, B, x, ldx, ctx->cp[ncp], ACT_NONE, nullptr, t->Xff + PA, K0, s))) return rc;
-        if (has_back) {
-            hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((R * C + 255) / 256)), dim3(256), 0, s, t->Xff + PA, (long)K0,
-                               t->Xbk + PA, (long)K0, C, R);
-            CADM_CHECK_HIP(hipGetLastError());
-        }
-    }
-    auto net_fwd = [&](const std::vector<DenseRef>& net, const float* X, NetBufs& nb, bool want_lv) -> int {
-        const float* x = X;
-        int ldx = K0;
-        for (int l = 0; l < NH; ++l) {
-            int r = fwd_layer(ctx, B, x, ldx, net[l], ACT_SWISH, nb.z[l], nb.h[l], HID, s);
-            if (r) return r;
-            x = nb.h[l]; ldx = HID;
-        }
-        int r = fwd_layer(ctx, B, x, HID, net[NH], ACT_NONE, nullptr, nb.mu, D, s);
-        if (r) return r;
-        if (want_lv) r = fwd_layer(ctx, B, x, HID, net[NH + 1], ACT_NONE, nullptr, nb.lv, D, s);
-        return r;
-    };
-    if ((rc = net_fwd(ctx->ff, t->Xff, t->ff, !det))) return rc;
-    if (has_back && (rc = net_fwd(ctx->back, t->Xbk, t->bk, false))) return rc;
-
-    return CADM_OK;
+    return launch_chain(ctx, B, PROG_FWD_FF, has_back ? PROG_FWD_BK : -1, s);
 }
 
 __global__ void clamp_logvar_kernel(const float* lv, const float* maxlv, const float* minlv, float* out, long n, int D) {
@@ -647,7 +838,7 @@ extern "C" int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act
     if (rc) return rc;
     TrainState* t = ctx->train;
     const cadm_train_hparams& hp = t->hp;
-    const int E = ctx->E, NH = ctx->NH, HID = ctx->HID, D = ctx->D, K0 = ctx->K0, C = ctx->C, PA = ctx->P + ctx->A;
+    const int E = ctx->E, NH = ctx->NH, HID = ctx->HID, D = ctx->D, K0 = ctx->K0;
     const int ncp = has_cp ? ctx->cfg.n_cp_hidden : 0;
     const int cpin = (ctx->D + ctx->A) * ctx->cfg.history_length;
     const long R = (long)E * B;
@@ -673,64 +864,49 @@ extern "C" int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act
                                (1.0 - pow((double)hp.beta1, (double)t->step)));
     const float coeff = hp.weight_decay_coeff;
     auto wd_dyn = [&](int l) { return coeff * (l < NH ? hp.weight_decays[l] : hp.weight_decays[NH]); };
-    if (has_cp) CADM_CHECK_HIP(hipMemsetAsync(t->dCtx, 0, (size_t)R * C * sizeof(float), s));
 
-    auto backward_net = [&](std::vector<DenseRef>& net, const float* X, NetBufs& nb, std::vector<AdamSlot>& ad,
-                            const float* dMu, const float* dLv, bool lv_l2_only) -> int {
-        int r;
-        float* dcur = t->dA;     // gradient w.r.t. the pre-activation of hidden layer NH-1
-        float* dnext = t->dBuf;
-        // d h_{NH-1} = dMu W_mu^T (+ dLv W_lv^T), then * swish'(z_{NH-1})
-        if ((r = dx_layer(ctx, B, dMu, net[NH], 0, HID, nullptr, ACT_NONE, dcur, HID, 0, s))) return r;
-        if (dLv && (r = dx_layer(ctx, B, dLv, net[NH + 1], 0, HID, nullptr, ACT_NONE, dcur, HID, 1, s))) return r;
-        hipLaunchKernelGGL(mul_actgrad_kernel, dim3((unsigned)((R * HID + 255) / 256)), dim3(256), 0, s, dcur, nb.z[NH - 1],
-                           R * HID, (int)ACT_SWISH);
-        CADM_CHECK_HIP(hipGetLastError());
-        // head weights
-        if ((r = dw_layer(ctx, B, nb.h[NH - 1], HID, dMu, net[NH], wd_dyn(NH), ad[2 * NH], ad[2 * NH + 1], lr_t, s))) return r;
-        if (dLv) {
-            if ((r = dw_layer(ctx, B, nb.h[NH - 1], HID, dLv, net[NH + 1], wd_dyn(NH + 1), ad[2 * (NH + 1)], ad[2 * (NH + 1) + 1], lr_t, s))) return r;
-        } else if (lv_l2_only) {
-            // output_logvar is outside the data path (deterministic / backward net): its weight only sees the L2 term,
-            // its bias has no gradient at all and is skipped like TF does
-            if ((r = adam_elem(net[NH + 1].W, ad[2 * (NH + 1)], nullptr, 0.f, 0.f, wd_dyn(NH + 1), hp, lr_t, s))) return r;
-        }
-        for (int l = NH - 1; l >= 0; --l) {
-            const float* xin = l == 0 ? X : nb.h[l - 1];
-            const int ldx = l == 0 ? K0 : HID;
-            if (l > 0) {
-                if ((r = dx_layer(ctx, B, dcur, net[l], 0, HID, nb.z[l - 1], ACT_SWISH, dnext, HID, 0, s))) return r;
-            } else if (has_cp) {
-                // only the context columns of the input carry a gradient; both nets accumulate into dCtx
-                if ((r = dx_layer(ctx, B, dcur, net[0], PA, C, nullptr, ACT_NONE, t->dCtx, C, 1, s))) return r;
-            }
-            if ((r = dw_layer(ctx, B, xin, ldx, dcur, net[l], wd_dyn(l), ad[2 * l], ad[2 * l + 1], lr_t, s))) return r;
-            float* tmp = dcur; dcur = dnext; dnext = tmp;
-        }
+    // backward chains (read W) ...
+    if ((rc = launch_chain(ctx, B, PROG_BWD_FF, has_back ? PROG_BWD_BK : -1, s))) return rc;
+    if (has_cp && (rc = launch_chain(ctx, B, PROG_BWD_CP, -1, s))) return rc;
+
+    // ... then every layer's weight gradient + Adam as one grouped launch (overwrites W)
+    DwArgs da{};
+    da.B = B; da.lr_t = lr_t; da.b1 = hp.beta1; da.b2 = hp.beta2; da.eps = hp.epsilon;
+    int tiles = 0;
+    auto add_job = [&](const float* X, int ldx, const float* dZ, const DenseRef& L, float wdc, AdamSlot& aw, AdamSlot& ab) -> int {
+        CADM_REQUIRE(da.njobs < DW_MAXJOBS, "cadm_train_step: too many layers for the grouped weight-gradient launch");
+        DwJob& j = da.job[da.njobs++];
+        j.X = X; j.dZ = dZ; j.W = L.W; j.Mw = aw.m; j.Vw = aw.v; j.bW = L.b; j.bM = ab.m; j.bV = ab.v;
+        j.ldx = ldx; j.M = L.din; j.N = L.dout; j.tile0 = tiles; j.wdc = wdc; j.tn = (L.dout + TN - 1) / TN;
+        tiles += j.tn * ((L.din + TM - 1) / TM);
         return CADM_OK;
     };
-    if ((rc = backward_net(ctx->ff, t->Xff, t->ff, t->a_ff, t->dMu, det ? nullptr : t->dLv, det))) return rc;
-    if (has_back && (rc = backward_net(ctx->back, t->Xbk, t->bk, t->a_bk, t->dBmu, nullptr, true))) return rc;
+    auto net_jobs = [&](std::vector<DenseRef>& net, const float* X, NetBufs& nb, std::vector<AdamSlot>& ad, const float* dMu,
+                        const float* dLv) -> int {
+        int r;
+        for (int l = 0; l < NH; ++l)
+            if ((r = add_job(l == 0 ? X : nb.h[l - 1], l == 0 ? K0 : HID, nb.dz[l], net[l], wd_dyn(l), ad[2 * l], ad[2 * l + 1]))) return r;
+        if ((r = add_job(nb.h[NH - 1], HID, dMu, net[NH], wd_dyn(NH), ad[2 * NH], ad[2 * NH + 1]))) return r;
+        if (dLv && (r = add_job(nb.h[NH - 1], HID, dLv, net[NH + 1], wd_dyn(NH + 1), ad[2 * (NH + 1)], ad[2 * (NH + 1) + 1]))) return r;
+        return CADM_OK;
+    };
+    if ((rc = net_jobs(ctx->ff, t->Xff, t->ff, t->a_ff, t->dMu, det ? nullptr : t->dLv))) return rc;
+    if (has_back && (rc = net_jobs(ctx->back, t->Xbk, t->bk, t->a_bk, t->dBmu, nullptr))) return rc;
+    if (has_cp) {
+        auto wd_cp = [&](int l) { return coeff * (l < ncp ? hp.context_weight_decays[l] : hp.context_weight_decays[ncp]); };
+        for (int l = 0; l <= ncp; ++l)
+            if ((rc = add_job(l == 0 ? t->Xcp : t->cp.h[l - 1], l == 0 ? cpin : ctx->cp[l - 1].dout, l == ncp ? t->dCtx : t->cp.dz[l],
+                              ctx->cp[l], wd_cp(l), t->a_cp[2 * l], t->a_cp[2 * l + 1]))) return rc;
+    }
+    hipLaunchKernelGGL(dw_adam_kernel, dim3(tiles, E), dim3(256), 0, s, da);
+    CADM_CHECK_HIP(hipGetLastError());
+    // output_logvar outside the data path (deterministic forward net / backward net): its weight only sees the L2 term,
+    // its bias has no gradient at all and is skipped like TF does
+    if (det && (rc = adam_elem(ctx->ff[NH + 1].W, t->a_ff[2 * (NH + 1)], nullptr, 0.f, 0.f, wd_dyn(NH + 1), hp, lr_t, s))) return rc;
+    if (has_back && (rc = adam_elem(ctx->back[NH + 1].W, t->a_bk[2 * (NH + 1)], nullptr, 0.f, 0.f, wd_dyn(NH + 1), hp, lr_t, s))) return rc;
     if (!det) {   // max/min_logvar of the forward net: data term + 0.01 regulariser (dynamics.py:308)
         if ((rc = adam_elem(ctx->ff_maxlv, t->a_mx, t->red + 4, 1.0f, 0.01f, 0.0f, hp, lr_t, s))) return rc;
         if ((rc = adam_elem(ctx->ff_minlv, t->a_mn, t->red + 4 + D, 1.0f, -0.01f, 0.0f, hp, lr_t, s))) return rc;
-    }
-    if (has_cp) {
-        auto wd_cp = [&](int l) { return coeff * (l < ncp ? hp.context_weight_decays[l] : hp.context_weight_decays[ncp]); };
-        float* dcur = t->dCtx;      // gradient w.r.t. the (linear) context output
-        float* bufs[2] = {t->dA, t->dBuf};
-        int flip = 0;
-        for (int l = ncp; l >= 0; --l) {
-            const float* xin = l == 0 ? t->Xcp : t->cp.h[l - 1];
-            const int ldx = l == 0 ? cpin : ctx->cp[l - 1].dout;
-            float* dprev = nullptr;
-            if (l > 0) {
-                dprev = bufs[flip]; flip ^= 1;
-                if ((rc = dx_layer(ctx, B, dcur, ctx->cp[l], 0, ctx->cp[l].din, t->cp.z[l - 1], ACT_RELU, dprev, ctx->cp[l].din, 0, s))) return rc;
-            }
-            if ((rc = dw_layer(ctx, B, xin, ldx, dcur, ctx->cp[l], wd_cp(l), t->a_cp[2 * l], t->a_cp[2 * l + 1], lr_t, s))) return rc;
-            dcur = dprev;
-        }
     }
     ctx->packed = false;   // planner streams are stale until cadm_repack
     return CADM_OK;
