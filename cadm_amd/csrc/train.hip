@@ -27,18 +27,18 @@ namespace {
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
 enum { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
 
+// Branch-free on the activation kind (uniform selects): v_exp_f32 / v_rcp_f32 sigmoid like the planner's swish_f.
+__device__ __forceinline__ float sigmoid_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
 __device__ __forceinline__ float act_fwd(int act, float z) {
-    if (act == ACT_SWISH) return z * (1.0f / (1.0f + expf(-z)));
-    if (act == ACT_RELU) return fmaxf(z, 0.0f);
-    return z;
+    const float sw = z * sigmoid_fast(z);
+    const float r = act == ACT_RELU ? fmaxf(z, 0.0f) : z;
+    return act == ACT_SWISH ? sw : r;
 }
 __device__ __forceinline__ float act_bwd(int act, float z) {   // d act / d z
-    if (act == ACT_SWISH) {
-        const float s = 1.0f / (1.0f + expf(-z));
-        return s * (1.0f + z * (1.0f - s));
-    }
-    if (act == ACT_RELU) return z > 0.0f ? 1.0f : 0.0f;
-    return 1.0f;
+    const float sg = sigmoid_fast(z);
+    const float sw = sg * (1.0f + z * (1.0f - sg));
+    const float r = act == ACT_RELU ? (z > 0.0f ? 1.0f : 0.0f) : 1.0f;
+    return act == ACT_SWISH ? sw : r;
 }
 
 __device__ __forceinline__ void adam_update(float& w, float& m, float& v, float g, float lr_t, float b1, float b2,
@@ -53,8 +53,14 @@ __device__ __forceinline__ void adam_update(float& w, float& m, float& v, float 
 // chain kernel: a list of LOAD / GEMM stages over a 16-row batch tile held in LDS
 // ---------------------------------------------------------------------------------------------
 enum { ST_LOAD = 0, ST_GEMM = 1 };
+// Pointers read out of a stage table are generic to the compiler (flat_load: slower, and it ties the vector-memory
+// counter to the LDS one); they all point to device memory, so say so.
+typedef __attribute__((address_space(1))) const float* gcptr;
+typedef __attribute__((address_space(1))) float* gptr;
+__device__ __forceinline__ gcptr as_global(const float* p) { return (gcptr)p; }
+__device__ __forceinline__ gptr as_global(float* p) { return (gptr)p; }
 #define CH_ROWS 16
-#define CH_PF 8            // k-steps of weights in flight per wave (register ring)
+#define CH_AD 3            // A fragments are read from LDS this many k-steps ahead
 #define CH_MAXSTAGE 20
 
 struct ChainPart {         // one product term of a GEMM stage: acc += src[16 x K] * Bop[K x N]
@@ -71,55 +77,220 @@ struct ChainStage {
     float *out0, *out1, *gsum;                           // out0: value before act_o, out1: after; gsum: LOAD echo
     int ldz, ldo, ld_in, pad;
 };
+#define CH_MAXPF 24
 struct ChainArgs {
     const ChainStage* prog;
-    int first[2], count[2];                              // stage range per blockIdx.y
+    int first[2], count[2];                              // stage range per chain (y)
     int B, bufsz;                                        // rows per member, floats per LDS activation buffer
+    int E, ny, ntiles, G, ips;                           // work decomposition, see chain_kernel
+    int npf;                                             // weight tensors to pull into this XCD's L2 up front
+    const float* pf_ptr[CH_MAXPF]; int pf_n[CH_MAXPF];   // base, floats per member
+    unsigned long long* tbuf;                            // cadm_debug_set_timing_buffer: per-stage clock of workgroup (0, y, 0)
 };
 
-// acc[j] += src(16 x K) * Bop(K x 16) for the NT column tiles nb + 16 j of this wave.  A comes from the LDS
-// activation buffer (k-major, lds[k * 16 + m]: the A fragment read is lane-linear), B straight from global
-// memory, CH_PF k-steps ahead.  Addresses are clamped, never predicated; steps beyond K multiply A = 0.
-template <int NT>
-__device__ __forceinline__ void chain_kloop(floatx4 (&acc)[4], const ChainPart& pt, const float* __restrict__ src, int e, int nb,
-                                            int N, int lane) {
+typedef __attribute__((address_space(1))) const char* gcbytes;
+typedef __attribute__((address_space(1))) const floatx4* gcptr4;
+
+// acc[j] += src(16 x K) * Bop(K x 16) for NT column tiles of this wave.  A comes from the LDS activation buffer
+// (k-major, lds[k * 16 + m]), B straight from global memory through a register ring PF k-steps deep, addressed as
+// (uniform base of the k-step) + (per-lane byte offset).  Three load shapes:
+//   MODE 0  dword per (tile, k-step); tile j <-> column nb + 16 j + c; any N, K, either weight orientation
+//   MODE 1  forward (Bop(k,n) = W[k][n]), N % 4 == 0: one b128 per k-step holds the 4 tiles, tile j <-> column nb + 4 c + j
+//   MODE 2  transposed (Bop(k,n) = W[n][k]), K % 4 == 0: one b128 per (tile, 4 k-steps), k-step 4 t + i <-> k = 16 t + 4 kq + i
+// The k loop is straight-line code (two fully unrolled ring blocks with forward exits) inside a rarely-iterating
+// outer loop: with a back edge around the ring hipcc falls back to s_waitcnt vmcnt(0) at every block, which
+// serialises load latency and MFMA work.  At most 60 loads are in flight (vmcnt is a 6-bit counter).
+// Nothing is predicated: k-step indices are clamped to the last one, whose lanes beyond K use offsets clamped
+// into the matrix, and A is zeroed for k >= K.
+template <int NT, int MODE>
+__device__ __forceinline__ void chain_kloop(floatx4 (&acc)[NT], const ChainPart& pt, const float* src, int e, int nb, int N,
+                                            int lane) {
+    constexpr int PF = MODE ? 32 : (NT == 1 ? 32 : NT == 2 ? 28 : NT == 3 ? 20 : 12);
+    constexpr int NR0 = MODE == 0 ? PF : 1, NR1 = MODE == 1 ? PF : 1, NR2 = MODE == 2 ? PF / 4 : 1;
     const int c = lane & 15, kq = lane >> 4;
-    const float* Wm = pt.W + (long)e * pt.sWe;
-    const int ks = pt.wt ? 1 : pt.ldw;
-    const int ns = pt.wt ? pt.ldw : 1;
-    const float* pj[NT];
+    const int K = pt.K;
+    const int nsteps = MODE == 2 ? ((K + 15) >> 4) * 4 : (K + 3) >> 2, last = nsteps - 1;
+    gcbytes Wm = (gcbytes)(as_global(pt.W) + (long)e * pt.sWe);
+    long step_bytes;                                        // per k-step (MODE 0/1) or per 4 k-steps (MODE 2)
+    unsigned boff[NT], boffl[NT];                           // per-lane byte offsets: regular / last (clamped) step
+    if (MODE == 0) {
+        const int ks = pt.wt ? 1 : pt.ldw, ns = pt.wt ? pt.ldw : 1;
+        const int kql = 4 * last + kq < K ? kq : K - 1 - 4 * last;
+        step_bytes = 16L * ks;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        int n = nb + 16 * j + c;
-        n = n < N ? n : N - 1;
-        pj[j] = Wm + (long)(pt.row0 + n) * ns;
-    }
-    const int K = pt.K, kmax = K - 1;
-    const int nsteps = (K + 3) >> 2;
-    float ring[CH_PF][NT];
+        for (int j = 0; j < NT; ++j) {
+            int n = nb + 16 * j + c;
+            n = n < N ? n : N - 1;
+            boff[j] = 4u * (unsigned)((pt.row0 + n) * ns + kq * ks);
+            boffl[j] = 4u * (unsigned)((pt.row0 + n) * ns + kql * ks);
+        }
+    } else if (MODE == 1) {
+        int n4 = nb + 4 * c;
+        n4 = n4 < N ? n4 : N - 4;
+        const int kql = 4 * last + kq < K ? kq : K - 1 - 4 * last;
+        step_bytes = 16L * pt.ldw;
+        boff[0] = 4u * (unsigned)(n4 + kq * pt.ldw);
+        boffl[0] = 4u * (unsigned)(n4 + kql * pt.ldw);
+    } else {
+        const int lastq = last >> 2;
+        const int k4l = 16 * lastq + 4 * kq <= K - 4 ? 4 * kq : K - 4 - 16 * lastq;
+        step_bytes = 64L;
 #pragma unroll
-    for (int u = 0; u < CH_PF; ++u) {
-        const int k = 4 * u + kq;
-        const int off = (k < kmax ? k : kmax) * ks;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) ring[u][j] = pj[j][off];
-    }
-    for (int s0 = 0; s0 < nsteps; s0 += CH_PF) {
-#pragma unroll
-        for (int u = 0; u < CH_PF; ++u) {
-            const int k = 4 * (s0 + u) + kq;
-            const float a = k < K ? src[k * CH_ROWS + c] : 0.0f;
-            float b[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = ring[u][j];
-            const int kn = k + 4 * CH_PF;
-            const int off = (kn < kmax ? kn : kmax) * ks;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) ring[u][j] = pj[j][off];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) {
+            int n = nb + 16 * j + c;
+            n = n < N ? n : N - 1;
+            boff[j] = 4u * (unsigned)((pt.row0 + n) * pt.ldw + 4 * kq);
+            boffl[j] = 4u * (unsigned)((pt.row0 + n) * pt.ldw + k4l);
         }
     }
+    float ring0[NR0][NT];
+    floatx4 ring1[NR1];
+    floatx4 ring2[NR2][NT];
+    float ar[4];
+    // issue the loads of k-step sidx (MODE 2: of the 4 k-steps starting at sidx) into ring slot u
+    auto issue = [&](int u, int sidx) {
+        if (MODE == 2) sidx >>= 2;
+        const int lim = MODE == 2 ? last >> 2 : last;
+        const int sc = sidx < lim ? sidx : lim;
+        gcbytes base = Wm + sc * step_bytes;
+        const bool tail = sidx >= lim;
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ring0[u][j] = *reinterpret_cast<gcptr>(base + (tail ? boffl[j] : boff[j]));
+        } else if (MODE == 1) {
+            ring1[u] = *reinterpret_cast<gcptr4>(base + (tail ? boffl[0] : boff[0]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) ring2[u >> 2][j] = *reinterpret_cast<gcptr4>(base + (tail ? boffl[j] : boff[j]));
+        }
+    };
+    // raw LDS read of the A fragment of k-step sidx (clamped); lanes with k >= K are zeroed at use (a_valid)
+    auto read_a = [&](int sidx) {
+        const int sc = sidx < last ? sidx : last;
+        if (MODE == 2) return src[(16 * (sc >> 2) + 4 * kq + (sc & 3)) * CH_ROWS + c];
+        return src[sc * 64 + lane];
+    };
+    const int vsteps = MODE == 2 ? ((K - 4 * kq + 15) >> 4) * 4 : (K - kq + 3) >> 2;   // this lane's k < K  <=>  sidx < vsteps
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (MODE != 2 || (u & 3) == 0) issue(u, u);
+#pragma unroll
+    for (int u = 0; u < CH_AD; ++u) ar[u] = read_a(u);
+    for (int s00 = 0; s00 < nsteps; s00 += 2 * PF) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int s0 = s00 + blk * PF;
+            if (blk > 0 && s0 >= nsteps) break;
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if ((u & 7) == 0 && u > 0 && s0 + u >= nsteps) break;     // uniform early exit, 8-step granularity
+                float b[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b[j] = MODE == 0 ? ring0[u][j] : MODE == 1 ? ring1[u][j] : ring2[u >> 2][j][u & 3];
+                const float av = s0 + u < vsteps ? ar[u & 3] : 0.0f;
+                if (MODE != 2) issue(u, s0 + u + PF);
+                else if ((u & 3) == 3) issue(u - 3, s0 + u - 3 + PF);
+                ar[(u + CH_AD) & 3] = read_a(s0 + u + CH_AD);
+                __builtin_amdgcn_sched_barrier(0);     // keep the LDS read CH_AD steps ahead of its use
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+// One GEMM stage for NT column tiles of this wave (VECN: tile j <-> column nb + 4 c + j, else nb + 16 j + c): all parts,
+// then the epilogue.
+template <int NT, bool VECN>
+__device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, int bufsz, int e, int B, int row0, int nb,
+                                            int lane) {
+    const int c = lane & 15, q = lane >> 4, N = st.N;
+    floatx4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // epilogue operands requested before the k loop so that their latency hides under it
+    float zp[NT][4], bv[NT];
+    const bool has_z = st.zprev != nullptr, has_b = st.bias != nullptr;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int n = VECN ? nb + 4 * c + j : nb + 16 * j + c;
+        n = n < N ? n : N - 1;
+        gcptr bp = as_global(has_b ? st.bias : st.part[0].W) + (has_b ? (long)e * N + n : 0);
+        bv[j] = *bp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = row0 + 4 * q + r;
+            row = row < B ? row : B - 1;
+            gcptr zq = as_global(has_z ? st.zprev : st.part[0].W) + (has_z ? ((long)e * B + row) * st.ldz + n : 0);
+            zp[j][r] = *zq;
+        }
+    }
+    for (int pi = 0; pi < st.nparts; ++pi) {
+        const ChainPart& pt = st.part[pi];
+        const float* src = bufs + pt.src * bufsz;
+        if (VECN) chain_kloop<NT, 1>(acc, pt, src, e, nb, N, lane);
+        else if (pt.wt && (pt.K & 3) == 0 && (pt.ldw & 3) == 0) chain_kloop<NT, 2>(acc, pt, src, e, nb, N, lane);
+        else chain_kloop<NT, 0>(acc, pt, src, e, nb, N, lane);
+    }
+    // D layout: col = lane & 15 -> column slot c, row = (lane >> 4) * 4 + r -> batch row
+    float* dst = st.dst >= 0 ? bufs + st.dst * bufsz : nullptr;
+    const int act_d = st.act_d, act_o = st.act_o;
+    gptr out0 = as_global(st.out0), out1 = as_global(st.out1);
+    const bool s0 = st.out0 != nullptr, s1 = st.out1 != nullptr;
+    floatx4 v0[NT], v1[NT];                       // [tile][r]: before / after the output activation
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[j][r] + (has_b ? bv[j] : 0.0f);
+            if (has_z) v *= act_bwd(act_d, zp[j][r]);
+            v0[j][r] = v;
+            v1[j][r] = act_fwd(act_o, v);
+        }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = VECN ? nb + 4 * c + j : nb + 16 * j + c;
+        if (dst && n < N) *reinterpret_cast<floatx4*>(dst + (st.dk0 + n) * CH_ROWS + 4 * q) = v1[j];
+    }
+    if (VECN && (st.ldo & 3) == 0) {              // a lane's 4 tiles are 4 adjacent columns: b128 stores
+        const int n = nb + 4 * c;
+        if (n < N) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * q + r;
+                if (row >= B) continue;
+                const long o = ((long)e * B + row) * st.ldo + n;
+                if (s0) *reinterpret_cast<__attribute__((address_space(1))) floatx4*>(out0 + o) = floatx4{v0[0][r], v0[1 % NT][r], v0[2 % NT][r], v0[3 % NT][r]};
+                if (s1) *reinterpret_cast<__attribute__((address_space(1))) floatx4*>(out1 + o) = floatx4{v1[0][r], v1[1 % NT][r], v1[2 % NT][r], v1[3 % NT][r]};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = VECN ? nb + 4 * c + j : nb + 16 * j + c;
+            if (n >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * q + r;
+                if (row >= B) continue;
+                const long o = ((long)e * B + row) * st.ldo + n;
+                if (s0) out0[o] = v0[j][r];
+                if (s1) out1[o] = v1[j][r];
+            }
+        }
+    }
+}
+
+// Work decomposition.  Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8), and every XCD has
+// its own L2, so the launch is 1-D and a member's work items (batch tile x chain) are all sent to the same
+// G = 8 / E XCDs (E <= 8; one XCD per member for the 5-member ensemble: 32 items on its 32 CUs): a member's
+// weights are then filled into exactly one L2 instead of eight.
+__device__ __forceinline__ bool xcd_affine_item(int E, int G, int ips, int per, int& e, int& item) {
+    const int lin = blockIdx.x, xcd = lin & 7, j = lin >> 3;
+    e = xcd / G + 8 * (j / ips);
+    item = (j % ips) * G + xcd % G;
+    return e < E && item < per;
 }
 
 __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
@@ -127,86 +298,83 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     ChainStage* const stg = reinterpret_cast<ChainStage*>(chain_smem);
     float* const bufs = chain_smem + (CH_MAXSTAGE * sizeof(ChainStage)) / sizeof(float);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int e = blockIdx.z, row0 = blockIdx.x * CH_ROWS, B = a.B;
-    const int nst = a.count[blockIdx.y];
+    int e, item;
+    const int per = a.ntiles * a.ny;
+    if (!xcd_affine_item(a.E, a.G, a.ips, per, e, item)) return;
+    const int y = item / a.ntiles, row0 = (item - y * a.ntiles) * CH_ROWS, B = a.B;
+    const int nst = a.count[y];
     {   // stage table of this chain -> LDS (one memory latency instead of one per stage)
-        const int* g = reinterpret_cast<const int*>(a.prog + a.first[blockIdx.y]);
+        const int* g = reinterpret_cast<const int*>(a.prog + a.first[y]);
         int* l = reinterpret_cast<int*>(stg);
         const int nw = nst * (int)(sizeof(ChainStage) / sizeof(int));
         for (int i = tid; i < nw; i += 256) l[i] = g[i];
     }
+    // Pull this member's weights into the XCD's L2 now (one 128-byte line per load, spread over the member's
+    // workgroups) so that the stages below start from L2, not from HBM.  The loads are fire-and-forget: inline
+    // asm keeps them out of the compiler's vmcnt bookkeeping (older loads only make its waits conservative), and
+    // `pf` stays live until the closing s_waitcnt so the destination register cannot be reused early.
+    float pf = 0.0f;
+    for (int i = 0; i < a.npf; ++i) {
+        gcptr base = as_global(a.pf_ptr[i]) + (long)e * a.pf_n[i];
+        const int nlines = (a.pf_n[i] + 31) >> 5;
+        for (int line = (item / a.G) * 256 + tid; line < nlines; line += a.ips * 256) {
+            gcptr q = base + line * 32;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(q) : "memory");
+        }
+    }
     __syncthreads();
-    const int c = lane & 15, q = lane >> 4;
+    const bool timed = a.tbuf && item == 0 && e == 0 && tid == 0;
+    if (timed) a.tbuf[0] = __builtin_readcyclecounter();
     for (int si = 0; si < nst; ++si) {
         const ChainStage& st = stg[si];
         if (st.kind == ST_LOAD) {
             float* dst = bufs + st.dst * a.bufsz;
             const int K = st.K;
-            for (int idx = tid; idx < CH_ROWS * K; idx += 256) {
-                const int m = idx / K, k = idx - m * K;
-                const int row = row0 + m;
-                float v = 0.0f;
-                if (row < B) {
-                    const long o = ((long)e * B + row) * st.ld_in + k;
-                    v = st.g0[o];
-                    if (st.g1) v += st.g1[o];
-                    if (st.gsum) st.gsum[((long)e * B + row) * st.ldo + k] = v;
+            if (((K | st.ld_in | st.ldo) & 3) == 0) {          // b128 path: every thread's loads are in flight together
+                const int K4 = K >> 2;
+                for (int idx = tid; idx < CH_ROWS * K4; idx += 256) {
+                    const int m = idx / K4, k = (idx - m * K4) * 4;
+                    const int row = row0 + m;
+                    floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
+                    if (row < B) {
+                        const long o = ((long)e * B + row) * st.ld_in + k;
+                        v = *reinterpret_cast<gcptr4>(as_global(st.g0) + o);
+                        if (st.g1) v += *reinterpret_cast<gcptr4>(as_global(st.g1) + o);
+                        if (st.gsum) *reinterpret_cast<__attribute__((address_space(1))) floatx4*>(as_global(st.gsum) + ((long)e * B + row) * st.ldo + k) = v;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dst[(st.dk0 + k + i) * CH_ROWS + m] = v[i];
                 }
-                dst[(st.dk0 + k) * CH_ROWS + m] = v;
+            } else {
+                for (int idx = tid; idx < CH_ROWS * K; idx += 256) {
+                    const int m = idx / K, k = idx - m * K;
+                    const int row = row0 + m;
+                    float v = 0.0f;
+                    if (row < B) {
+                        const long o = ((long)e * B + row) * st.ld_in + k;
+                        v = as_global(st.g0)[o];
+                        if (st.g1) v += as_global(st.g1)[o];
+                        if (st.gsum) as_global(st.gsum)[((long)e * B + row) * st.ldo + k] = v;
+                    }
+                    dst[(st.dk0 + k) * CH_ROWS + m] = v;
+                }
             }
         } else {
             const int N = st.N;
             for (int nb = wave * 64; nb < N; nb += 256) {
                 const int nt = (N - nb + 15) >> 4;
-                floatx4 acc[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-                // epilogue operands requested before the k loop so that their latency hides under it
-                float zp[4][4], bv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int n = nb + 16 * j + c;
-                    n = n < N ? n : N - 1;
-                    bv[j] = st.bias ? st.bias[(long)e * N + n] : 0.0f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        int row = row0 + 4 * q + r;
-                        row = row < B ? row : B - 1;
-                        zp[j][r] = st.zprev ? st.zprev[((long)e * B + row) * st.ldz + n] : 0.0f;
-                    }
-                }
-                for (int pi = 0; pi < st.nparts; ++pi) {
-                    const ChainPart& pt = st.part[pi];
-                    const float* src = bufs + pt.src * a.bufsz;
-                    if (nt >= 4) chain_kloop<4>(acc, pt, src, e, nb, N, lane);
-                    else if (nt == 3) chain_kloop<3>(acc, pt, src, e, nb, N, lane);
-                    else if (nt == 2) chain_kloop<2>(acc, pt, src, e, nb, N, lane);
-                    else chain_kloop<1>(acc, pt, src, e, nb, N, lane);
-                }
-                // D layout: col = lane & 15 -> n, row = (lane >> 4) * 4 + r -> batch row
-                float* dst = st.dst >= 0 ? bufs + st.dst * a.bufsz : nullptr;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = nb + 16 * j + c;
-                    if (n >= N) continue;
-                    floatx4 w;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = row0 + 4 * q + r;
-                        float v = acc[j][r] + bv[j];
-                        if (st.zprev) v *= act_bwd(st.act_d, zp[j][r]);
-                        const long o = ((long)e * B + row) * st.ldo + n;
-                        if (st.out0 && row < B) st.out0[o] = v;
-                        v = act_fwd(st.act_o, v);
-                        if (st.out1 && row < B) st.out1[o] = v;
-                        w[r] = v;
-                    }
-                    if (dst) *reinterpret_cast<floatx4*>(dst + (st.dk0 + n) * CH_ROWS + 4 * q) = w;
-                }
+                const ChainPart& p0 = st.part[0];
+                if (st.nparts == 1 && !p0.wt && (N & 3) == 0 && (p0.ldw & 3) == 0) chain_group<4, true>(st, bufs, a.bufsz, e, B, row0, nb, lane);
+                else if (nt >= 4) chain_group<4, false>(st, bufs, a.bufsz, e, B, row0, nb, lane);
+                else if (nt == 3) chain_group<3, false>(st, bufs, a.bufsz, e, B, row0, nb, lane);
+                else if (nt == 2) chain_group<2, false>(st, bufs, a.bufsz, e, B, row0, nb, lane);
+                else chain_group<1, false>(st, bufs, a.bufsz, e, B, row0, nb, lane);
             }
         }
         __syncthreads();
+        if (timed) a.tbuf[si + 1] = __builtin_readcyclecounter();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::"v"(pf) : "memory");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -759,7 +927,7 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
         t->prog_host = prog;
     }
     for (int i = 0; i < 5; ++i) { t->prog_first[i] = first[i]; t->prog_count[i] = count[i]; }
-    t->chain_bufsz = CH_ROWS * ((maxk + 3) & ~3);
+    t->chain_bufsz = CH_ROWS * ((maxk + 15) & ~15);
     return CADM_OK;
 }
 
@@ -768,9 +936,21 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
     ChainArgs a{};
     a.prog = t->prog_dev;
     a.first[0] = t->prog_first[p0]; a.count[0] = t->prog_count[p0];
-    int ny = 1;
-    if (p1 >= 0 && t->prog_count[p1] > 0) { a.first[1] = t->prog_first[p1]; a.count[1] = t->prog_count[p1]; ny = 2; }
+    a.ny = 1;
+    if (p1 >= 0 && t->prog_count[p1] > 0) { a.first[1] = t->prog_first[p1]; a.count[1] = t->prog_count[p1]; a.ny = 2; }
     a.B = B; a.bufsz = t->chain_bufsz;
+    a.tbuf = ctx->tbuf ? ctx->tbuf + 64 * (p0 / 2) : nullptr;   // [fwd | bwd | bwd context] x 64 stamps
+    a.E = ctx->E; a.ntiles = (B + CH_ROWS - 1) / CH_ROWS;
+    a.G = ctx->E <= 8 ? 8 / ctx->E : 1;
+    const int per = a.ntiles * a.ny;
+    a.ips = (per + a.G - 1) / a.G;
+    const int rounds = (ctx->E + 7) / 8;
+    auto pf_net = [&](const std::vector<DenseRef>& net) {
+        for (auto& d : net)
+            if (a.npf < CH_MAXPF) { a.pf_ptr[a.npf] = d.W; a.pf_n[a.npf] = d.din * d.dout; ++a.npf; }
+    };
+    if (p0 == PROG_BWD_CP || (p0 == PROG_FWD_FF && ctx->C > 0)) pf_net(ctx->cp);
+    if (p0 != PROG_BWD_CP) { pf_net(ctx->ff); if (a.ny == 2) pf_net(ctx->back); }
     const size_t lds = CH_MAXSTAGE * sizeof(ChainStage) + 3 * (size_t)t->chain_bufsz * sizeof(float);
     CADM_REQUIRE(lds <= 160 * 1024, "training chain: layer too wide for the LDS-resident activation tile");
     static size_t attr_lds = 0;
@@ -778,7 +958,7 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
         CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(chain_kernel, dim3((B + CH_ROWS - 1) / CH_ROWS, ny, ctx->E), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(chain_kernel, dim3(8 * a.ips * rounds), dim3(256), lds, s, a);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
 }
