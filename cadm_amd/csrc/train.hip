@@ -59,6 +59,9 @@ typedef __attribute__((address_space(1))) const float* gcptr;
 typedef __attribute__((address_space(1))) float* gptr;
 __device__ __forceinline__ gcptr as_global(const float* p) { return (gcptr)p; }
 __device__ __forceinline__ gptr as_global(float* p) { return (gptr)p; }
+#ifndef CH_ABL
+#define CH_ABL 0
+#endif
 #define CH_ROWS 16
 #define CH_AD 3            // A fragments are read from LDS this many k-steps ahead
 #define CH_MAXSTAGE 20
@@ -85,7 +88,9 @@ struct ChainArgs {
     int E, ny, ntiles, G, ips;                           // work decomposition, see chain_kernel
     int npf;                                             // weight tensors to pull into this XCD's L2 up front
     const float* pf_ptr[CH_MAXPF]; int pf_n[CH_MAXPF];   // base, floats per member
-    unsigned long long* tbuf;                            // cadm_debug_set_timing_buffer: per-stage clock of workgroup (0, y, 0)
+    unsigned long long* tbuf;                            // cadm_debug_set_timing_buffer: clocks of member 0's first work item:
+                                                         // [0..63] stage boundaries, [64 + 4 si ..] wave 0: group start, k loop end,
+                                                         // epilogue end, barrier reached
 };
 
 typedef __attribute__((address_space(1))) const char* gcbytes;
@@ -97,15 +102,18 @@ typedef __attribute__((address_space(1))) const floatx4* gcptr4;
 //   MODE 0  dword per (tile, k-step); tile j <-> column nb + 16 j + c; any N, K, either weight orientation
 //   MODE 1  forward (Bop(k,n) = W[k][n]), N % 4 == 0: one b128 per k-step holds the 4 tiles, tile j <-> column nb + 4 c + j
 //   MODE 2  transposed (Bop(k,n) = W[n][k]), K % 4 == 0: one b128 per (tile, 4 k-steps), k-step 4 t + i <-> k = 16 t + 4 kq + i
-// The k loop is straight-line code (two fully unrolled ring blocks with forward exits) inside a rarely-iterating
-// outer loop: with a back edge around the ring hipcc falls back to s_waitcnt vmcnt(0) at every block, which
-// serialises load latency and MFMA work.  At most 60 loads are in flight (vmcnt is a 6-bit counter).
-// Nothing is predicated: k-step indices are clamped to the last one, whose lanes beyond K use offsets clamped
-// into the matrix, and A is zeroed for k >= K.
+// The k loop is a compact rolled loop (this kernel runs each piece of code once per stage, so long unrolled
+// stretches turn into instruction-cache misses that cost more than the MFMAs: ~300 cycles per k-step were measured
+// with 32-step straight-line blocks).  B is double-buffered in registers by blocks of PF k-steps: the loads of
+// block i + 1 are issued as a group before block i is consumed.  (A finer-grained ring does not survive hipcc's
+// s_waitcnt placement across a loop back edge -- it waits for every outstanding load at the first use -- whereas
+// here "everything issued before this block's own loads" is exactly what the block needs.)
+// A block that reaches past K is padded, never predicated: k-step indices are clamped to the last one, whose lanes
+// beyond K use offsets clamped into the matrix, and A is zeroed for k >= K.
 template <int NT, int MODE>
 __device__ __forceinline__ void chain_kloop(floatx4 (&acc)[NT], const ChainPart& pt, const float* src, int e, int nb, int N,
                                             int lane) {
-    constexpr int PF = MODE ? 32 : (NT == 1 ? 32 : NT == 2 ? 28 : NT == 3 ? 20 : 12);
+    constexpr int PF = 8;                                  // k-steps per block
     constexpr int NR0 = MODE == 0 ? PF : 1, NR1 = MODE == 1 ? PF : 1, NR2 = MODE == 2 ? PF / 4 : 1;
     const int c = lane & 15, kq = lane >> 4;
     const int K = pt.K;
@@ -143,60 +151,71 @@ __device__ __forceinline__ void chain_kloop(floatx4 (&acc)[NT], const ChainPart&
             boffl[j] = 4u * (unsigned)((pt.row0 + n) * pt.ldw + k4l);
         }
     }
-    float ring0[NR0][NT];
-    floatx4 ring1[NR1];
-    floatx4 ring2[NR2][NT];
+    struct Blk {
+        float r0[NR0][NT];
+        floatx4 r1[NR1];
+        floatx4 r2[NR2][NT];
+    };
+    Blk ba, bb;
     float ar[4];
-    // issue the loads of k-step sidx (MODE 2: of the 4 k-steps starting at sidx) into ring slot u
-    auto issue = [&](int u, int sidx) {
-        if (MODE == 2) sidx >>= 2;
-        const int lim = MODE == 2 ? last >> 2 : last;
-        const int sc = sidx < lim ? sidx : lim;
-        gcbytes base = Wm + sc * step_bytes;
-        const bool tail = sidx >= lim;
-        if (MODE == 0) {
+    // loads of the PF k-steps starting at s0 into a block
+    auto issue_block = [&](Blk& blk, int s0) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) ring0[u][j] = *reinterpret_cast<gcptr>(base + (tail ? boffl[j] : boff[j]));
-        } else if (MODE == 1) {
-            ring1[u] = *reinterpret_cast<gcptr4>(base + (tail ? boffl[0] : boff[0]));
-        } else {
+        for (int u = 0; u < PF; u += (MODE == 2 ? 4 : 1)) {
+            const int sidx = MODE == 2 ? (s0 + u) >> 2 : s0 + u;
+            const int lim = MODE == 2 ? last >> 2 : last;
+            const int sc = sidx < lim ? sidx : lim;
+            gcbytes base = Wm + sc * step_bytes;
+            const bool tail = sidx >= lim;
+            if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) ring2[u >> 2][j] = *reinterpret_cast<gcptr4>(base + (tail ? boffl[j] : boff[j]));
+                for (int j = 0; j < NT; ++j) blk.r0[u][j] = *reinterpret_cast<gcptr>(base + (tail ? boffl[j] : boff[j]));
+            } else if (MODE == 1) {
+                blk.r1[u] = *reinterpret_cast<gcptr4>(base + (tail ? boffl[0] : boff[0]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) blk.r2[u >> 2][j] = *reinterpret_cast<gcptr4>(base + (tail ? boffl[j] : boff[j]));
+            }
         }
     };
-    // raw LDS read of the A fragment of k-step sidx (clamped); lanes with k >= K are zeroed at use (a_valid)
+    // raw LDS read of the A fragment of k-step sidx (clamped); lanes with k >= K are zeroed at use
     auto read_a = [&](int sidx) {
         const int sc = sidx < last ? sidx : last;
         if (MODE == 2) return src[(16 * (sc >> 2) + 4 * kq + (sc & 3)) * CH_ROWS + c];
         return src[sc * 64 + lane];
     };
     const int vsteps = MODE == 2 ? ((K - 4 * kq + 15) >> 4) * 4 : (K - kq + 3) >> 2;   // this lane's k < K  <=>  sidx < vsteps
+    auto compute_block = [&](const Blk& blk, int s0) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
-        if (MODE != 2 || (u & 3) == 0) issue(u, u);
+        for (int u = 0; u < PF; ++u) {
+            float b[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b[j] = MODE == 0 ? blk.r0[u][j] : MODE == 1 ? blk.r1[u][j] : blk.r2[u >> 2][j][u & 3];
+            const float av = s0 + u < vsteps ? ar[u & 3] : 0.0f;
+#if !(CH_ABL & 2)
+            ar[(u + CH_AD) & 3] = read_a(s0 + u + CH_AD);
+#endif
+            __builtin_amdgcn_sched_barrier(0);     // keep the LDS read CH_AD steps ahead of its use
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j], acc[j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    issue_block(ba, 0);
 #pragma unroll
     for (int u = 0; u < CH_AD; ++u) ar[u] = read_a(u);
-    for (int s00 = 0; s00 < nsteps; s00 += 2 * PF) {
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            const int s0 = s00 + blk * PF;
-            if (blk > 0 && s0 >= nsteps) break;
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                if ((u & 7) == 0 && u > 0 && s0 + u >= nsteps) break;     // uniform early exit, 8-step granularity
-                float b[NT];
-#pragma unroll
-                for (int j = 0; j < NT; ++j) b[j] = MODE == 0 ? ring0[u][j] : MODE == 1 ? ring1[u][j] : ring2[u >> 2][j][u & 3];
-                const float av = s0 + u < vsteps ? ar[u & 3] : 0.0f;
-                if (MODE != 2) issue(u, s0 + u + PF);
-                else if ((u & 3) == 3) issue(u - 3, s0 + u - 3 + PF);
-                ar[(u + CH_AD) & 3] = read_a(s0 + u + CH_AD);
-                __builtin_amdgcn_sched_barrier(0);     // keep the LDS read CH_AD steps ahead of its use
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j], acc[j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+#pragma unroll 1
+    for (int s0 = 0; s0 < nsteps; s0 += 2 * PF) {
+#if !(CH_ABL & 1)
+        issue_block(bb, s0 + PF);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        compute_block(ba, s0);
+#if !(CH_ABL & 1)
+        issue_block(ba, s0 + 2 * PF);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if (s0 + PF < nsteps) compute_block(bb, s0 + PF);
     }
 }
 
@@ -204,7 +223,8 @@ __device__ __forceinline__ void chain_kloop(floatx4 (&acc)[NT], const ChainPart&
 // then the epilogue.
 template <int NT, bool VECN>
 __device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, int bufsz, int e, int B, int row0, int nb,
-                                            int lane) {
+                                            int lane, unsigned long long* dbg) {
+    if (dbg) dbg[0] = __builtin_readcyclecounter();
     const int c = lane & 15, q = lane >> 4, N = st.N;
     floatx4 acc[NT];
 #pragma unroll
@@ -233,6 +253,7 @@ __device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, i
         else if (pt.wt && (pt.K & 3) == 0 && (pt.ldw & 3) == 0) chain_kloop<NT, 2>(acc, pt, src, e, nb, N, lane);
         else chain_kloop<NT, 0>(acc, pt, src, e, nb, N, lane);
     }
+    if (dbg) dbg[1] = __builtin_readcyclecounter();
     // D layout: col = lane & 15 -> column slot c, row = (lane >> 4) * 4 + r -> batch row
     float* dst = st.dst >= 0 ? bufs + st.dst * bufsz : nullptr;
     const int act_d = st.act_d, act_o = st.act_o;
@@ -280,6 +301,7 @@ __device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, i
             }
         }
     }
+    if (dbg) dbg[2] = __builtin_readcyclecounter();
 }
 
 // Work decomposition.  Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8), and every XCD has
@@ -364,13 +386,15 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
             for (int nb = wave * 64; nb < N; nb += 256) {
                 const int nt = (N - nb + 15) >> 4;
                 const ChainPart& p0 = st.part[0];
-                if (st.nparts == 1 && !p0.wt && (N & 3) == 0 && (p0.ldw & 3) == 0) chain_group<4, true>(st, bufs, a.bufsz, e, B, row0, nb, lane);
-                else if (nt >= 4) chain_group<4, false>(st, bufs, a.bufsz, e, B, row0, nb, lane);
-                else if (nt == 3) chain_group<3, false>(st, bufs, a.bufsz, e, B, row0, nb, lane);
-                else if (nt == 2) chain_group<2, false>(st, bufs, a.bufsz, e, B, row0, nb, lane);
-                else chain_group<1, false>(st, bufs, a.bufsz, e, B, row0, nb, lane);
+                unsigned long long* dbg = timed ? a.tbuf + 64 + si * 4 : nullptr;
+                if (st.nparts == 1 && !p0.wt && (N & 3) == 0 && (p0.ldw & 3) == 0) chain_group<4, true>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
+                else if (nt >= 4) chain_group<4, false>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
+                else if (nt == 3) chain_group<3, false>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
+                else if (nt == 2) chain_group<2, false>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
+                else chain_group<1, false>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
             }
         }
+        if (timed) a.tbuf[64 + si * 4 + 3] = __builtin_readcyclecounter();
         __syncthreads();
         if (timed) a.tbuf[si + 1] = __builtin_readcyclecounter();
     }
@@ -408,12 +432,12 @@ struct DwArgs {
 __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     __shared__ __attribute__((aligned(16))) float As[DW_NSLAB * TK * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[DW_NSLAB * TK * LDB];
+    const int tile = blockIdx.x, e = blockIdx.y;
     int ji = 0;
 #pragma unroll 1
-    while (ji + 1 < a.njobs && (int)blockIdx.x >= a.job[ji + 1].tile0) ++ji;
+    while (ji + 1 < a.njobs && tile >= a.job[ji + 1].tile0) ++ji;
     const DwJob& jb = a.job[ji];
-    const int t = blockIdx.x - jb.tile0;
-    const int e = blockIdx.y;
+    const int t = tile - jb.tile0;
     const int mb = (t / jb.tn) * TM, nb = (t % jb.tn) * TN;
     const int M = jb.M, N = jb.N, K = a.B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -450,7 +474,7 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     const int kmax = K - 1;
     const bool do_colsum = jb.bW && mb == 0 && tid < TN;
 
-    for (int kp = 0; kp < K; kp += DW_NSLAB * TK) {
+    for (int kp = 0; kp < (jb.X ? K : 0); kp += DW_NSLAB * TK) {     // X == null: L2-only job, gradient = wdc * W
         if (kp > 0) __syncthreads();               // previous panel fully consumed before its LDS is overwritten
 #pragma unroll
         for (int s = 0; s < DW_NSLAB; ++s) {
@@ -513,17 +537,6 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
         adam_update(w, mo, vo, colsum, a.lr_t, a.b1, a.b2, a.eps);
         jb.bW[o] = w; jb.bM[o] = mo; jb.bV[o] = vo;
     }
-}
-
-// elementwise Adam for tensors whose gradient is a closed form: g = gscale * gsrc (+ wdc * w)
-__global__ void adam_elem_kernel(float* w, float* m, float* v, const float* gsrc, float gscale, float gconst, float wdc,
-                                 long n, float lr_t, float b1, float b2, float eps) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float ww = w[i], mm = m[i], vv = v[i];
-    const float g = (gsrc ? gscale * gsrc[i] : 0.0f) + gconst + wdc * ww;
-    adam_update(ww, mm, vv, g, lr_t, b1, b2, eps);
-    w[i] = ww; m[i] = mm; v[i] = vv;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -625,36 +638,70 @@ __global__ void loss_kernel(const LossP p) {
     }
 }
 
-// deterministic reductions: block q < 4 sums terms[q] over everything; block 4 + d / 4 + D + d sum the
-// max/min logvar gradient terms over rows for dim d.  out: [4 + 2D]
-__global__ void reduce_kernel(const float* terms, long n, int D, float* out) {
-    __shared__ float sh[256];
-    const int q = blockIdx.x;
-    float acc = 0.0f;
+// Deterministic reductions, one workgroup per output: block q < 4 sums terms[q] over everything; blocks 4 + d and
+// 4 + D + d sum the max / min logvar gradient terms over rows for dim d.  out: [4 + 2D].  The workgroup that
+// finishes last turns the sums into losses_out = [mse, back_mse, recon] (dynamics.py:505-507: recon = loss - reg -
+// coeff * l2) and, when training a probabilistic model, applies Adam to max/min_logvar (data term + the 0.01
+// regulariser of dynamics.py:308) -- nothing else reads them until the next step's loss kernel.
+struct ReduceP {
+    const float* terms; long n; int D; float* out; unsigned* counter;
+    int det, has_back; float back_coeff; float* losses_out;
+    int adam_mm;                                   // 1: update max/min_logvar
+    float *maxlv, *minlv, *mx_m, *mx_v, *mn_m, *mn_v;
+    float lr_t, b1, b2, eps;
+};
+
+__global__ __launch_bounds__(1024) void reduce_finalize_kernel(const ReduceP p) {
+    __shared__ float sh[1024];
+    __shared__ bool is_last;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;      // independent chains: 4 loads in flight per thread
     if (q < 4) {
-        for (long i = threadIdx.x; i < n; i += 256) acc += terms[q * n + i];
+        const float* src = p.terms + q * p.n;
+        long i = tid;
+        for (; i + 3072 < p.n; i += 4096) { a0 += src[i]; a1 += src[i + 1024]; a2 += src[i + 2048]; a3 += src[i + 3072]; }
+        for (; i < p.n; i += 1024) a0 += src[i];
     } else {
-        const int which = (q - 4) / D, d = (q - 4) % D;
-        const float* src = terms + (4 + which) * n;
-        for (long r = threadIdx.x; r * D + d < n; r += 256) acc += src[r * D + d];
+        const int which = (q - 4) / p.D, d = (q - 4) % p.D;
+        const float* src = p.terms + (4 + which) * p.n + d;
+        const long rows = p.n / p.D;
+        long r = tid;
+        for (; r + 3072 < rows; r += 4096) { a0 += src[r * p.D]; a1 += src[(r + 1024) * p.D]; a2 += src[(r + 2048) * p.D]; a3 += src[(r + 3072) * p.D]; }
+        for (; r < rows; r += 1024) a0 += src[r * p.D];
     }
-    sh[threadIdx.x] = acc;
+    sh[tid] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[q] = sh[0];
-}
-
-// losses_out = [mse, back_mse, recon]  (dynamics.py:505-507: recon = loss - reg - coeff*l2)
-__global__ void finalize_loss_kernel(const float* red, int det, float back_coeff, int has_back, float* losses_out) {
-    const float mse = red[0], mu_loss = red[1], var_loss = red[2], back = red[3];
-    float recon = det ? mse : mu_loss + var_loss;
-    if (has_back) recon += back_coeff * back;
-    losses_out[0] = mse;
-    losses_out[1] = has_back ? back : 0.0f;
-    losses_out[2] = recon;
+    if (tid == 0) {
+        p.out[q] = sh[0];
+        __threadfence();
+        is_last = atomicInc(p.counter, gridDim.x - 1) == gridDim.x - 1;     // wraps back to 0 for the next step
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const volatile float* red = p.out;
+    if (tid == 0) {
+        const float mse = red[0], mu_loss = red[1], var_loss = red[2], back = red[3];
+        float recon = p.det ? mse : mu_loss + var_loss;
+        if (p.has_back) recon += p.back_coeff * back;
+        p.losses_out[0] = mse;
+        p.losses_out[1] = p.has_back ? back : 0.0f;
+        p.losses_out[2] = recon;
+    }
+    if (p.adam_mm && tid < 2 * p.D) {
+        const bool mx = tid < p.D;
+        const int d = mx ? tid : tid - p.D;
+        float* w = (mx ? p.maxlv : p.minlv) + d;
+        float* m = (mx ? p.mx_m : p.mn_m) + d;
+        float* v = (mx ? p.mx_v : p.mn_v) + d;
+        float ww = *w, mm = *m, vv = *v;
+        adam_update(ww, mm, vv, red[4 + tid] + (mx ? 0.01f : -0.01f), p.lr_t, p.b1, p.b2, p.eps);
+        *w = ww; *m = mm; *v = vv;
+    }
 }
 
 }  // namespace
@@ -769,6 +816,7 @@ static int ensure_workspace(cadm_ctx* ctx, int B) {
     t->ff.mu = w + omu; t->ff.lv = w + olv; t->bk.mu = w + obmu; t->bk.lv = w + oblv;
     t->dMu = w + odMu; t->dLv = w + odLv; t->dBmu = w + odBmu;
     t->terms = w + oterms; t->red = w + ored;
+    CADM_CHECK_HIP(hipMemset(t->red, 0, (4 + 2 * (size_t)D + 8) * sizeof(float)));   // incl. the reduction's arrival counter
     t->B = B;
     return CADM_OK;
 }
@@ -939,7 +987,7 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
     a.ny = 1;
     if (p1 >= 0 && t->prog_count[p1] > 0) { a.first[1] = t->prog_first[p1]; a.count[1] = t->prog_count[p1]; a.ny = 2; }
     a.B = B; a.bufsz = t->chain_bufsz;
-    a.tbuf = ctx->tbuf ? ctx->tbuf + 64 * (p0 / 2) : nullptr;   // [fwd | bwd | bwd context] x 64 stamps
+    a.tbuf = ctx->tbuf ? ctx->tbuf + 256 * (p0 / 2) : nullptr;   // [fwd | bwd | bwd context] x 256 stamps (tools/chain_timing.py)
     a.E = ctx->E; a.ntiles = (B + CH_ROWS - 1) / CH_ROWS;
     a.G = ctx->E <= 8 ? 8 / ctx->E : 1;
     const int per = a.ntiles * a.ny;
@@ -959,14 +1007,6 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
         attr_lds = lds;
     }
     hipLaunchKernelGGL(chain_kernel, dim3(8 * a.ips * rounds), dim3(256), lds, s, a);
-    CADM_CHECK_HIP(hipGetLastError());
-    return CADM_OK;
-}
-
-int adam_elem(float* w, AdamSlot& a, const float* gsrc, float gscale, float gconst, float wdc, const cadm_train_hparams& hp,
-              float lr_t, hipStream_t s) {
-    hipLaunchKernelGGL(adam_elem_kernel, dim3((unsigned)((a.n + 255) / 256)), dim3(256), 0, s, w, a.m, a.v, gsrc, gscale,
-                       gconst, wdc, (long)a.n, lr_t, hp.beta1, hp.beta2, hp.epsilon);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
 }
@@ -1033,15 +1073,22 @@ extern "C" int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act
     lp.dMu = t->dMu; lp.dLv = t->dLv; lp.dBmu = t->dBmu; lp.terms = t->terms;
     lp.n = R * D; lp.D = D; lp.B = B; lp.det = det; lp.has_back = has_back; lp.back_coeff = hp.back_coeff;
     hipLaunchKernelGGL(loss_kernel, dim3((unsigned)((lp.n + 255) / 256)), dim3(256), 0, s, lp);
-    hipLaunchKernelGGL(reduce_kernel, dim3(4 + 2 * D), dim3(256), 0, s, t->terms, lp.n, D, t->red);
-    hipLaunchKernelGGL(finalize_loss_kernel, dim3(1), dim3(1), 0, s, t->red, (int)det, hp.back_coeff, (int)has_back, losses_out);
+    // lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t)  (TF1 Adam)
+    if (train) t->step += 1;
+    const float lr_t = (float)(hp.learning_rate * sqrt(1.0 - pow((double)hp.beta2, (double)t->step)) /
+                               (1.0 - pow((double)hp.beta1, (double)t->step)));
+    ReduceP rp{};
+    rp.terms = t->terms; rp.n = lp.n; rp.D = D; rp.out = t->red; rp.counter = reinterpret_cast<unsigned*>(t->red + 4 + 2 * D);
+    rp.det = det; rp.has_back = has_back; rp.back_coeff = hp.back_coeff; rp.losses_out = losses_out;
+    rp.adam_mm = train && !det;
+    rp.maxlv = ctx->ff_maxlv; rp.minlv = ctx->ff_minlv;
+    rp.mx_m = t->a_mx.m; rp.mx_v = t->a_mx.v; rp.mn_m = t->a_mn.m; rp.mn_v = t->a_mn.v;
+    rp.lr_t = lr_t; rp.b1 = hp.beta1; rp.b2 = hp.beta2; rp.eps = hp.epsilon;
+    hipLaunchKernelGGL(reduce_finalize_kernel, dim3(4 + 2 * D), dim3(1024), 0, s, rp);
     CADM_CHECK_HIP(hipGetLastError());
     if (!train) return CADM_OK;
 
-    // ---- backward + TF1 Adam (lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t)) ----
-    t->step += 1;
-    const float lr_t = (float)(hp.learning_rate * sqrt(1.0 - pow((double)hp.beta2, (double)t->step)) /
-                               (1.0 - pow((double)hp.beta1, (double)t->step)));
+    // ---- backward + Adam ----
     const float coeff = hp.weight_decay_coeff;
     auto wd_dyn = [&](int l) { return coeff * (l < NH ? hp.weight_decays[l] : hp.weight_decays[NH]); };
 
@@ -1078,16 +1125,20 @@ extern "C" int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act
             if ((rc = add_job(l == 0 ? t->Xcp : t->cp.h[l - 1], l == 0 ? cpin : ctx->cp[l - 1].dout, l == ncp ? t->dCtx : t->cp.dz[l],
                               ctx->cp[l], wd_cp(l), t->a_cp[2 * l], t->a_cp[2 * l + 1]))) return rc;
     }
+    // output_logvar outside the data path (deterministic forward net / backward net): its weight only sees the L2 term
+    // (a job without data: X = null), its bias has no gradient at all and is skipped like TF does
+    auto l2_only_job = [&](const DenseRef& L, float wdc, AdamSlot& aw) -> int {
+        CADM_REQUIRE(da.njobs < DW_MAXJOBS, "cadm_train_step: too many layers for the grouped weight-gradient launch");
+        DwJob& j = da.job[da.njobs++];
+        j.X = nullptr; j.dZ = nullptr; j.W = L.W; j.Mw = aw.m; j.Vw = aw.v; j.bW = nullptr; j.bM = nullptr; j.bV = nullptr;
+        j.ldx = 0; j.M = L.din; j.N = L.dout; j.tile0 = tiles; j.wdc = wdc; j.tn = (L.dout + TN - 1) / TN;
+        tiles += j.tn * ((L.din + TM - 1) / TM);
+        return CADM_OK;
+    };
+    if (det && (rc = l2_only_job(ctx->ff[NH + 1], wd_dyn(NH + 1), t->a_ff[2 * (NH + 1)]))) return rc;
+    if (has_back && (rc = l2_only_job(ctx->back[NH + 1], wd_dyn(NH + 1), t->a_bk[2 * (NH + 1)]))) return rc;
     hipLaunchKernelGGL(dw_adam_kernel, dim3(tiles, E), dim3(256), 0, s, da);
     CADM_CHECK_HIP(hipGetLastError());
-    // output_logvar outside the data path (deterministic forward net / backward net): its weight only sees the L2 term,
-    // its bias has no gradient at all and is skipped like TF does
-    if (det && (rc = adam_elem(ctx->ff[NH + 1].W, t->a_ff[2 * (NH + 1)], nullptr, 0.f, 0.f, wd_dyn(NH + 1), hp, lr_t, s))) return rc;
-    if (has_back && (rc = adam_elem(ctx->back[NH + 1].W, t->a_bk[2 * (NH + 1)], nullptr, 0.f, 0.f, wd_dyn(NH + 1), hp, lr_t, s))) return rc;
-    if (!det) {   // max/min_logvar of the forward net: data term + 0.01 regulariser (dynamics.py:308)
-        if ((rc = adam_elem(ctx->ff_maxlv, t->a_mx, t->red + 4, 1.0f, 0.01f, 0.0f, hp, lr_t, s))) return rc;
-        if ((rc = adam_elem(ctx->ff_minlv, t->a_mn, t->red + 4 + D, 1.0f, -0.01f, 0.0f, hp, lr_t, s))) return rc;
-    }
     ctx->packed = false;   // planner streams are stale until cadm_repack
     return CADM_OK;
 }

@@ -26,14 +26,16 @@ def main():
     for _ in range(3):
         eng.train_step(batch, train=True)
     torch.cuda.synchronize()
-    t = tbuf.cpu().numpy()[:192].reshape(3, 64)
+    raw = tbuf.cpu().numpy()[:768].reshape(3, 256)
     for li, lname in enumerate(["forward", "backward", "backward (context)"]):
-        row = t[li]
+        row = raw[li, :64]
         n = int((row > 0).sum())
         if n < 2:
             continue
         d = np.diff(row[:n]).astype(np.float64)
         print("%-20s total %8.0f ticks | " % (lname, row[n - 1] - row[0]) + " ".join("%5.0f" % x for x in d))
+        fine = raw[li, 64:64 + 4 * (n - 1)].reshape(n - 1, 4)
+        print("   wave 0 per GEMM stage: k loop / epilogue   " + "  ".join("%d/%d" % (r[1] - r[0], r[2] - r[1]) for r in fine if r[0]))
 
 
 if __name__ == "__main__":
