@@ -59,9 +59,6 @@ typedef __attribute__((address_space(1))) const float* gcptr;
 typedef __attribute__((address_space(1))) float* gptr;
 __device__ __forceinline__ gcptr as_global(const float* p) { return (gcptr)p; }
 __device__ __forceinline__ gptr as_global(float* p) { return (gptr)p; }
-#ifndef CH_ABL
-#define CH_ABL 0
-#endif
 #define CH_ROWS 16
 #define CH_AD 3            // A fragments are read from LDS this many k-steps ahead
 #define CH_MAXSTAGE 20
@@ -104,41 +101,68 @@ typedef __attribute__((address_space(1))) const floatx4* gcptr4;
 //   MODE 2  transposed (Bop(k,n) = W[n][k]), K % 4 == 0: one b128 per (tile, 4 k-steps), k-step 4 t + i <-> k = 16 t + 4 kq + i
 // The k loop is a compact rolled loop (this kernel runs each piece of code once per stage, so long unrolled
 // stretches turn into instruction-cache misses that cost more than the MFMAs: ~300 cycles per k-step were measured
-// with 32-step straight-line blocks).  B is double-buffered in registers by blocks of PF k-steps: the loads of
-// block i + 1 are issued as a group before block i is consumed.  (A finer-grained ring does not survive hipcc's
-// s_waitcnt placement across a loop back edge -- it waits for every outstanding load at the first use -- whereas
-// here "everything issued before this block's own loads" is exactly what the block needs.)
+// with 32-step straight-line blocks).  B lives in four register blocks of PF k-steps that rotate: while block b is
+// consumed, blocks b+1, b+2 and b+3 are in flight, which covers the ~2000-cycle L2 latency seen when a member's 32
+// workgroups stream the same weights.
+// hipcc cannot express that pipeline: its s_waitcnt placement gives up across the loop back edge and waits for
+// every outstanding load at the first use, i.e. a lookahead of at most one block.  The weight loads are therefore
+// issued from inline asm (invisible to the compiler's counters) and ordered with explicit `s_waitcnt vmcnt(n)`:
+// loads return in issue order, so "at most n younger loads outstanding" is exact; older compiler-issued accesses
+// (epilogue operands, stores of the previous stage) only make a wait conservative.  Every wait is followed by a
+// sched_barrier so that no consumer can move above it, and nothing is left in flight when the function returns.
 // A block that reaches past K is padded, never predicated: k-step indices are clamped to the last one, whose lanes
 // beyond K use offsets clamped into the matrix, and A is zeroed for k >= K.
+// (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): no vector address arithmetic per load
+__device__ __forceinline__ void async_load(float& dst, gcbytes base, unsigned off) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void async_load(floatx4& dst, gcbytes base, unsigned off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// Values read out of the LDS stage table are wave-uniform, but the compiler cannot know: make them scalar.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ gcbytes uni(gcbytes p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (gcbytes)(((unsigned long long)hi << 32) | lo);
+}
+
 template <int NT, int MODE>
 __device__ __forceinline__ void chain_kloop(floatx4 (&acc)[NT], const ChainPart& pt, const float* src, int e, int nb, int N,
                                             int lane) {
     constexpr int PF = 8;                                  // k-steps per block
     constexpr int NR0 = MODE == 0 ? PF : 1, NR1 = MODE == 1 ? PF : 1, NR2 = MODE == 2 ? PF / 4 : 1;
+    constexpr int LPB = MODE == 0 ? PF * NT : MODE == 1 ? PF : (PF / 4) * NT;      // loads per block
     const int c = lane & 15, kq = lane >> 4;
-    const int K = pt.K;
+    const int K = uni(pt.K), ldw = uni(pt.ldw), wt = uni(pt.wt), prow0 = uni(pt.row0);
     const int nsteps = MODE == 2 ? ((K + 15) >> 4) * 4 : (K + 3) >> 2, last = nsteps - 1;
-    gcbytes Wm = (gcbytes)(as_global(pt.W) + (long)e * pt.sWe);
+    const int nblk = (nsteps + PF - 1) / PF;
+    gcbytes Wm = uni((gcbytes)(as_global(pt.W) + (long)e * pt.sWe));
     long step_bytes;                                        // per k-step (MODE 0/1) or per 4 k-steps (MODE 2)
     unsigned boff[NT], boffl[NT];                           // per-lane byte offsets: regular / last (clamped) step
     if (MODE == 0) {
-        const int ks = pt.wt ? 1 : pt.ldw, ns = pt.wt ? pt.ldw : 1;
+        const int ks = wt ? 1 : ldw, ns = wt ? ldw : 1;
         const int kql = 4 * last + kq < K ? kq : K - 1 - 4 * last;
         step_bytes = 16L * ks;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             int n = nb + 16 * j + c;
             n = n < N ? n : N - 1;
-            boff[j] = 4u * (unsigned)((pt.row0 + n) * ns + kq * ks);
-            boffl[j] = 4u * (unsigned)((pt.row0 + n) * ns + kql * ks);
+            boff[j] = 4u * (unsigned)((prow0 + n) * ns + kq * ks);
+            boffl[j] = 4u * (unsigned)((prow0 + n) * ns + kql * ks);
         }
     } else if (MODE == 1) {
         int n4 = nb + 4 * c;
         n4 = n4 < N ? n4 : N - 4;
         const int kql = 4 * last + kq < K ? kq : K - 1 - 4 * last;
-        step_bytes = 16L * pt.ldw;
-        boff[0] = 4u * (unsigned)(n4 + kq * pt.ldw);
-        boffl[0] = 4u * (unsigned)(n4 + kql * pt.ldw);
+        step_bytes = 16L * ldw;
+        boff[0] = 4u * (unsigned)(n4 + kq * ldw);
+        boffl[0] = 4u * (unsigned)(n4 + kql * ldw);
     } else {
         const int lastq = last >> 2;
         const int k4l = 16 * lastq + 4 * kq <= K - 4 ? 4 * kq : K - 4 - 16 * lastq;
@@ -147,8 +171,8 @@ __device__ __forceinline__ void chain_kloop(floatx4 (&acc)[NT], const ChainPart&
         for (int j = 0; j < NT; ++j) {
             int n = nb + 16 * j + c;
             n = n < N ? n : N - 1;
-            boff[j] = 4u * (unsigned)((pt.row0 + n) * pt.ldw + 4 * kq);
-            boffl[j] = 4u * (unsigned)((pt.row0 + n) * pt.ldw + k4l);
+            boff[j] = 4u * (unsigned)((prow0 + n) * ldw + 4 * kq);
+            boffl[j] = 4u * (unsigned)((prow0 + n) * ldw + k4l);
         }
     }
     struct Blk {
@@ -156,66 +180,91 @@ __device__ __forceinline__ void chain_kloop(floatx4 (&acc)[NT], const ChainPart&
         floatx4 r1[NR1];
         floatx4 r2[NR2][NT];
     };
-    Blk ba, bb;
+    Blk b0, b1, b2, b3;
     float ar[4];
-    // loads of the PF k-steps starting at s0 into a block
-    auto issue_block = [&](Blk& blk, int s0) {
+    // loads of block bi (its PF k-steps) into a register block.  Blocks that end before the last k-step take the
+    // fast path: a scalar base walks the k-steps, the per-lane offsets never change.
+    auto issue_block = [&](Blk& blk, int bi) {
+        const int s0 = bi * PF;
+        constexpr int SPL = MODE == 2 ? 4 : 1;              // k-steps per load group
+        const int lim = MODE == 2 ? last >> 2 : last;
+        const int i0 = s0 / SPL;                            // first load-group index of the block
+        if (i0 + PF / SPL - 1 < lim) {
+            gcbytes base = Wm + i0 * step_bytes;
 #pragma unroll
-        for (int u = 0; u < PF; u += (MODE == 2 ? 4 : 1)) {
-            const int sidx = MODE == 2 ? (s0 + u) >> 2 : s0 + u;
-            const int lim = MODE == 2 ? last >> 2 : last;
-            const int sc = sidx < lim ? sidx : lim;
-            gcbytes base = Wm + sc * step_bytes;
-            const bool tail = sidx >= lim;
-            if (MODE == 0) {
+            for (int u = 0; u < PF; u += SPL) {
+                if (MODE == 0) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) blk.r0[u][j] = *reinterpret_cast<gcptr>(base + (tail ? boffl[j] : boff[j]));
-            } else if (MODE == 1) {
-                blk.r1[u] = *reinterpret_cast<gcptr4>(base + (tail ? boffl[0] : boff[0]));
-            } else {
+                    for (int j = 0; j < NT; ++j) async_load(blk.r0[u][j], base, boff[j]);
+                } else if (MODE == 1) {
+                    async_load(blk.r1[u], base, boff[0]);
+                } else {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) blk.r2[u >> 2][j] = *reinterpret_cast<gcptr4>(base + (tail ? boffl[j] : boff[j]));
+                    for (int j = 0; j < NT; ++j) async_load(blk.r2[u >> 2][j], base, boff[j]);
+                }
+                base += step_bytes;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < PF; u += SPL) {
+                const int sidx = i0 + u / SPL;
+                const int sc = sidx < lim ? sidx : lim;
+                gcbytes base = Wm + sc * step_bytes;
+                const bool tail = sidx >= lim;
+                if (MODE == 0) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) async_load(blk.r0[u][j], base, tail ? boffl[j] : boff[j]);
+                } else if (MODE == 1) {
+                    async_load(blk.r1[u], base, tail ? boffl[0] : boff[0]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) async_load(blk.r2[u >> 2][j], base, tail ? boffl[j] : boff[j]);
+                }
             }
         }
     };
-    // raw LDS read of the A fragment of k-step sidx (clamped); lanes with k >= K are zeroed at use
-    auto read_a = [&](int sidx) {
-        const int sc = sidx < last ? sidx : last;
-        if (MODE == 2) return src[(16 * (sc >> 2) + 4 * kq + (sc & 3)) * CH_ROWS + c];
-        return src[sc * 64 + lane];
-    };
-    const int vsteps = MODE == 2 ? ((K - 4 * kq + 15) >> 4) * 4 : (K - kq + 3) >> 2;   // this lane's k < K  <=>  sidx < vsteps
-    auto compute_block = [&](const Blk& blk, int s0) {
+    // A fragment of k-step sidx: MODE 0/1 lds[(4 sidx + kq) * 16 + c] = lds[64 sidx + lane]; MODE 2 (sidx = 4 t + i)
+    // lds[(16 t + 4 kq + i) * 16 + c].  Neither clamped nor masked: the stage has zeroed rows K .. round32(K) of its
+    // source buffers (chain_kernel), and anything a lookahead read fetches beyond that is never used.  (A per-step
+    // compare + select feeding the MFMA costs ~30 cycles per k-step that do not overlap with the matrix pipe.)
+    const float* abase = MODE == 2 ? src + 64 * kq + c : src + lane;
+    auto read_a = [&](int sidx) { return MODE == 2 ? abase[256 * (sidx >> 2) + 16 * (sidx & 3)] : abase[64 * sidx]; };
+    auto compute_block = [&](const Blk& blk, int bi) {
+        const int s0 = bi * PF;
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             float b[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) b[j] = MODE == 0 ? blk.r0[u][j] : MODE == 1 ? blk.r1[u][j] : blk.r2[u >> 2][j][u & 3];
-            const float av = s0 + u < vsteps ? ar[u & 3] : 0.0f;
-#if !(CH_ABL & 2)
+            const float av = ar[u & 3];
             ar[(u + CH_AD) & 3] = read_a(s0 + u + CH_AD);
-#endif
             __builtin_amdgcn_sched_barrier(0);     // keep the LDS read CH_AD steps ahead of its use
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j], acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    issue_block(ba, 0);
+    // consume block bi from `cur`; `nxt` is the register block that was consumed last (free) and receives block bi + 3
+    auto step = [&](Blk& cur, Blk& nxt, int bi) {
+        const int rem = nblk - 1 - bi;             // blocks after this one
+        if (rem >= 3) { issue_block(nxt, bi + 3); wait_vmcnt<3 * LPB>(); }
+        else if (rem == 2) wait_vmcnt<2 * LPB>();
+        else if (rem == 1) wait_vmcnt<LPB>();
+        else wait_vmcnt<0>();
+        compute_block(cur, bi);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    issue_block(b0, 0);
+    if (nblk > 1) issue_block(b1, 1);
+    if (nblk > 2) issue_block(b2, 2);
 #pragma unroll
     for (int u = 0; u < CH_AD; ++u) ar[u] = read_a(u);
 #pragma unroll 1
-    for (int s0 = 0; s0 < nsteps; s0 += 2 * PF) {
-#if !(CH_ABL & 1)
-        issue_block(bb, s0 + PF);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        compute_block(ba, s0);
-#if !(CH_ABL & 1)
-        issue_block(ba, s0 + 2 * PF);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        if (s0 + PF < nsteps) compute_block(bb, s0 + PF);
+    for (int bi = 0; bi < nblk; bi += 4) {
+        step(b0, b3, bi);
+        if (bi + 1 < nblk) step(b1, b0, bi + 1);
+        if (bi + 2 < nblk) step(b2, b1, bi + 2);
+        if (bi + 3 < nblk) step(b3, b2, bi + 3);
     }
 }
 
@@ -382,6 +431,16 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                 }
             }
         } else {
+            // rows K .. round32(K) of every source buffer <- 0: the k loops run whole 32-deep blocks without masking A
+            bool padded = false;
+            for (int pi = 0; pi < st.nparts; ++pi) {
+                const int K = st.part[pi].K, Kp = (K + 31) & ~31;
+                if (Kp == K) continue;
+                float* sb = bufs + st.part[pi].src * a.bufsz + K * CH_ROWS;
+                for (int i = tid; i < (Kp - K) * CH_ROWS / 4; i += 256) reinterpret_cast<floatx4*>(sb)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+                padded = true;
+            }
+            if (padded) __syncthreads();
             const int N = st.N;
             for (int nb = wave * 64; nb < N; nb += 256) {
                 const int nt = (N - nb + 15) >> 4;
@@ -975,7 +1034,7 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
         t->prog_host = prog;
     }
     for (int i = 0; i < 5; ++i) { t->prog_first[i] = first[i]; t->prog_count[i] = count[i]; }
-    t->chain_bufsz = CH_ROWS * ((maxk + 15) & ~15);
+    t->chain_bufsz = CH_ROWS * ((maxk + 31) & ~31);
     return CADM_OK;
 }
 
