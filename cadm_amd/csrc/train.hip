@@ -60,6 +60,8 @@ typedef __attribute__((address_space(1))) float* gptr;
 __device__ __forceinline__ gcptr as_global(const float* p) { return (gcptr)p; }
 __device__ __forceinline__ gptr as_global(float* p) { return (gptr)p; }
 #define CH_ROWS 16
+#define CH_THREADS 512        // 8 waves: two per SIMD, so one wave's LDS / load / scalar work overlaps the other's MFMAs
+#define CH_GW 32              // output columns per wave and pass (NT <= 2 MFMA tiles)
 #define CH_AD 3            // A fragments are read from LDS this many k-steps ahead
 #define CH_MAXSTAGE 20
 
@@ -92,12 +94,13 @@ struct ChainArgs {
 
 typedef __attribute__((address_space(1))) const char* gcbytes;
 typedef __attribute__((address_space(1))) const floatx4* gcptr4;
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 // acc[j] += src(16 x K) * Bop(K x 16) for NT column tiles of this wave.  A comes from the LDS activation buffer
 // (k-major, lds[k * 16 + m]), B straight from global memory through a register ring PF k-steps deep, addressed as
 // (uniform base of the k-step) + (per-lane byte offset).  Three load shapes:
 //   MODE 0  dword per (tile, k-step); tile j <-> column nb + 16 j + c; any N, K, either weight orientation
-//   MODE 1  forward (Bop(k,n) = W[k][n]), N % 4 == 0: one b128 per k-step holds the 4 tiles, tile j <-> column nb + 4 c + j
+//   MODE 1  forward (Bop(k,n) = W[k][n]), N % 2 == 0: one b64 per k-step holds the 2 tiles, tile j <-> column nb + 2 c + j
 //   MODE 2  transposed (Bop(k,n) = W[n][k]), K % 4 == 0: one b128 per (tile, 4 k-steps), k-step 4 t + i <-> k = 16 t + 4 kq + i
 // The k loop is a compact rolled loop (this kernel runs each piece of code once per stage, so long unrolled
 // stretches turn into instruction-cache misses that cost more than the MFMAs: ~300 cycles per k-step were measured
@@ -115,6 +118,9 @@ typedef __attribute__((address_space(1))) const floatx4* gcptr4;
 // (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): no vector address arithmetic per load
 __device__ __forceinline__ void async_load(float& dst, gcbytes base, unsigned off) {
     asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void async_load(floatx2& dst, gcbytes base, unsigned off) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
 }
 __device__ __forceinline__ void async_load(floatx4& dst, gcbytes base, unsigned off) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
@@ -157,12 +163,12 @@ __device__ __forceinline__ void chain_kloop(floatx4 (&acc)[NT], const ChainPart&
             boffl[j] = 4u * (unsigned)((prow0 + n) * ns + kql * ks);
         }
     } else if (MODE == 1) {
-        int n4 = nb + 4 * c;
-        n4 = n4 < N ? n4 : N - 4;
+        int n2 = nb + 2 * c;
+        n2 = n2 < N ? n2 : N - 2;
         const int kql = 4 * last + kq < K ? kq : K - 1 - 4 * last;
         step_bytes = 16L * ldw;
-        boff[0] = 4u * (unsigned)(n4 + kq * ldw);
-        boffl[0] = 4u * (unsigned)(n4 + kql * ldw);
+        boff[0] = 4u * (unsigned)(n2 + kq * ldw);
+        boffl[0] = 4u * (unsigned)(n2 + kql * ldw);
     } else {
         const int lastq = last >> 2;
         const int k4l = 16 * lastq + 4 * kq <= K - 4 ? 4 * kq : K - 4 - 16 * lastq;
@@ -177,7 +183,7 @@ __device__ __forceinline__ void chain_kloop(floatx4 (&acc)[NT], const ChainPart&
     }
     struct Blk {
         float r0[NR0][NT];
-        floatx4 r1[NR1];
+        floatx2 r1[NR1];
         floatx4 r2[NR2][NT];
     };
     Blk b0, b1, b2, b3;
@@ -268,7 +274,7 @@ __device__ __forceinline__ void chain_kloop(floatx4 (&acc)[NT], const ChainPart&
     }
 }
 
-// One GEMM stage for NT column tiles of this wave (VECN: tile j <-> column nb + 4 c + j, else nb + 16 j + c): all parts,
+// One GEMM stage for NT column tiles of this wave (VECN: tile j <-> column nb + 2 c + j, else nb + 16 j + c): all parts,
 // then the epilogue.
 template <int NT, bool VECN>
 __device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, int bufsz, int e, int B, int row0, int nb,
@@ -283,7 +289,7 @@ __device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, i
     const bool has_z = st.zprev != nullptr, has_b = st.bias != nullptr;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        int n = VECN ? nb + 4 * c + j : nb + 16 * j + c;
+        int n = VECN ? nb + 2 * c + j : nb + 16 * j + c;
         n = n < N ? n : N - 1;
         gcptr bp = as_global(has_b ? st.bias : st.part[0].W) + (has_b ? (long)e * N + n : 0);
         bv[j] = *bp;
@@ -320,25 +326,25 @@ __device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, i
         }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int n = VECN ? nb + 4 * c + j : nb + 16 * j + c;
+        const int n = VECN ? nb + 2 * c + j : nb + 16 * j + c;
         if (dst && n < N) *reinterpret_cast<floatx4*>(dst + (st.dk0 + n) * CH_ROWS + 4 * q) = v1[j];
     }
-    if (VECN && (st.ldo & 3) == 0) {              // a lane's 4 tiles are 4 adjacent columns: b128 stores
-        const int n = nb + 4 * c;
+    if (VECN && (st.ldo & 1) == 0) {              // a lane's 2 tiles are 2 adjacent columns: b64 stores
+        const int n = nb + 2 * c;
         if (n < N) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + 4 * q + r;
                 if (row >= B) continue;
                 const long o = ((long)e * B + row) * st.ldo + n;
-                if (s0) *reinterpret_cast<__attribute__((address_space(1))) floatx4*>(out0 + o) = floatx4{v0[0][r], v0[1 % NT][r], v0[2 % NT][r], v0[3 % NT][r]};
-                if (s1) *reinterpret_cast<__attribute__((address_space(1))) floatx4*>(out1 + o) = floatx4{v1[0][r], v1[1 % NT][r], v1[2 % NT][r], v1[3 % NT][r]};
+                if (s0) *reinterpret_cast<__attribute__((address_space(1))) floatx2*>(out0 + o) = floatx2{v0[0][r], v0[1 % NT][r]};
+                if (s1) *reinterpret_cast<__attribute__((address_space(1))) floatx2*>(out1 + o) = floatx2{v1[0][r], v1[1 % NT][r]};
             }
         }
     } else {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int n = VECN ? nb + 4 * c + j : nb + 16 * j + c;
+            const int n = VECN ? nb + 2 * c + j : nb + 16 * j + c;
             if (n >= N) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -364,7 +370,7 @@ __device__ __forceinline__ bool xcd_affine_item(int E, int G, int ips, int per, 
     return e < E && item < per;
 }
 
-__global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
+__global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float chain_smem[];
     ChainStage* const stg = reinterpret_cast<ChainStage*>(chain_smem);
     float* const bufs = chain_smem + (CH_MAXSTAGE * sizeof(ChainStage)) / sizeof(float);
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
         const int* g = reinterpret_cast<const int*>(a.prog + a.first[y]);
         int* l = reinterpret_cast<int*>(stg);
         const int nw = nst * (int)(sizeof(ChainStage) / sizeof(int));
-        for (int i = tid; i < nw; i += 256) l[i] = g[i];
+        for (int i = tid; i < nw; i += CH_THREADS) l[i] = g[i];
     }
     // Pull this member's weights into the XCD's L2 now (one 128-byte line per load, spread over the member's
     // workgroups) so that the stages below start from L2, not from HBM.  The loads are fire-and-forget: inline
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     for (int i = 0; i < a.npf; ++i) {
         gcptr base = as_global(a.pf_ptr[i]) + (long)e * a.pf_n[i];
         const int nlines = (a.pf_n[i] + 31) >> 5;
-        for (int line = (item / a.G) * 256 + tid; line < nlines; line += a.ips * 256) {
+        for (int line = (item / a.G) * CH_THREADS + tid; line < nlines; line += a.ips * CH_THREADS) {
             gcptr q = base + line * 32;
             asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(q) : "memory");
         }
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
             const int K = st.K;
             if (((K | st.ld_in | st.ldo) & 3) == 0) {          // b128 path: every thread's loads are in flight together
                 const int K4 = K >> 2;
-                for (int idx = tid; idx < CH_ROWS * K4; idx += 256) {
+                for (int idx = tid; idx < CH_ROWS * K4; idx += CH_THREADS) {
                     const int m = idx / K4, k = (idx - m * K4) * 4;
                     const int row = row0 + m;
                     floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                     for (int i = 0; i < 4; ++i) dst[(st.dk0 + k + i) * CH_ROWS + m] = v[i];
                 }
             } else {
-                for (int idx = tid; idx < CH_ROWS * K; idx += 256) {
+                for (int idx = tid; idx < CH_ROWS * K; idx += CH_THREADS) {
                     const int m = idx / K, k = idx - m * K;
                     const int row = row0 + m;
                     float v = 0.0f;
@@ -437,19 +443,17 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                 const int K = st.part[pi].K, Kp = (K + 31) & ~31;
                 if (Kp == K) continue;
                 float* sb = bufs + st.part[pi].src * a.bufsz + K * CH_ROWS;
-                for (int i = tid; i < (Kp - K) * CH_ROWS / 4; i += 256) reinterpret_cast<floatx4*>(sb)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+                for (int i = tid; i < (Kp - K) * CH_ROWS / 4; i += CH_THREADS) reinterpret_cast<floatx4*>(sb)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
                 padded = true;
             }
             if (padded) __syncthreads();
             const int N = st.N;
-            for (int nb = wave * 64; nb < N; nb += 256) {
+            for (int nb = wave * CH_GW; nb < N; nb += CH_GW * (CH_THREADS / 64)) {
                 const int nt = (N - nb + 15) >> 4;
                 const ChainPart& p0 = st.part[0];
                 unsigned long long* dbg = timed ? a.tbuf + 64 + si * 4 : nullptr;
-                if (st.nparts == 1 && !p0.wt && (N & 3) == 0 && (p0.ldw & 3) == 0) chain_group<4, true>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
-                else if (nt >= 4) chain_group<4, false>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
-                else if (nt == 3) chain_group<3, false>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
-                else if (nt == 2) chain_group<2, false>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
+                if (st.nparts == 1 && !p0.wt && (N & 1) == 0 && (p0.ldw & 1) == 0) chain_group<2, true>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
+                else if (nt >= 2) chain_group<2, false>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
                 else chain_group<1, false>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
             }
         }
@@ -1065,7 +1069,7 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
         CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(chain_kernel, dim3(8 * a.ips * rounds), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(chain_kernel, dim3(8 * a.ips * rounds), dim3(CH_THREADS), lds, s, a);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
 }
