@@ -92,6 +92,30 @@ def cpu_baseline(prob, n, p, budget_s=15.0):
                                                                           single, torch.__version__))
 
 
+def train_step_bench(device, steps=100, warmup=10, B=256):
+    """Second leg of the path: one fused forward/backward/Adam step of the 5-member CaDM ensemble
+    (+ backward model) on a device-resident [E, B, .] bootstrap batch.  Reported beside the headline, never as it."""
+    from cadm_amd import synth
+    from helpers import make_engine
+    prob = synth.make_problem(env="halfcheetah", context=True, E=5, with_back=True, seed=0)
+    eng = make_engine(prob, p=20, device=device)
+    eng.train_configure(1e-3, (0.000025, 0.00005, 0.000075, 0.000075, 0.0001), (0.000025, 0.00005, 0.000075), 1.0, 0.5,
+                        max_batch=B)
+    batch = {k: eng._t(v) for k, v in synth.make_train_batch(prob, B=B, seed=1).items()}
+    for _ in range(warmup):
+        eng.train_step(batch, train=True)
+    torch.cuda.synchronize(eng.device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = eng.train_step(batch, train=True)
+    torch.cuda.synchronize(eng.device)
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(losses).all()
+    flops = 3 * 2 * 5 * B * (2 * 134000 + 103040)      # fwd + dX + dW of the ff, backward and context nets
+    return {"ms_per_step": dt * 1e3, "batch": B, "members": 5, "rows_per_s": 5 * B / dt, "tflops": flops / dt / 1e12,
+            "workload": "halfcheetah CaDM ensemble + backward model, fwd/bwd/TF1-Adam, fp32"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,6 +228,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, n, p)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if world == 1:
+            out["train_step"] = train_step_bench("cuda:%d" % local_rank)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

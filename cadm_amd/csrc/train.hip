@@ -486,7 +486,7 @@ struct DwArgs {
 #define TK 32
 #define LDA (TM + 4)
 #define LDB (TN + 4)
-#define DW_NSLAB 4                   // slabs per K panel: the whole panel (128 deep) is in flight at once
+#define DW_NSLAB 2                   // slabs per K panel: a 64-deep panel is in flight at once; small enough for 4 workgroups per CU
 
 // One 32 x 64 tile of one job per workgroup, reduction over the batch.  The global loads of a whole K panel are
 // issued up front (registers) and the panel is then walked slab by slab -- stash slab s into its own LDS
