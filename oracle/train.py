@@ -237,3 +237,23 @@ def normalization_stats(norm, D, A, Hh, discrete, state_diff):
         s["cp_act_mean"], s["cp_act_std"] = norm["cp_act"]
     s["back_delta_mean"], s["back_delta_std"] = norm["back_delta"]
     return s
+
+
+def early_stop_trace(v_recon, persistency):
+    """Restatement of the rolling-average early stop of `fit` (reference
+    cadm/dynamics/mlp_cadm_ensemble_cem_dynamics.py:544-564): given the per-epoch validation recon losses,
+    returns (index of the last epoch that ran, the rolling averages after each of those epochs)."""
+    rolling, prev, trace = None, None, []
+    last = -1
+    for epoch, v in enumerate(v_recon):
+        last = epoch
+        if rolling is None:                      # :544-549
+            rolling, prev = 1.5 * v, 2 * v
+            if v < 0:
+                rolling, prev = v / 1.5, v / 2
+        rolling = persistency * rolling + (1.0 - persistency) * v      # :551-552
+        trace.append(rolling)
+        if prev < rolling:                       # :554-556
+            break
+        prev = rolling                           # :564
+    return last, trace
