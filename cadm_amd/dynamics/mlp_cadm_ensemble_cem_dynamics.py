@@ -159,6 +159,8 @@ class MLPEnsembleCEMDynamicsModel(object):
                 self._dist_failed = True
                 logger.log("cadm_amd: in-library RCCL init failed (%s); using torch.distributed all_gather" % exc)
         fused = shard.world == 1 or self.engine.dist_world == shard.world
+        if not any(isinstance(x, torch.Tensor) for x in (obs, cp_obs, cp_act, cem_init_mean, cem_init_var)):
+            obs, cp_obs, cp_act, cem_init_mean, cem_init_var = self.engine.stage((obs, cp_obs, cp_act, cem_init_mean, cem_init_var))
         if cem_init_mean is not None:
             if fused:
                 action = self.engine.cem_plan(obs, cp_obs, cp_act, cem_init_mean, cem_init_var, self.n_candidates,
