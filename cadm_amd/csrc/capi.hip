@@ -6,7 +6,8 @@
 
 int cadm_launch_clip(const float* in, float* out, int total, float lo, float hi, int do_clip, hipStream_t s);
 int cadm_launch_refit(cadm_ctx* ctx, const float* cand_returns, const float* rows, int G, int n_local, const float* actions,
-                      int m, float* mean_io, float* var_io, int32_t* elites_out, hipStream_t stream);
+                      int m, const float* mean_in, const float* var_in, float* mean_out, float* var_out, int32_t* elites_out,
+                      float* plan_out, hipStream_t stream);
 
 static thread_local char g_err[1024] = "";
 
@@ -274,27 +275,28 @@ extern "C" int cadm_cem_plan(cadm_ctx* ctx, const float* obs, const float* cp_ob
     carve(ctx, m, n, (char*)workspace, &w);
     int rc;
     if (ctx->C > 0 && (rc = cadm_context_forward(ctx, cp_obs, cp_act, m, 0, w.ctxv, stream))) return rc;
-    const size_t mv = (size_t)m * ctx->H * ctx->A * sizeof(float);
-    CADM_CHECK_HIP(hipMemcpyAsync(w.mean, init_mean, mv, hipMemcpyDeviceToDevice, s));
-    CADM_CHECK_HIP(hipMemcpyAsync(w.var, init_var, mv, hipMemcpyDeviceToDevice, s));
     const int G = ctx->comm ? ctx->nranks : 1;
     CADM_REQUIRE(n % G == 0, "cadm_cem_plan: n_candidates %d not divisible by %d ranks", n, G);
     const int nl = n / G, off = (ctx->comm ? ctx->rank : 0) * nl;
-    for (int it = 0; it < ctx->cfg.num_cem_iters; ++it) {
+    const int iters = ctx->cfg.num_cem_iters;
+    for (int it = 0; it < iters; ++it) {
+        // iteration 0 reads the caller's mean / var directly; the last refit also writes the clipped plan (dynamics.py:365-366)
+        const float* mean_in = it == 0 ? init_mean : w.mean;
+        const float* var_in = it == 0 ? init_var : w.var;
+        float* plan = it + 1 == iters ? plan_out : nullptr;
         // every rank draws ALL n candidates (counter-based RNG keyed by global candidate id): elites need no exchange
-        if ((rc = cadm_sample_actions(ctx, w.mean, w.var, nullptr, seed, call, it, m, n, w.actions, stream))) return rc;
+        if ((rc = cadm_sample_actions(ctx, mean_in, var_in, nullptr, seed, call, it, m, n, w.actions, stream))) return rc;
         if ((rc = cadm_rollout_returns(ctx, obs, nullptr, ctx->C > 0 ? w.ctxv : nullptr, w.actions, nullptr, 1, seed,
                                        call, it, off, n, m, nl, w.rows, nullptr, stream))) return rc;
         if (G > 1) {   // the one collective of the path: [m, n/G] per rank -> [G, m, n/G] everywhere
             if ((rc = cadm_particle_mean(ctx, w.rows, m, nl, w.cand, stream))) return rc;
             if ((rc = cadm_dist_allgather(ctx, w.cand, w.gath, (size_t)m * nl, s))) return rc;
-            if ((rc = cadm_launch_refit(ctx, w.gath, nullptr, G, nl, w.actions, m, w.mean, w.var, nullptr, s))) return rc;
+            if ((rc = cadm_launch_refit(ctx, w.gath, nullptr, G, nl, w.actions, m, mean_in, var_in, w.mean, w.var, nullptr, plan, s))) return rc;
         } else {       // single rank: the particle mean is taken inside the refit kernel
-            if ((rc = cadm_launch_refit(ctx, nullptr, w.rows, 1, nl, w.actions, m, w.mean, w.var, nullptr, s))) return rc;
+            if ((rc = cadm_launch_refit(ctx, nullptr, w.rows, 1, nl, w.actions, m, mean_in, var_in, w.mean, w.var, nullptr, plan, s))) return rc;
         }
     }
-    return cadm_launch_clip(w.mean, plan_out, m * ctx->H * ctx->A, ctx->cfg.lower_bound, ctx->cfg.upper_bound,
-                            !ctx->cfg.discrete, s);
+    return CADM_OK;
 }
 
 __global__ void gather_raw_first_kernel(const int32_t* raw, const int32_t* best, int m, int n, int H, int32_t* out) {

@@ -115,8 +115,9 @@ __device__ void bitonic_sort_lds(uint64_t* keys, int npow2) {
 
 __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __restrict__ rows, int p, int G, int n_local,
                                  const float* __restrict__ actions,
-                                 int m, int H, int A, int K, float alpha, int npow2, float* __restrict__ mean_io,
-                                 float* __restrict__ var_io, int32_t* __restrict__ elites_out) {
+                                 int m, int H, int A, int K, float alpha, int npow2, const float* mean_in,
+                                 const float* var_in, float* mean_out, float* var_out, int32_t* __restrict__ elites_out,
+                                 float* __restrict__ plan_out, float lo, float hi, int do_clip, int part_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);
     const int mi = blockIdx.x;
@@ -142,21 +143,68 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
     }
     if (elites_out)
         for (int k = threadIdx.x; k < K; k += blockDim.x) elites_out[(size_t)mi * K + k] = (int32_t)(keys[k] & 0xFFFFFFFFu);
+    // elite statistics: KG thread groups each take every KG-th elite of one (t, a) element, partial sums meet in LDS
+    // (fixed order -> deterministic); the elites' actions stay in registers between the mean and the variance pass
     const int HA = H * A;
     const float* act_m = actions + (size_t)mi * n * HA;
-    for (int ta = threadIdx.x; ta < HA; ta += blockDim.x) {
+    float* part = reinterpret_cast<float*>(smem_raw + part_off);                  // [KG][HA]
+    constexpr int MAXE = 16;                                                       // elites per thread (K <= KG * MAXE)
+    const int KG = min((int)blockDim.x / HA, K) > 0 ? min((int)blockDim.x / HA, K) : 1;
+    const int tq = threadIdx.x;
+    const bool par = KG * MAXE >= K && HA * KG <= (int)blockDim.x;
+    if (par) {
+        const int ta = tq % HA, kg = tq / HA;
+        const bool on = kg < KG;
+        float v[MAXE];
         float s = 0.0f;
-        for (int k = 0; k < K; ++k) s += act_m[(size_t)(keys[k] & 0xFFFFFFFFu) * HA + ta];
-        const float nm = s / (float)K;                                             // :482
-        float v = 0.0f;
-        for (int k = 0; k < K; ++k) {
-            const float d = act_m[(size_t)(keys[k] & 0xFFFFFFFFu) * HA + ta] - nm;
-            v += d * d;
+#pragma unroll
+        for (int i = 0; i < MAXE; ++i) {
+            const int k = kg + i * KG;
+            v[i] = (on && k < K) ? act_m[(size_t)(keys[k < K ? k : 0] & 0xFFFFFFFFu) * HA + ta] : 0.0f;
         }
-        const float nv = v / (float)K;                                             // :483
-        const size_t o = (size_t)mi * HA + ta;
-        mean_io[o] = mean_io[o] * alpha + (1.0f - alpha) * nm;                     // :485
-        var_io[o] = var_io[o] * alpha + (1.0f - alpha) * nv;                       // :486
+#pragma unroll
+        for (int i = 0; i < MAXE; ++i) s += v[i];
+        if (on) part[kg * HA + ta] = s;
+        __syncthreads();
+        float nm = 0.0f;
+        for (int g = 0; g < KG; ++g) nm += part[g * HA + ta];
+        nm = nm / (float)K;                                                        // :482
+        __syncthreads();
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXE; ++i) {
+            const float d = v[i] - nm;
+            q += (on && kg + i * KG < K) ? d * d : 0.0f;
+        }
+        if (on) part[kg * HA + ta] = q;
+        __syncthreads();
+        if (tq < HA) {
+            float nv = 0.0f;
+            for (int g = 0; g < KG; ++g) nv += part[g * HA + ta];
+            nv = nv / (float)K;                                                    // :483
+            const size_t o = (size_t)mi * HA + ta;
+            const float mo = mean_in[o] * alpha + (1.0f - alpha) * nm;             // :485
+            mean_out[o] = mo;
+            var_out[o] = var_in[o] * alpha + (1.0f - alpha) * nv;                  // :486
+            if (plan_out) plan_out[o] = do_clip ? fminf(fmaxf(mo, lo), hi) : mo;   // dynamics.py:365-366 (last iteration)
+        }
+    } else {
+        for (int ta = threadIdx.x; ta < HA; ta += blockDim.x) {
+            float s = 0.0f;
+            for (int k = 0; k < K; ++k) s += act_m[(size_t)(keys[k] & 0xFFFFFFFFu) * HA + ta];
+            const float nm = s / (float)K;
+            float v = 0.0f;
+            for (int k = 0; k < K; ++k) {
+                const float d = act_m[(size_t)(keys[k] & 0xFFFFFFFFu) * HA + ta] - nm;
+                v += d * d;
+            }
+            const float nv = v / (float)K;
+            const size_t o = (size_t)mi * HA + ta;
+            const float mo = mean_in[o] * alpha + (1.0f - alpha) * nm;
+            mean_out[o] = mo;
+            var_out[o] = var_in[o] * alpha + (1.0f - alpha) * nv;
+            if (plan_out) plan_out[o] = do_clip ? fminf(fmaxf(mo, lo), hi) : mo;
+        }
     }
 }
 
@@ -241,22 +289,28 @@ extern "C" int cadm_particle_mean(cadm_ctx* ctx, const float* returns_rows, int 
 }
 
 int cadm_launch_refit(cadm_ctx* ctx, const float* cand_returns, const float* rows, int G, int n_local, const float* actions,
-                      int m, float* mean_io, float* var_io, int32_t* elites_out, hipStream_t stream) {
+                      int m, const float* mean_in, const float* var_in, float* mean_out, float* var_out, int32_t* elites_out,
+                      float* plan_out, hipStream_t stream) {
     const int n = G * n_local;
     CADM_REQUIRE(n >= ctx->cfg.num_elites, "cadm_cem_refit: n_candidates %d < num_elites %d (tf.nn.top_k would fail)",
                  n, ctx->cfg.num_elites);
     int npow2 = 1;
     while (npow2 < n) npow2 <<= 1;
-    const size_t lds = (size_t)npow2 * sizeof(uint64_t) * (n <= 2048 ? 2 : 1);
-    CADM_REQUIRE(lds <= 128 * 1024, "cadm_cem_refit: n_candidates %d exceeds the in-LDS sort capacity (16384)", n);
+    const size_t lds_keys = (size_t)npow2 * sizeof(uint64_t) * (n <= 2048 ? 2 : 1);
+    const int HA = ctx->H * ctx->A;
+    const int KG = 1024 / HA > 0 ? 1024 / HA : 1;
+    const size_t lds = lds_keys + (size_t)KG * HA * sizeof(float);
+    CADM_REQUIRE(lds <= 160 * 1024 - 4096 && lds_keys <= 128 * 1024,
+                 "cadm_cem_refit: n_candidates %d exceeds the in-LDS sort capacity (16384)", n);
     static bool attr_set = false;
     if (!attr_set) {
         CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cem_refit_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr_set = true;
     }
     hipLaunchKernelGGL(cem_refit_kernel, dim3(m), dim3(1024), lds, stream, cand_returns, rows, ctx->p, G, n_local, actions,
-                       m, ctx->H, ctx->A, ctx->cfg.num_elites, ctx->cfg.alpha, npow2, mean_io, var_io, elites_out);
+                       m, ctx->H, ctx->A, ctx->cfg.num_elites, ctx->cfg.alpha, npow2, mean_in, var_in, mean_out, var_out,
+                       elites_out, plan_out, ctx->cfg.lower_bound, ctx->cfg.upper_bound, ctx->cfg.discrete ? 0 : 1, (int)lds_keys);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
 }
@@ -265,7 +319,8 @@ extern "C" int cadm_cem_refit(cadm_ctx* ctx, const float* cand_returns, int G, i
                               int m, float* mean_io, float* var_io, int32_t* elites_out, void* stream) {
     CADM_REQUIRE(ctx && cand_returns && actions && mean_io && var_io && G > 0 && n_local > 0 && m > 0,
                  "cadm_cem_refit: bad arguments");
-    return cadm_launch_refit(ctx, cand_returns, nullptr, G, n_local, actions, m, mean_io, var_io, elites_out, (hipStream_t)stream);
+    return cadm_launch_refit(ctx, cand_returns, nullptr, G, n_local, actions, m, mean_io, var_io, mean_io, var_io, elites_out,
+                             nullptr, (hipStream_t)stream);
 }
 
 extern "C" int cadm_rs_select(cadm_ctx* ctx, const float* cand_returns, int G, int n_local, const float* actions,
