@@ -251,28 +251,56 @@ class MLPEnsembleCEMDynamicsModel(object):
         N = ds["obs"].shape[0]
         n_valid = min(int(N * valid_split_ratio), max_logging)
         perm = rng.permutation(N)
-        keys = ("obs", "act", "delta", "cp_obs", "cp_act", "future_bool", "obs_next", "back_delta")
-        tr = {k: ds[k][perm[n_valid:]] for k in keys}
-        va = {k: ds[k][perm[:n_valid]] for k in keys}
-        train = self._preprocess_inputs(**tr)
-        valid = self._preprocess_inputs(**va) if n_valid > 0 else None
-        return self._fit_loop(train, valid, epochs, rolling_average_persitency, verbose, log_tabular, rng)
+        # The reference explodes every window into F rows on the host (`_preprocess_inputs`, :676-696: reshape, tile the
+        # history F times, mask by future_bool) and feeds numpy batches.  Here the windowed dataset goes to HBM once and
+        # a row is the pair (window, future offset): batches gather straight from the windows, the history is never tiled.
+        dev = self._upload_dataset(ds)
+        train_rows = self._row_index(ds["future_bool"], perm[n_valid:])
+        valid_rows = self._row_index(ds["future_bool"], perm[:n_valid]) if n_valid > 0 else None
+        return self._fit_loop(dev, train_rows, valid_rows, epochs, rolling_average_persitency, verbose, log_tabular, rng)
 
-    def _fit_loop(self, train, valid, epochs, persistency, verbose, log_tabular, rng):
+    _BATCH_KEYS = ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
+
+    def _upload_dataset(self, ds):
+        eng = self.engine
+        return {k: eng._t(ds[k]) for k in self._BATCH_KEYS}
+
+    @staticmethod
+    def _row_index(future_bool, windows):
+        """Rows of `_preprocess_inputs(ds[windows])` as (window id, future offset), in the same order
+        (window-major, masked by future_bool)."""
+        wl, f = np.nonzero(future_bool[windows] > 0)
+        return np.asarray(windows)[wl].astype(np.int64), f.astype(np.int64)
+
+    def _gather_rows(self, dev, w, f):
+        """[..] index tensors -> the batch dict of `cadm_train_step` ([.., dim] each)."""
+        D, A, F = self.obs_space_dims, self.action_space_dims, self.future_length
+        N = dev["obs"].shape[0]
+        out = {}
+        for k in ("obs", "delta", "obs_next", "back_delta"):
+            out[k] = dev[k].view(N, F, D)[w, f]
+        out["act"] = dev["act"].view(N, F, A)[w, f]
+        out["cp_obs"] = dev["cp_obs"][w]
+        out["cp_act"] = dev["cp_act"][w]
+        return out
+
+    def _fit_loop(self, dev, train_rows, valid_rows, epochs, persistency, verbose, log_tabular, rng):
         """Epoch / batch loop (reference :460-569): bootstrap indices, shuffle_rows, one fused
         fwd/bwd/Adam step per batch, validation, rolling-average early stop."""
         self._ensure_train()
         eng, E = self.engine, self.ensemble_size
-        names = ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
-        dev_train = {k: eng._t(v) for k, v in zip(names, train)}    # dataset resident in HBM
-        n_train = train[0].shape[0]
+        row_w = torch.as_tensor(train_rows[0], device=eng.device)
+        row_f = torch.as_tensor(train_rows[1], device=eng.device)
+        n_train = int(row_w.shape[0])
         if E > 1:
             bootstrap_idx = rng.integers(0, n_train, size=(E, n_train))       # :465
         else:
             bootstrap_idx = np.tile(np.arange(n_train, dtype="int64"), (E, 1))  # :467
         dev_valid = None
-        if valid is not None and valid[0].shape[0] > 0:
-            dev_valid = {k: eng._t(v)[None].expand(E, -1, -1).contiguous() for k, v in zip(names, valid)}  # :470,515-521
+        if valid_rows is not None and valid_rows[0].shape[0] > 0:
+            vw = torch.as_tensor(valid_rows[0], device=eng.device)
+            vf = torch.as_tensor(valid_rows[1], device=eng.device)
+            dev_valid = {k: v[None].expand(E, -1, -1).contiguous() for k, v in self._gather_rows(dev, vw, vf).items()}  # :470,515-521
         rolling, rolling_prev = None, None
         epoch = -1
         for epoch in range(epochs):
@@ -283,8 +311,8 @@ class MLPEnsembleCEMDynamicsModel(object):
             didx = torch.as_tensor(bootstrap_idx, device=eng.device)
             losses = []
             for b in range(int(np.ceil(n_train / self.batch_size))):
-                bi = didx[:, b * self.batch_size:(b + 1) * self.batch_size]    # [E,B]
-                batch = {k: v[bi] for k, v in dev_train.items()}               # device gather -> [E,B,.]
+                bi = didx[:, b * self.batch_size:(b + 1) * self.batch_size]    # [E,B] row ids
+                batch = self._gather_rows(dev, row_w[bi], row_f[bi])           # device gather -> [E,B,.]
                 losses.append(eng.train_step(batch, train=True))
             tl = torch.stack(losses).mean(0).cpu().numpy() if losses else np.zeros(3)
             if dev_valid is not None:
@@ -312,7 +340,8 @@ class MLPEnsembleCEMDynamicsModel(object):
             logger.logkv("Epochs", epoch)
 
     def _preprocess_inputs(self, obs, act, delta, cp_obs, cp_act, future_bool, obs_next, back_delta):
-        """reference :676-696: explode the future window into rows, tile the history, mask."""
+        """reference :676-696: explode the future window into rows, tile the history, mask.  Kept as the host-side
+        definition of a "row" (tests compare the device gather of `fit` against it); `fit` itself no longer calls it."""
         D, A, Hh, F = self.obs_space_dims, self.action_space_dims, self.history_length, self.future_length
         fb = future_bool.reshape(-1) > 0
         rows = lambda x, w: x.reshape((-1, w))[fb]

@@ -114,6 +114,11 @@ def test_split_preprocess_bootstrap_batches(E):
             assert float(dist.max()) < 1e-6
             if E == 1:
                 assert sorted(map(tuple, seen.numpy().round(5))) == sorted(map(tuple, train_obs.numpy().round(5)))
+                # all seven tensors of a batch row belong to the SAME (window, future offset) row, history untiled
+                names = ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
+                joint = np.concatenate([torch.cat([b[k][e] for b in batches]).numpy() for k in names], axis=1)
+                ref = np.concatenate([np.asarray(w_, dtype=np.float32) for w_ in want], axis=1)
+                assert sorted(map(tuple, joint.round(4))) == sorted(map(tuple, ref.round(4)))
     # epoch 2 reshuffles the SAME bootstrap multiset (shuffle_rows, :472-474)
     for e in range(E):
         e0 = torch.cat([b["obs"][e] for b in eng.train_batches[:nb]]).numpy().round(5)
