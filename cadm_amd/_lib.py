@@ -73,6 +73,7 @@ SIGNATURES = {
     "cadm_rs_plan": (_i, [_P, _P, _P, _P, _i, _i, _u32, _u32, _P, _P, _P, _P]),
     "cadm_train_configure": (_i, [_P, C.POINTER(TrainHParams), _i]),
     "cadm_train_step": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _P, _P]),
+    "cadm_train_step_rows": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _i, _P, _P, _P, C.c_longlong, _i, _i, _P, _P]),
     "cadm_train_reset": (_i, [_P, _P]),
     "cadm_predict": (_i, [_P, _P, _P, _P, _P, _i, _P, _P, _P]),
     "cadm_profile_enable": (_i, [_P, _i]),

@@ -605,7 +605,23 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
 // ---------------------------------------------------------------------------------------------
 // input assembly (core/utils.py:372-379 and :619-621 of the reference)
 // ---------------------------------------------------------------------------------------------
+// Where batch row (e, b) lives in the caller's tensors.  Direct: row r of [E*B, .] tensors.  Indexed (`fit`'s windowed
+// dataset, cadm_train_step_rows): rid = idx[r], window w = row_w[rid], future offset f = row_f[rid]; per-step tensors are
+// [N, F, .] (source row w*F + f), history tensors [N, .] (source row w).
+struct RowMap {
+    const long long *idx, *row_w, *row_f;
+    int F, B;
+    long long idx_ld;                 // idx[e * idx_ld + b]: a batch is a column slice of the [E, n_train] bootstrap matrix
+};
+__device__ __forceinline__ void map_row(const RowMap& m, long r, long& srow, long& swin) {
+    if (!m.idx) { srow = r; swin = r; return; }
+    const long long rid = m.idx[(r / m.B) * m.idx_ld + r % m.B];
+    swin = m.row_w[rid];
+    srow = swin * m.F + m.row_f[rid];
+}
+
 struct AsmP {
+    RowMap map;
     const float *obs, *obs_next, *act, *cp_obs, *cp_act;
     const float *obs_mean, *obs_std, *act_mean, *act_std, *cp_obs_mean, *cp_obs_std, *cp_act_mean, *cp_act_std;
     float *Xff, *Xbk, *Xcp;
@@ -625,14 +641,16 @@ __device__ __forceinline__ float preproc_at(int env, const float* o, int pf) {
 
 __global__ void assemble_kernel(const AsmP p) {
     const int row = blockIdx.x;                       // e * B + b
+    long srow, swin;
+    map_row(p.map, row, srow, swin);
     for (int f = threadIdx.x; f < p.P + p.A; f += blockDim.x) {
         if (f < p.P) {
             const float inv = p.obs_std[f] + 1e-10f;
-            p.Xff[(long)row * p.K0 + f] = (preproc_at(p.env, p.obs + (long)row * p.D, f) - p.obs_mean[f]) / inv;
-            if (p.has_back) p.Xbk[(long)row * p.K0 + f] = (preproc_at(p.env, p.obs_next + (long)row * p.D, f) - p.obs_mean[f]) / inv;
+            p.Xff[(long)row * p.K0 + f] = (preproc_at(p.env, p.obs + srow * p.D, f) - p.obs_mean[f]) / inv;
+            if (p.has_back) p.Xbk[(long)row * p.K0 + f] = (preproc_at(p.env, p.obs_next + srow * p.D, f) - p.obs_mean[f]) / inv;
         } else {
             const int a = f - p.P;
-            const float v = (p.act[(long)row * p.A + a] - p.act_mean[a]) / (p.act_std[a] + 1e-10f);
+            const float v = (p.act[srow * p.A + a] - p.act_mean[a]) / (p.act_std[a] + 1e-10f);
             p.Xff[(long)row * p.K0 + f] = v;
             if (p.has_back) p.Xbk[(long)row * p.K0 + f] = v;
         }
@@ -641,8 +659,8 @@ __global__ void assemble_kernel(const AsmP p) {
         const int n = p.ncpo + p.ncpa;
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             float v;
-            if (i < p.ncpo) v = (p.cp_obs[(long)row * p.ncpo + i] - p.cp_obs_mean[i]) / (p.cp_obs_std[i] + 1e-10f);
-            else v = (p.cp_act[(long)row * p.ncpa + (i - p.ncpo)] - p.cp_act_mean[i - p.ncpo]) / (p.cp_act_std[i - p.ncpo] + 1e-10f);
+            if (i < p.ncpo) v = (p.cp_obs[swin * p.ncpo + i] - p.cp_obs_mean[i]) / (p.cp_obs_std[i] + 1e-10f);
+            else v = (p.cp_act[swin * p.ncpa + (i - p.ncpo)] - p.cp_act_mean[i - p.ncpo]) / (p.cp_act_std[i - p.ncpo] + 1e-10f);
             p.Xcp[(long)row * n + i] = v;
         }
     }
@@ -652,8 +670,9 @@ __global__ void assemble_kernel(const AsmP p) {
 // losses (dynamics.py:269-314) and output-layer gradients
 // ---------------------------------------------------------------------------------------------
 struct LossP {
+    RowMap map;
     const float *mu, *lv, *bmu;              // head outputs [E*B, D]
-    const float *delta, *back_delta;         // raw targets [E*B, D]
+    const float *delta, *back_delta;         // raw targets [E*B, D] (or through map)
     const float *dmean, *dstd, *bdmean, *bdstd, *maxlv, *minlv;
     float *dMu, *dLv, *dBmu;                 // d loss / d head pre-activation
     float *terms;                            // [7][E*B*D]: mse, mu_loss, var_loss, back_mse, g_maxlv, g_minlv, (unused)
@@ -668,8 +687,11 @@ __global__ void loss_kernel(const LossP p) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= p.n) return;
     const int d = (int)(i % p.D);
+    long srow, swin;
+    map_row(p.map, i / p.D, srow, swin);
+    const long si = srow * p.D + d;                            // this element in the caller's target tensors
     const float s = 1.0f / ((float)p.B * (float)p.D);         // reduce_mean over b then d; reduce_sum over e
-    const float t = (p.delta[i] - p.dmean[d]) / (p.dstd[d] + 1e-10f);
+    const float t = (p.delta[si] - p.dmean[d]) / (p.dstd[d] + 1e-10f);
     const float mu = p.mu[i];
     const float diff = mu - t;
     p.terms[0 * p.n + i] = diff * diff * s;                                   // mse            (:273-274)
@@ -692,7 +714,7 @@ __global__ void loss_kernel(const LossP p) {
         p.terms[5 * p.n + i] = g_lvc * (1.0f - s1);                           // d / d min_logvar
     }
     if (p.has_back) {
-        const float tb = (p.back_delta[i] - p.bdmean[d]) / (p.bdstd[d] + 1e-10f);
+        const float tb = (p.back_delta[si] - p.bdmean[d]) / (p.bdstd[d] + 1e-10f);
         const float db = p.bmu[i] - tb;
         p.terms[3 * p.n + i] = db * db * s;                                   // back_mse       (:280-281)
         p.dBmu[i] = p.back_coeff * 2.0f * s * db;
@@ -1075,7 +1097,7 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
 }
 
 // forward of the context / forward (/ backward) nets on one [E,B,.] batch into the workspace
-int forward_nets(cadm_ctx* ctx, const float* obs, const float* act, const float* obs_next, const float* cp_obs,
+int forward_nets(cadm_ctx* ctx, const RowMap& map, const float* obs, const float* act, const float* obs_next, const float* cp_obs,
                  const float* cp_act, int B, bool has_back, hipStream_t s) {
     TrainState* t = ctx->train;
     const bool has_cp = ctx->C > 0;
@@ -1084,6 +1106,7 @@ int forward_nets(cadm_ctx* ctx, const float* obs, const float* act, const float*
     int rc;
     if ((rc = sync_programs(ctx, s))) return rc;
     AsmP ap{};
+    ap.map = map;
     ap.obs = obs; ap.obs_next = obs_next; ap.act = act; ap.cp_obs = cp_obs; ap.cp_act = cp_act;
     ap.obs_mean = ctx->st.obs_mean; ap.obs_std = ctx->st.obs_std; ap.act_mean = ctx->st.act_mean; ap.act_std = ctx->st.act_std;
     ap.cp_obs_mean = ctx->st.cp_obs_mean; ap.cp_obs_std = ctx->st.cp_obs_std;
@@ -1106,9 +1129,9 @@ __global__ void clamp_logvar_kernel(const float* lv, const float* maxlv, const f
 }
 }  // namespace
 
-extern "C" int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act, const float* delta,
-                               const float* obs_next, const float* back_delta, const float* cp_obs,
-                               const float* cp_act, int B, int train, float* losses_out, void* stream) {
+static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, const float* act, const float* delta,
+                           const float* obs_next, const float* back_delta, const float* cp_obs, const float* cp_act, int B,
+                           int train, float* losses_out, void* stream) {
     CADM_REQUIRE(ctx && obs && act && delta && losses_out && B > 0, "cadm_train_step: bad arguments");
     CADM_REQUIRE(ctx->train && ctx->train->configured, "cadm_train_step: call cadm_train_configure first");
     CADM_REQUIRE(ctx->st.set, "cadm_train_step: normalisation stats not set");
@@ -1126,10 +1149,11 @@ extern "C" int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act
     const int cpin = (ctx->D + ctx->A) * ctx->cfg.history_length;
     const long R = (long)E * B;
 
-    if ((rc = forward_nets(ctx, obs, act, obs_next, cp_obs, cp_act, B, has_back, s))) return rc;
+    if ((rc = forward_nets(ctx, map, obs, act, obs_next, cp_obs, cp_act, B, has_back, s))) return rc;
 
     // ---- losses + head gradients ----
     LossP lp{};
+    lp.map = map;
     lp.mu = t->ff.mu; lp.lv = t->ff.lv; lp.bmu = t->bk.mu; lp.delta = delta; lp.back_delta = back_delta;
     lp.dmean = ctx->st.delta_mean; lp.dstd = ctx->st.delta_std; lp.bdmean = ctx->st.back_delta_mean; lp.bdstd = ctx->st.back_delta_std;
     lp.maxlv = ctx->ff_maxlv; lp.minlv = ctx->ff_minlv;
@@ -1206,6 +1230,25 @@ extern "C" int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act
     return CADM_OK;
 }
 
+extern "C" int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act, const float* delta,
+                               const float* obs_next, const float* back_delta, const float* cp_obs,
+                               const float* cp_act, int B, int train, float* losses_out, void* stream) {
+    return train_step_impl(ctx, RowMap{}, obs, act, delta, obs_next, back_delta, cp_obs, cp_act, B, train, losses_out, stream);
+}
+
+// The same step on rows of a WINDOWED dataset resident on the device (fit(), dynamics.py:382-569 + :676-696): per-step
+// tensors [N, F, .], history tensors [N, .]; training row rid = (row_w[rid], row_f[rid]); the batch is idx[e * idx_ld + b].
+extern "C" int cadm_train_step_rows(cadm_ctx* ctx, const float* ds_obs, const float* ds_act, const float* ds_delta,
+                                    const float* ds_obs_next, const float* ds_back_delta, const float* ds_cp_obs,
+                                    const float* ds_cp_act, int F, const long long* row_w, const long long* row_f,
+                                    const long long* idx, long long idx_ld, int B, int train, float* losses_out,
+                                    void* stream) {
+    CADM_REQUIRE(F >= 1 && row_w && row_f && idx && idx_ld >= B, "cadm_train_step_rows: bad row index arguments");
+    RowMap map{idx, row_w, row_f, F, B, idx_ld};
+    return train_step_impl(ctx, map, ds_obs, ds_act, ds_delta, ds_obs_next, ds_back_delta, ds_cp_obs, ds_cp_act, B, train, losses_out,
+                           stream);
+}
+
 // One-step prediction heads of every member on an [E,B,.] batch (the vanilla reference's `_get_pred`,
 // mlp_ensemble_cem_dynamics.py:185-189: [mlp.mu, mlp.logvar]): normalised mean and clamped log-variance.
 extern "C" int cadm_predict(cadm_ctx* ctx, const float* obs, const float* act, const float* cp_obs, const float* cp_act,
@@ -1219,7 +1262,7 @@ extern "C" int cadm_predict(cadm_ctx* ctx, const float* obs, const float* act, c
     int rc = ensure_state(ctx);
     if (rc) return rc;
     if ((rc = ensure_workspace(ctx, B))) return rc;
-    if ((rc = forward_nets(ctx, obs, act, nullptr, cp_obs, cp_act, B, false, s))) return rc;
+    if ((rc = forward_nets(ctx, RowMap{}, obs, act, nullptr, cp_obs, cp_act, B, false, s))) return rc;
     TrainState* t = ctx->train;
     const long n = (long)ctx->E * B * ctx->D;
     CADM_CHECK_HIP(hipMemcpyAsync(mu_out, t->ff.mu, n * sizeof(float), hipMemcpyDeviceToDevice, s));

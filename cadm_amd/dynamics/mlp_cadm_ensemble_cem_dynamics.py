@@ -312,8 +312,8 @@ class MLPEnsembleCEMDynamicsModel(object):
             losses = []
             for b in range(int(np.ceil(n_train / self.batch_size))):
                 bi = didx[:, b * self.batch_size:(b + 1) * self.batch_size]    # [E,B] row ids
-                batch = self._gather_rows(dev, row_w[bi], row_f[bi])           # device gather -> [E,B,.]
-                losses.append(eng.train_step(batch, train=True))
+                # the step reads its rows through (row id -> window, offset) inside the kernels: no gathered batch
+                losses.append(eng.train_step_rows(dev, self.future_length, row_w, row_f, bi, train=True))
             tl = torch.stack(losses).mean(0).cpu().numpy() if losses else np.zeros(3)
             if dev_valid is not None:
                 v_mse, v_back, v_recon = eng.train_step(dev_valid, train=False).cpu().numpy()

@@ -368,6 +368,20 @@ class HipEngine:
               "cadm_train_step")
         return losses
 
+    def train_step_rows(self, dev, F, row_w, row_f, idx, train=True):
+        """One step on rows of the windowed device dataset `dev` (dict of [N, F*dim] / [N, dim] tensors): idx [E,B] int64
+        row ids, row_w / row_f int64 (window, future offset) of every training row.  No gather is materialised."""
+        B = idx.shape[1]
+        if idx.stride(1) != 1:
+            idx = idx.contiguous()
+        g = lambda k: ptr(dev.get(k))
+        losses = torch.empty((3,), dtype=torch.float32, device=self.device)
+        check(self.lib.cadm_train_step_rows(self._ctx, g("obs"), g("act"), g("delta"), g("obs_next"), g("back_delta"),
+                                            g("cp_obs"), g("cp_act"), int(F), ptr(row_w), ptr(row_f), ptr(idx), int(idx.stride(0)), B,
+                                            int(train),
+                                            ptr(losses), self.stream), "cadm_train_step_rows")
+        return losses
+
     # ------------------------------------------------------------------ multi-GPU (RCCL communicator owned by the ctx)
     def dist_init(self, group=None):
         """Create the ctx's RCCL communicator over the ranks of a torch.distributed group (the group is only

@@ -191,6 +191,15 @@ int cadm_train_configure(cadm_ctx* ctx, const cadm_train_hparams* hp, int max_ba
 int cadm_train_step(cadm_ctx* ctx, const float* obs, const float* act, const float* delta,
                     const float* obs_next, const float* back_delta, const float* cp_obs,
                     const float* cp_act, int B, int train, float* losses_out, void* stream);
+/* The same step on rows of a windowed dataset that stays on the device -- what `fit` (dynamics.py:382-569) feeds after
+ * `_preprocess_inputs` (:676-696) without materialising the exploded rows: per-step tensors are [N, F, .] (obs, act,
+ * delta, obs_next, back_delta), history tensors [N, .] (cp_obs, cp_act); training row rid is window row_w[rid] at future
+ * offset row_f[rid]; the batch is idx[e * idx_ld + b], b < B (row ids, int64): a column slice of the [E, n_train] bootstrap
+ * matrix needs no copy. */
+int cadm_train_step_rows(cadm_ctx* ctx, const float* ds_obs, const float* ds_act, const float* ds_delta,
+                         const float* ds_obs_next, const float* ds_back_delta, const float* ds_cp_obs,
+                         const float* ds_cp_act, int F, const long long* row_w, const long long* row_f,
+                         const long long* idx, long long idx_ld, int B, int train, float* losses_out, void* stream);
 /* One-step prediction heads of every member on an [E,B,.] batch: normalised mean mu [E,B,D] and (optional,
  * probabilistic models) soft-clamped log-variance [E,B,D] -- the vanilla reference's `_get_pred`
  * (mlp_ensemble_cem_dynamics.py:185-189 -> [mlp.mu, mlp.logvar]); backs the public predict(). */

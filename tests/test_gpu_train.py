@@ -149,3 +149,37 @@ def test_train_then_plan_uses_updated_weights(gpu):
     ctx2 = eng2.context_forward(prob["cp_obs"], prob["cp_act"])
     r2 = eng2.rollout_returns(prob["obs"], ctx2, acts, eps=eps).cpu().numpy()
     np.testing.assert_array_equal(r1, r2)
+
+
+def test_train_step_rows_equals_gathered_batch(gpu):
+    """cadm_train_step_rows (rows addressed as (window, future offset) inside the kernels) == cadm_train_step on the
+    batch gathered the way the reference's _preprocess_inputs + bootstrap indexing would (dynamics.py:676-696,:478-503)."""
+    env, E, B, N, F, Hh = "halfcheetah", 5, 48, 40, 3, 10
+    prob = synth.make_problem(env=env, context=True, E=E, trained_like=True, with_back=True, seed=41)
+    r = np.random.default_rng(5)
+    D, A = 18, 6
+    ds = dict(obs=r.standard_normal((N, F * D)), act=r.standard_normal((N, F * A)), delta=r.standard_normal((N, F * D)),
+              obs_next=r.standard_normal((N, F * D)), back_delta=r.standard_normal((N, F * D)),
+              cp_obs=0.1 * r.standard_normal((N, D * Hh)), cp_act=r.uniform(-1, 1, (N, A * Hh)))
+    fb = r.uniform(size=(N, F)) < 0.8
+    w, f = np.nonzero(fb)
+    idx = r.integers(0, w.shape[0], size=(E, B))
+    results = []
+    for mode in ("rows", "gathered"):
+        eng = make_engine(prob, p=E)
+        eng.train_configure(1e-3, WD, CWD, 1.0, 0.5, max_batch=B)
+        dev = {k: eng._t(v) for k, v in ds.items()}
+        tw, tf_, ti = (torch.as_tensor(x, device=eng.device) for x in (w, f, idx))
+        for _ in range(3):
+            if mode == "rows":
+                losses = eng.train_step_rows(dev, F, tw, tf_, ti, train=True)
+            else:
+                ww, ff = tw[ti], tf_[ti]
+                batch = {k: dev[k].view(N, F, -1)[ww, ff] for k in ("obs", "act", "delta", "obs_next", "back_delta")}
+                batch["cp_obs"], batch["cp_act"] = dev["cp_obs"][ww], dev["cp_act"][ww]
+                losses = eng.train_step({k: v.contiguous() for k, v in batch.items()}, train=True)
+        results.append((losses.cpu().numpy(), {n: {k: v.cpu().numpy() for k, v in eng.nets[n].items()} for n in eng.net_names()}))
+    np.testing.assert_array_equal(results[0][0], results[1][0])
+    for n in results[0][1]:
+        for k in results[0][1][n]:
+            np.testing.assert_array_equal(results[0][1][n][k], results[1][1][n][k], err_msg="%s/%s" % (n, k))

@@ -56,6 +56,14 @@ class _Recorder:
         self.valid_calls += 1
         return torch.tensor([0.5, 0.25, v])
 
+    def train_step_rows(self, dev, F, row_w, row_f, idx, train=True):
+        """what cadm_train_step_rows reads: per-step tensors [N, F, .] at (w, f), history tensors at w"""
+        w, f = row_w[idx], row_f[idx]
+        N = dev["obs"].shape[0]
+        batch = {k: dev[k].view(N, F, -1)[w, f] for k in ("obs", "act", "delta", "obs_next", "back_delta")}
+        batch["cp_obs"], batch["cp_act"] = dev["cp_obs"][w], dev["cp_act"][w]
+        return self.train_step(batch, train)
+
     def repack(self):
         self.repacked += 1
 

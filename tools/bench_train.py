@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the fused training step (B=256, E=5, back_coeff=0.5, probabilistic).
-Prints ms/step of cadm_train_step with a device-resident batch, and of the host loop's gather + step."""
+Prints ms/step of cadm_train_step with a device-resident batch, and of fit()'s indexed step on a windowed dataset."""
 import os
 import sys
 import time
@@ -35,16 +35,23 @@ def main():
     dt = (time.perf_counter() - t0) / N
     flops = 3 * 2 * 5 * B * (2 * 134000 + 103040)
     print("train_step B=%d: %.3f ms/step  (%.1f GFLOP/step -> %.1f TFLOP/s)" % (B, dt * 1e3, flops / 1e9, flops / dt / 1e12))
-    # host loop flavour: device gather of a bootstrap batch + step
-    Ntr = 20000
-    data = {k: eng._t(np.random.default_rng(0).standard_normal((Ntr,) + v.shape[2:])) for k, v in batch.items()}
-    idx = torch.randint(0, Ntr, (5, B), device=eng.device)
-    t0 = time.perf_counter()
-    for _ in range(N):
-        b = {k: v[idx] for k, v in data.items()}
-        eng.train_step(b, train=True)
+    # fit() flavour: rows of a windowed device dataset addressed through bootstrap indices (cadm_train_step_rows)
+    Nw, F = 2000, 10
+    r = np.random.default_rng(0)
+    dims = {k: v.shape[2] for k, v in batch.items()}
+    dev = {k: eng._t(r.standard_normal((Nw, (1 if k.startswith("cp_") else F) * d))) for k, d in dims.items()}
+    row_w = torch.arange(Nw, device=eng.device).repeat_interleave(F)
+    row_f = torch.arange(F, device=eng.device).repeat(Nw)
+    idx = torch.randint(0, Nw * F, (5, 20 * B), device=eng.device)
+    for _ in range(5):
+        eng.train_step_rows(dev, F, row_w, row_f, idx[:, :B], train=True)
     torch.cuda.synchronize()
-    print("gather + train_step: %.3f ms/step" % ((time.perf_counter() - t0) / N * 1e3))
+    t0 = time.perf_counter()
+    for i in range(N):
+        j = (i % 20) * B
+        eng.train_step_rows(dev, F, row_w, row_f, idx[:, j:j + B], train=True)
+    torch.cuda.synchronize()
+    print("fit-loop step (rows gathered inside the kernels): %.3f ms/step" % ((time.perf_counter() - t0) / N * 1e3))
 
 
 if __name__ == "__main__":
