@@ -296,6 +296,9 @@ class MLPEnsembleCEMDynamicsModel(object):
             bootstrap_idx = rng.integers(0, n_train, size=(E, n_train))       # :465
         else:
             bootstrap_idx = np.tile(np.arange(n_train, dtype="int64"), (E, 1))  # :467
+        didx = torch.as_tensor(bootstrap_idx, device=eng.device)
+        gen = torch.Generator(device=eng.device)     # per-epoch shuffles run on the device, seeded from the caller's rng
+        gen.manual_seed(int(rng.integers(0, 2 ** 62)))
         dev_valid = None
         if valid_rows is not None and valid_rows[0].shape[0] > 0:
             vw = torch.as_tensor(valid_rows[0], device=eng.device)
@@ -305,10 +308,9 @@ class MLPEnsembleCEMDynamicsModel(object):
         epoch = -1
         for epoch in range(epochs):
             t0 = time.time()
-            # shuffle_rows (:472-474,483): independent permutation of every member's index row
-            idxs = np.argsort(rng.uniform(size=bootstrap_idx.shape), axis=-1)
-            bootstrap_idx = bootstrap_idx[np.arange(E)[:, None], idxs]
-            didx = torch.as_tensor(bootstrap_idx, device=eng.device)
+            # shuffle_rows (:472-474,483): independent permutation of every member's index row (argsort of uniforms)
+            order = torch.argsort(torch.rand(didx.shape, generator=gen, device=eng.device), dim=-1)
+            didx = torch.gather(didx, 1, order)
             losses = []
             for b in range(int(np.ceil(n_train / self.batch_size))):
                 bi = didx[:, b * self.batch_size:(b + 1) * self.batch_size]    # [E,B] row ids
