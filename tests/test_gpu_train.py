@@ -183,3 +183,50 @@ def test_train_step_rows_equals_gathered_batch(gpu):
     for n in results[0][1]:
         for k in results[0][1][n]:
             np.testing.assert_array_equal(results[0][1][n][k], results[1][1][n][k], err_msg="%s/%s" % (n, k))
+
+
+SHAPES = [  # env, E, B, hidden_sizes, cp_hidden_sizes: every load shape of the chain kernels, odd widths, ragged tiles, E > 8
+    ("pendulum", 2, 1, (128,) * 2, (64,)),                 # single row; D = 3 (odd heads), tiny K0
+    ("slim_humanoid", 3, 17, (256,) * 3, (100, 50)),       # D = 45 (odd), cp widths not multiples of 4 / 16
+    ("ant", 9, 33, (128,) * 2, (256, 128, 64)),            # E > 8: two members per XCD slot; K0 = 45 (odd)
+    ("cartpole", 7, 40, (136,) * 2, (72, 36)),             # widths that are multiples of 4 but not of 16 / 32
+    ("halfcheetah", 4, 50, (200,) * 4, (30, 22)),          # E = 4: two XCDs per member; even-only cp widths (b64 but not b128)
+]
+
+
+@pytest.mark.parametrize("env,E,B,hid,cph", SHAPES)
+def test_chain_kernel_shapes(gpu, env, E, B, hid, cph):
+    prob = synth.make_problem(env=env, context=True, E=E, hidden_sizes=hid, cp_hidden_sizes=cph, trained_like=True,
+                              with_back=True, seed=50)
+    wd, cwd = WD[:len(hid)] + (WD[-1],), CWD[:len(cph)] + (CWD[-1],)
+    cfg = dict(deterministic=False, back_coeff=0.5, weight_decay_coeff=1.0, weight_decays=wd, context_weight_decays=cwd,
+               n_hidden=len(hid), n_cp_hidden=len(cph))
+    batch = synth.make_train_batch(prob, B=B, seed=6)
+    tb = {k: torch.tensor(v, dtype=torch.float64) for k, v in batch.items()}
+    # losses
+    eng = make_engine(prob, p=E)
+    eng.train_configure(1e-3, wd, cwd, 1.0, 0.5, max_batch=B)
+    got = eng.train_step(_dev_batch(eng, batch, True, True), train=False).cpu().numpy()
+    ff, back, cp, st = _oracle_nets(prob, torch.float64, False)
+    ref = otrain.train_losses(env, ff, back, cp, st, tb, cfg)
+    want = np.array([float(ref["mse"]), float(ref["back_mse"]), float(ref["recon"])])
+    np.testing.assert_allclose(got, want, rtol=5e-5, atol=5e-5)
+    # gradients through the linearised Adam step (see test_gradients_via_linearised_adam)
+    eng = make_engine(prob, p=E)
+    eng.train_configure(1e6, wd, cwd, 1.0, 0.5, max_batch=B, beta1=0.0, beta2=0.0, epsilon=1e6)
+    before = {n: {k: v.clone() for k, v in eng.nets[n].items()} for n in eng.net_names()}
+    eng.train_step(_dev_batch(eng, batch, True, True), train=True)
+    ff, back, cp, st = _oracle_nets(prob, torch.float64)
+    out = otrain.train_losses(env, ff, back, cp, st, tb, cfg)
+    grads = otrain.grads_of(out["loss"], {"ff_model": ff, "backward_model": back, "context_model": cp})
+    for net in eng.net_names():
+        for name, w0 in before[net].items():
+            g_ref = grads[net][name]
+            g_hip = (w0 - eng.nets[net][name]).cpu().numpy().astype(np.float64)
+            if g_ref is None:
+                assert np.abs(g_hip).max() == 0.0, "%s/%s moved although it has no gradient" % (net, name)
+                continue
+            g_ref = g_ref.numpy()
+            scale = max(np.abs(g_ref).max(), 1e-12)
+            err = np.abs(g_hip - g_ref).max() / scale
+            assert err < 2e-3, "%s/%s gradient off: rel-to-max err %.3e (max |g| %.3e)" % (net, name, err, scale)
