@@ -122,9 +122,11 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);
     const int mi = blockIdx.x;
     const int n = G * n_local;
-    if (n <= 2048) {
+    constexpr int SMALL_N = 256, LISTMAX = 1024;
+    bool done = false;
+    if (n <= SMALL_N) {
         // small n: every candidate's rank by counting (keys are unique: index in the low word); the K best
-        // land sorted in keys[0..K) with one barrier instead of the O(log^2 n) barriers of the bitonic sort
+        // land sorted in keys[0..K) with one barrier instead of the O(log^2 n) barriers of a sort
         uint64_t* raw = keys + npow2;
         for (int i = threadIdx.x; i < n; i += blockDim.x) raw[i] = make_key(cand_value(cand, rows, p, G, n_local, m, mi, i), (uint32_t)i);
         __syncthreads();
@@ -135,7 +137,75 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
             if (rank < K) keys[rank] = ki;
         }
         __syncthreads();
+        done = true;
     } else {
+        // larger n (every rank of a sharded planner refits over the GLOBAL candidate set): radix-select the K-th smallest
+        // key's value word (4 passes of 8-bit LDS histograms), collect the keys at or below it (K plus value ties) and
+        // rank only those.  O(n) instead of O(n^2 / threads) LDS reads; tie order (lower index first) is untouched
+        // because the final ranking uses the full (value, index) keys.
+        uint64_t* list = keys + LISTMAX;                       // [LISTMAX]
+        uint64_t* raw = keys + 2 * LISTMAX;                    // [n]
+        unsigned* hist = reinterpret_cast<unsigned*>(raw + n); // [256] + {prefix, krem, count}
+        unsigned* ctl = hist + 256;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) raw[i] = make_key(cand_value(cand, rows, p, G, n_local, m, mi, i), (uint32_t)i);
+        if (threadIdx.x == 0) { ctl[0] = 0u; ctl[1] = (unsigned)K; ctl[2] = 0u; }
+        for (int pass = 3; pass >= 0; --pass) {
+            for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0u;
+            __syncthreads();
+            const unsigned prefix = ctl[0];
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const unsigned hv = (unsigned)(raw[i] >> 32);
+                if (pass == 3 || (hv >> (8 * (pass + 1))) == prefix) atomicAdd(&hist[(hv >> (8 * pass)) & 255u], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) {                            // wave 0: 256-bin prefix scan, 4 bins per lane
+                const unsigned krem = ctl[1];
+                const int l = threadIdx.x;
+                const unsigned h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+                const unsigned tot = h0 + h1 + h2 + h3;
+                unsigned incl = tot;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const unsigned up = __shfl_up(incl, d, 64);
+                    if (l >= d) incl += up;
+                }
+                const unsigned long long hit = __ballot(incl >= krem);       // krem <= elements under the prefix: never empty
+                const int first = __ffsll((long long)hit) - 1;
+                if (l == first) {
+                    unsigned cum = incl - tot, b = 4u * l;
+                    if (cum + h0 < krem) { cum += h0; ++b;
+                        if (cum + h1 < krem) { cum += h1; ++b;
+                            if (cum + h2 < krem) { cum += h2; ++b; } } }
+                    ctl[0] = (prefix << 8) | b;
+                    ctl[1] = krem - cum;
+                }
+            }
+            __syncthreads();
+        }
+        const unsigned hvk = ctl[0];                            // value word of the K-th smallest key
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint64_t ki = raw[i];
+            if ((unsigned)(ki >> 32) <= hvk) {
+                const unsigned pos = atomicAdd(&ctl[2], 1u);
+                if (pos < (unsigned)LISTMAX) list[pos] = ki;
+            }
+        }
+        __syncthreads();
+        const int cnt = (int)ctl[2];
+        if (cnt <= LISTMAX) {
+            for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+                const uint64_t ki = list[i];
+                int rank = 0;
+                for (int j = 0; j < cnt; ++j) rank += list[j] < ki ? 1 : 0;
+                if (rank < K) keys[rank] = ki;
+            }
+            __syncthreads();
+            done = true;
+        } else {
+            __syncthreads();                                    // more than LISTMAX ties on the K-th value: full sort below
+        }
+    }
+    if (!done) {
         for (int i = threadIdx.x; i < npow2; i += blockDim.x)
             keys[i] = i < n ? make_key(cand_value(cand, rows, p, G, n_local, m, mi, i), (uint32_t)i) : ~0ull;
         __syncthreads();
@@ -296,11 +366,17 @@ int cadm_launch_refit(cadm_ctx* ctx, const float* cand_returns, const float* row
                  n, ctx->cfg.num_elites);
     int npow2 = 1;
     while (npow2 < n) npow2 <<= 1;
-    const size_t lds_keys = (size_t)npow2 * sizeof(uint64_t) * (n <= 2048 ? 2 : 1);
+    // counting path: keys[npow2] + raw[npow2]; select path: keys/list[2 * 1024] + raw[n] + histogram; sort fallback: keys[npow2]
+    size_t lds_keys = (size_t)npow2 * sizeof(uint64_t) * (n <= 256 ? 2 : 1);
+    if (n > 256) {
+        const size_t sel = (size_t)(2 * 1024 + n) * sizeof(uint64_t) + 260 * sizeof(unsigned);
+        lds_keys = sel > lds_keys ? sel : lds_keys;
+        lds_keys = (lds_keys + 15) & ~(size_t)15;
+    }
     const int HA = ctx->H * ctx->A;
     const int KG = 1024 / HA > 0 ? 1024 / HA : 1;
     const size_t lds = lds_keys + (size_t)KG * HA * sizeof(float);
-    CADM_REQUIRE(lds <= 160 * 1024 - 4096 && lds_keys <= 128 * 1024,
+    CADM_REQUIRE(lds <= 156 * 1024 && npow2 <= 16384,
                  "cadm_cem_refit: n_candidates %d exceeds the in-LDS sort capacity (16384)", n);
     static bool attr_set = false;
     if (!attr_set) {

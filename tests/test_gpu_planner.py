@@ -269,11 +269,11 @@ def test_candidate_shards_compose(gpu):
     np.testing.assert_array_equal(_np(v1), _np(v2))
 
 
-def test_refit_large_n_bitonic_path(gpu):
+def test_refit_large_n(gpu):
     prob = synth.make_problem(env="halfcheetah", m=2, H=4, seed=6)
     eng = make_engine(prob, p=5, H=4)
     rng = np.random.default_rng(3)
-    m, n = 2, 3000                                   # > 2048 -> bitonic sort path
+    m, n = 2, 3000                                   # radix-select path
     acts = rng.uniform(-1, 1, (m, n, 4, 6)).astype(np.float32)
     cand = rng.standard_normal((m, n)).astype(np.float32)
     cand[0, 2999] = cand[0, 5] = cand.max() + 1.0    # tie at the top: lower index first
@@ -282,7 +282,35 @@ def test_refit_large_n_bitonic_path(gpu):
     el = eng.cem_refit(eng._t(cand), eng._t(acts), mt, vt, want_elites=True)
     rm, rv, ridx = oplanner.elite_refit(mean, var, acts, cand)
     np.testing.assert_array_equal(_np(el), ridx)
-    assert_close(_np(mt), rm, 1e-6, "refit mean (bitonic)")
+    assert_close(_np(mt), rm, 1e-6, "refit mean (large n)")
+
+
+@pytest.mark.parametrize("n,ties", [(257, "few"), (401, "few"), (1600, "few"), (1600, "boundary"), (3000, "all"), (8000, "half")])
+def test_refit_selection_paths_and_ties(gpu, n, ties):
+    """n > 256: radix-select + ranking of the candidates at or below the K-th value; ties on the K-th value keep
+    tf.nn.top_k's lower-index-first order; more than 1024 ties fall back to the full in-LDS sort."""
+    prob = synth.make_problem(env="halfcheetah", m=2, H=4, seed=6)
+    eng = make_engine(prob, p=5, H=4)
+    rng = np.random.default_rng(n)
+    m = 2
+    acts = rng.uniform(-1, 1, (m, n, 4, 6)).astype(np.float32)
+    cand = rng.standard_normal((m, n)).astype(np.float32)
+    if ties == "boundary":          # the 50th best value is shared by 7 candidates: only some of them are elites
+        order = np.argsort(-cand[0])
+        cand[0, order[45:52]] = cand[0, order[45]]
+    elif ties == "all":             # every return identical: elites are candidates 0..49
+        cand[:] = 1.25
+    elif ties == "half":            # 4000 candidates share the best value
+        cand[1, ::2] = cand.max() + 1.0
+    else:
+        cand[0, n - 1] = cand[0, 5] = cand.max() + 1.0
+    mean = np.zeros((m, 4, 6), np.float32); var = np.full((m, 4, 6), 0.25, np.float32)
+    mt, vt = eng._t(mean).clone(), eng._t(var).clone()
+    el = eng.cem_refit(eng._t(cand), eng._t(acts), mt, vt, want_elites=True)
+    rm, rv, ridx = oplanner.elite_refit(mean, var, acts, cand)
+    np.testing.assert_array_equal(_np(el), ridx)
+    assert_close(_np(mt), rm, 1e-6, "refit mean")
+    assert_close(_np(vt), rv, 1e-5, "refit var")
 
 
 def test_in_library_rccl_path_single_rank(gpu):
