@@ -209,7 +209,8 @@ __device__ __forceinline__ void ring_load(Ring<G>& ring, __amdgpu_buffer_rsrc_t 
 //   ring holds chunks 0..PF-1 of this layer on entry and chunks 0..PF-1 of the NEXT layer on exit.
 //   B operands: chunks [0, NCH-IN_NS) come from lds_in (already activated), the last IN_NS chunks
 //   are the producer's K-split tiles, rebuilt into bsplit / bsplit_sel by the `side` hook (they are
-//   only needed at the END of the sweep, so the rebuild runs in the MFMA shadow of an early chunk).
+//   only needed at the END of the sweep, so the rebuild is interleaved with an early chunk: a co-resident workgroup's
+//   MFMAs fill the matrix pipe meanwhile -- a wave's own MFMAs do not, see profiles/r1_mfma_issue_microbench.md).
 //   The K-split output tiles of THIS layer use k-step `wave` of every chunk: its B operand is one
 //   float per lane, read straight from LDS at a wave-dependent address (no selects, no branches).
 //   side(jc) is extra independent work scheduled inside chunk jc's MFMA region.
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
             }
         };
         // producer's K-split tiles: sum the 4 partials, activate.  Loads are issued one chunk before the
-        // arithmetic; the per-wave k-step select is a masked sum (branch-free, weaves into the MFMA shadow).
+        // arithmetic; the per-wave k-step select is a masked sum (branch-free, interleaves between the MFMAs).
         floatx4 rb[MT][cmax(NS, 1)][4];
         floatx4 rv[MT][cmax(NS, 1)];
         auto rebuild_step = [&](int part) {     // 0: issue LDS reads, 1: sum, 2: activate r=0,1, 3: r=2,3, 4: k-step select
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
                     }
                 }
         };
-        // Gaussian-head noise of THIS step for this thread's pairs, generated in the MFMA shadow of
+        // Gaussian-head noise of THIS step for this thread's pairs, generated between the MFMAs of
         // the head pass (Philox4x32-10 round by round + Box-Muller), or fetched from the injected eps.
         uint32_t pc[MT][NPI][4], pk[MT][NPI][2];
         auto noise_part = [&](auto part_c) {    // 0: setup + load (inject), 1..10: one Philox round each, 11: Box-Muller
