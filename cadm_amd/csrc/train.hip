@@ -8,8 +8,9 @@
 //   chain_kernel (forward)   a workgroup owns 16 batch rows of one member of one net and walks the whole
 //                            layer chain (context encoder -> dynamics net -> heads) with the activations
 //                            resident in LDS; weights stream from L2 straight into the MFMA B operand
-//                            through a register ring (no LDS staging: a weight is used by exactly one
-//                            wave).  z / h of every layer are stored for the backward pass.
+//                            through rotating register blocks (no LDS staging: a weight is used by exactly
+//                            one wave; 8 waves, two per SIMD).  z / h of every layer are stored for the
+//                            backward pass.
 //   chain_kernel (backward)  same kernel, transposed weight indexing: dZ_{l-1} = (dZ_l W_l^T) * act'(z_{l-1})
 //                            down the chain; once for the forward+backward nets, once for the context net.
 //   dw_adam_kernel           every layer's W <- Adam(W, X^T dZ + c*wd*W), b <- Adam(b, colsum dZ) as ONE
@@ -25,7 +26,6 @@
 namespace {
 
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
-enum { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
 
 // Branch-free on the activation kind (uniform selects): v_exp_f32 / v_rcp_f32 sigmoid like the planner's swish_f.
 __device__ __forceinline__ float sigmoid_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
