@@ -482,16 +482,17 @@ struct DwArgs {
 };
 
 #define TN 64
-#define TM 32
+#define TM 48
 #define TK 32
 #define LDA (TM + 4)
 #define LDB (TN + 4)
-#define DW_NSLAB 2                   // slabs per K panel: a 64-deep panel is in flight at once; small enough for 4 workgroups per CU
+#define DW_NSLAB 1                   // slabs per K panel in flight (registers): one keeps the kernel at 120 VGPRs = 4 workgroups per CU
 
-// One 32 x 64 tile of one job per workgroup, reduction over the batch.  The global loads of a whole K panel are
-// issued up front (registers) and the panel is then walked slab by slab -- stash slab s into its own LDS
-// region as its loads land, barrier, 32-deep MFMA sweep -- so a panel exposes one memory latency, not one
-// per slab.  2 x 2 waves, each 16 x 32.
+// One 48 x 64 tile of one job per workgroup, reduction over the batch: the whole step's ~925 tiles then fit the chip's
+// 1024 workgroup slots (4 per CU) in ONE round (32 x 64 tiles needed 1330 = two rounds).  The global loads of a K
+// panel are issued up front (registers) and the panel is then walked slab by slab -- stash slab s into its own LDS
+// region as its loads land, barrier, 32-deep MFMA sweep.  4 waves side by side, each 48 x 16.  Occupancy beats panel
+// depth here: 2-slab panels (156 VGPRs, 3 per CU) and register double-buffering (178 VGPRs) both measured slower.
 __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     __shared__ __attribute__((aligned(16))) float As[DW_NSLAB * TK * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[DW_NSLAB * TK * LDB];
@@ -503,12 +504,13 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     const int t = tile - jb.tile0;
     const int mb = (t / jb.tn) * TM, nb = (t % jb.tn) * TN;
     const int M = jb.M, N = jb.N, K = a.B;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const float* A = jb.X + (long)e * K * jb.ldx;       // A(m = k_in, k = b) = X[b][k_in]
     const float* Bm = jb.dZ + (long)e * K * N;          // B(k = b, n)        = dZ[b][n]
-    floatx4 acc[2];
-    acc[0] = acc[1] = floatx4{0.f, 0.f, 0.f, 0.f};
+    constexpr int MI = TM / 16;
+    floatx4 acc[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     float colsum = 0.0f;                                // bias gradient (threads < 64 of the m-tile-0 blocks)
     constexpr int NLA = TM * TK / 256, NLB = TN * TK / 256;
     float ra[DW_NSLAB][NLA], rb[DW_NSLAB][NLB];
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
 #pragma unroll
     for (int it = 0; it < NLA; ++it) {
         const int idx = tid + it * 256;
-        const int am = idx & (TM - 1), ak = idx / TM;
+        const int ak = idx / TM, am = idx - ak * TM;
         ka[it] = ak; la[it] = ak * LDA + am;
         va[it] = mb + am < M;
         pa[it] = A + (va[it] ? mb + am : 0);
@@ -571,27 +573,25 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
 #pragma unroll
             for (int ks = 0; ks < TK / 4; ++ks) {
                 const int kr = ks * 4 + (lane >> 4);
-                const float av = as[kr * LDA + wm * 16 + (lane & 15)];
-                float b[2];
+                const float b = bs[kr * LDB + wn * 16 + (lane & 15)];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[j] = bs[kr * LDB + wn * 32 + j * 16 + (lane & 15)];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j], acc[j], 0, 0, 0);
+                for (int i = 0; i < MI; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[kr * LDA + i * 16 + (lane & 15)], b, acc[i], 0, 0, 0);
             }
         }
     }
 
     // ---- epilogue: D layout col = lane & 15 -> n, row = (lane >> 4) * 4 + r -> m ----
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = mb + wm * 16 + (lane >> 4) * 4 + r;
-            const int n = nb + wn * 32 + j * 16 + (lane & 15);
+            const int m = mb + i * 16 + (lane >> 4) * 4 + r;
+            const int n = nb + wn * 16 + (lane & 15);
             if (m >= M || n >= N) continue;
             const long o = ((long)e * M + m) * N + n;
             float w = jb.W[o], mo = jb.Mw[o], vo = jb.Vw[o];
-            adam_update(w, mo, vo, acc[j][r] + jb.wdc * w, a.lr_t, a.b1, a.b2, a.eps);
+            adam_update(w, mo, vo, acc[i][r] + jb.wdc * w, a.lr_t, a.b1, a.b2, a.eps);
             jb.W[o] = w; jb.Mw[o] = mo; jb.Vw[o] = vo;
         }
     if (do_colsum && nb + tid < N) {
