@@ -77,7 +77,9 @@ struct ChainStage {
     ChainPart part[2];
     const float *bias, *zprev, *g0, *g1;                 // g0 (+ g1): LOAD sources [E][B][ld_in]
     float *out0, *out1, *gsum;                           // out0: value before act_o, out1: after; gsum: LOAD echo
-    int ldz, ldo, ld_in, pad;
+    int ldz, ldo, ld_in;
+    int zpad;                                            // rows to zero behind the written range of dst: the consumer's k loops run
+                                                         // whole 32-deep blocks without masking A (host: round32(width) - width)
 };
 #define CH_MAXPF 24
 struct ChainArgs {
@@ -230,8 +232,8 @@ __device__ __forceinline__ void chain_kloop(floatx4 (&acc)[NT], const ChainPart&
         }
     };
     // A fragment of k-step sidx: MODE 0/1 lds[(4 sidx + kq) * 16 + c] = lds[64 sidx + lane]; MODE 2 (sidx = 4 t + i)
-    // lds[(16 t + 4 kq + i) * 16 + c].  Neither clamped nor masked: the stage has zeroed rows K .. round32(K) of its
-    // source buffers (chain_kernel), and anything a lookahead read fetches beyond that is never used.  (A per-step
+    // lds[(16 t + 4 kq + i) * 16 + c].  Neither clamped nor masked: the producing stage zeroed rows K .. round32(K)
+    // (ChainStage::zpad), and anything a lookahead read fetches beyond that is never used.  (A per-step
     // compare + select feeding the MFMA costs ~30 cycles per k-step that do not overlap with the matrix pipe.)
     const float* abase = MODE == 2 ? src + 64 * kq + c : src + lane;
     auto read_a = [&](int sidx) { return MODE == 2 ? abase[256 * (sidx >> 2) + 16 * (sidx & 3)] : abase[64 * sidx]; };
@@ -404,6 +406,10 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     if (timed) a.tbuf[0] = __builtin_readcyclecounter();
     for (int si = 0; si < nst; ++si) {
         const ChainStage& st = stg[si];
+        if (st.zpad > 0) {      // nobody reads dst during this stage, its readers wait for the stage-end barrier
+            float* zb = bufs + st.dst * a.bufsz + (st.dk0 + (st.kind == ST_LOAD ? st.K : st.N)) * CH_ROWS;
+            for (int i = tid; i < st.zpad * CH_ROWS / 4; i += CH_THREADS) reinterpret_cast<floatx4*>(zb)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
         if (st.kind == ST_LOAD) {
             float* dst = bufs + st.dst * a.bufsz;
             const int K = st.K;
@@ -437,16 +443,6 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
                 }
             }
         } else {
-            // rows K .. round32(K) of every source buffer <- 0: the k loops run whole 32-deep blocks without masking A
-            bool padded = false;
-            for (int pi = 0; pi < st.nparts; ++pi) {
-                const int K = st.part[pi].K, Kp = (K + 31) & ~31;
-                if (Kp == K) continue;
-                float* sb = bufs + st.part[pi].src * a.bufsz + K * CH_ROWS;
-                for (int i = tid; i < (Kp - K) * CH_ROWS / 4; i += CH_THREADS) reinterpret_cast<floatx4*>(sb)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-                padded = true;
-            }
-            if (padded) __syncthreads();
             const int N = st.N;
             for (int nb = wave * CH_GW; nb < N; nb += CH_GW * (CH_THREADS / 64)) {
                 const int nt = (N - nb + 15) >> 4;
@@ -942,9 +938,13 @@ namespace {
 
 enum { PROG_FWD_FF = 0, PROG_FWD_BK = 1, PROG_BWD_FF = 2, PROG_BWD_BK = 3, PROG_BWD_CP = 4 };
 
-ChainStage load_stage(const float* g0, const float* g1, float* gsum, int ld_in, int ldo, int K, int dst, int dk0) {
+int pad32(int w) { return ((w + 31) & ~31) - w; }
+
+// `complete`: this stage finishes the buffer (width dk0 + K) -> zero-pad behind it
+ChainStage load_stage(const float* g0, const float* g1, float* gsum, int ld_in, int ldo, int K, int dst, int dk0, bool complete = true) {
     ChainStage s{};
     s.kind = ST_LOAD; s.g0 = g0; s.g1 = g1; s.gsum = gsum; s.ld_in = ld_in; s.ldo = ldo; s.K = K; s.dst = dst; s.dk0 = dk0;
+    s.zpad = complete ? pad32(dk0 + K) : 0;
     return s;
 }
 
@@ -962,6 +962,10 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
     const int ncp = has_cp ? ctx->cfg.n_cp_hidden : 0;
     const int cpin = (ctx->D + ctx->A) * ctx->cfg.history_length;
     std::vector<ChainStage> prog;
+    auto push_gemm = [&](ChainStage g) {
+        g.zpad = g.dst >= 0 ? pad32(g.dk0 + g.N) : 0;
+        prog.push_back(g);
+    };
     int first[5], count[5];
     int maxk = K0 > HID ? K0 : HID;
     maxk = D > maxk ? D : maxk;
@@ -982,10 +986,10 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
                 } else {   // context vector -> the ctx columns of this net's input (LDS and global)
                     g.act_o = ACT_NONE; g.out1 = X + PA; g.ldo = K0; g.dk0 = PA;
                 }
-                prog.push_back(g);
+                push_gemm(g);
                 cur ^= 1;
             }
-            prog.push_back(load_stage(X, nullptr, nullptr, K0, 0, PA, cur, 0));
+            prog.push_back(load_stage(X, nullptr, nullptr, K0, 0, PA, cur, 0, false));   // [PA, K0) holds the context vector
         } else {
             prog.push_back(load_stage(X, nullptr, nullptr, K0, 0, K0, 0, 0));
         }
@@ -993,14 +997,14 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
             ChainStage g{};
             g.kind = ST_GEMM; g.N = HID; g.nparts = 1; g.part[0] = part_of(net[l], 0, 0, net[l].din, cur);
             g.bias = net[l].b; g.act_o = ACT_SWISH; g.out0 = nb.z[l]; g.out1 = nb.h[l]; g.ldo = HID; g.dst = cur ^ 1;
-            prog.push_back(g);
+            push_gemm(g);
             cur ^= 1;
         }
         for (int hd = 0; hd < (want_lv ? 2 : 1); ++hd) {
             ChainStage g{};
             g.kind = ST_GEMM; g.N = D; g.nparts = 1; g.part[0] = part_of(net[NH + hd], 0, 0, HID, cur);
             g.bias = net[NH + hd].b; g.act_o = ACT_NONE; g.out1 = hd ? nb.lv : nb.mu; g.ldo = D; g.dst = -1;
-            prog.push_back(g);
+            push_gemm(g);
         }
     };
     auto bwd_prog = [&](const std::vector<DenseRef>& net, NetBufs& nb, const float* dMu, const float* dLv) {
@@ -1012,21 +1016,21 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
             g.part[0] = part_of(net[NH], 1, 0, D, 0);
             if (dLv) g.part[1] = part_of(net[NH + 1], 1, 0, D, 1);
             g.zprev = nb.z[NH - 1]; g.ldz = HID; g.act_d = ACT_SWISH; g.out1 = nb.dz[NH - 1]; g.ldo = HID; g.dst = 2;
-            prog.push_back(g);
+            push_gemm(g);
         }
         int cur = 2;
         for (int l = NH - 1; l >= 1; --l) {
             ChainStage g{};
             g.kind = ST_GEMM; g.N = net[l].din; g.nparts = 1; g.part[0] = part_of(net[l], 1, 0, net[l].dout, cur);
             g.zprev = nb.z[l - 1]; g.ldz = HID; g.act_d = ACT_SWISH; g.out1 = nb.dz[l - 1]; g.ldo = HID; g.dst = (cur + 1) % 3;
-            prog.push_back(g);
+            push_gemm(g);
             cur = (cur + 1) % 3;
         }
         if (has_cp) {   // only the context columns of the input carry a gradient
             ChainStage g{};
             g.kind = ST_GEMM; g.N = C; g.nparts = 1; g.part[0] = part_of(net[0], 1, PA, net[0].dout, cur);
             g.out1 = nb.dctx; g.ldo = C; g.dst = -1;
-            prog.push_back(g);
+            push_gemm(g);
         }
     };
 
@@ -1043,7 +1047,7 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
             ChainStage g{};
             g.kind = ST_GEMM; g.N = L.din; g.nparts = 1; g.part[0] = part_of(L, 1, 0, L.dout, cur);
             g.zprev = t->cp.z[l - 1]; g.ldz = L.din; g.act_d = ACT_RELU; g.out1 = t->cp.dz[l - 1]; g.ldo = L.din; g.dst = cur ^ 1;
-            prog.push_back(g);
+            push_gemm(g);
             cur ^= 1;
         }
     }
