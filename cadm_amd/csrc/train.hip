@@ -278,32 +278,45 @@ __device__ __forceinline__ void chain_kloop(floatx4 (&acc)[NT], const ChainPart&
 
 // One GEMM stage for NT column tiles of this wave (VECN: tile j <-> column nb + 2 c + j, else nb + 16 j + c): all parts,
 // then the epilogue.
+__device__ __forceinline__ gcbytes uni_ptr(const float* p) { return uni((gcbytes)as_global(p)); }
+
 template <int NT, bool VECN>
 __device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, int bufsz, int e, int B, int row0, int nb,
                                             int lane, unsigned long long* dbg) {
     if (dbg) dbg[0] = __builtin_readcyclecounter();
-    const int c = lane & 15, q = lane >> 4, N = st.N;
+    const int c = lane & 15, q = lane >> 4;
+    // stage constants -> SGPRs (they come out of LDS): scalar address bases, uniform branches on the activation kinds
+    const int N = uni(st.N), ldo = uni(st.ldo), ldz = uni(st.ldz), dk0 = uni(st.dk0), dsti = uni(st.dst);
+    const int act_d = uni(st.act_d), act_o = uni(st.act_o), nparts = uni(st.nparts);
+    gcbytes p_bias = uni_ptr(st.bias), p_z = uni_ptr(st.zprev), p_o0 = uni_ptr(st.out0), p_o1 = uni_ptr(st.out1);
+    const bool has_z = p_z != nullptr, has_b = p_bias != nullptr, s0 = p_o0 != nullptr, s1 = p_o1 != nullptr;
+    const long mrow = (long)e * B;                        // first row of this member in the [E][B][.] tensors
     floatx4 acc[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    // epilogue operands requested before the k loop so that their latency hides under it
+    // epilogue operands requested before the k loop so that their latency hides under it (clamped, never predicated)
     float zp[NT][4], bv[NT];
-    const bool has_z = st.zprev != nullptr, has_b = st.bias != nullptr;
+    int ncl[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        int n = VECN ? nb + 2 * c + j : nb + 16 * j + c;
-        n = n < N ? n : N - 1;
-        gcptr bp = as_global(has_b ? st.bias : st.part[0].W) + (has_b ? (long)e * N + n : 0);
-        bv[j] = *bp;
+        const int n = VECN ? nb + 2 * c + j : nb + 16 * j + c;
+        ncl[j] = n < N ? n : N - 1;
+    }
+    {
+        gcbytes bb = has_b ? p_bias + (long)e * N * 4 : (gcbytes)as_global(st.part[0].W);
+        gcbytes zb = has_z ? p_z + mrow * ldz * 4 : (gcbytes)as_global(st.part[0].W);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int row = row0 + 4 * q + r;
-            row = row < B ? row : B - 1;
-            gcptr zq = as_global(has_z ? st.zprev : st.part[0].W) + (has_z ? ((long)e * B + row) * st.ldz + n : 0);
-            zp[j][r] = *zq;
+        for (int j = 0; j < NT; ++j) {
+            bv[j] = *reinterpret_cast<gcptr>(bb + (has_b ? 4u * (unsigned)ncl[j] : 0u));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = row0 + 4 * q + r;
+                row = row < B ? row : B - 1;
+                zp[j][r] = *reinterpret_cast<gcptr>(zb + (has_z ? 4u * (unsigned)(row * ldz + ncl[j]) : 0u));
+            }
         }
     }
-    for (int pi = 0; pi < st.nparts; ++pi) {
+    for (int pi = 0; pi < nparts; ++pi) {
         const ChainPart& pt = st.part[pi];
         const float* src = bufs + pt.src * bufsz;
         if (VECN) chain_kloop<NT, 1>(acc, pt, src, e, nb, N, lane);
@@ -312,35 +325,63 @@ __device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, i
     }
     if (dbg) dbg[1] = __builtin_readcyclecounter();
     // D layout: col = lane & 15 -> column slot c, row = (lane >> 4) * 4 + r -> batch row
-    float* dst = st.dst >= 0 ? bufs + st.dst * bufsz : nullptr;
-    const int act_d = st.act_d, act_o = st.act_o;
-    gptr out0 = as_global(st.out0), out1 = as_global(st.out1);
-    const bool s0 = st.out0 != nullptr, s1 = st.out1 != nullptr;
     floatx4 v0[NT], v1[NT];                       // [tile][r]: before / after the output activation
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float v = acc[j][r] + (has_b ? bv[j] : 0.0f);
-            if (has_z) v *= act_bwd(act_d, zp[j][r]);
-            v0[j][r] = v;
-            v1[j][r] = act_fwd(act_o, v);
-        }
+        for (int r = 0; r < 4; ++r) v0[j][r] = acc[j][r] + (has_b ? bv[j] : 0.0f);
+    if (has_z) {
+        if (act_d == ACT_SWISH) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = VECN ? nb + 2 * c + j : nb + 16 * j + c;
-        if (dst && n < N) *reinterpret_cast<floatx4*>(dst + (st.dk0 + n) * CH_ROWS + 4 * q) = v1[j];
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = zp[j][r], sg = sigmoid_fast(z);
+                    v0[j][r] *= sg * (1.0f + z * (1.0f - sg));
+                }
+        } else if (act_d == ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v0[j][r] = zp[j][r] > 0.0f ? v0[j][r] : 0.0f;
+        }
     }
-    if (VECN && (st.ldo & 1) == 0) {              // a lane's 2 tiles are 2 adjacent columns: b64 stores
+    if (act_o == ACT_SWISH) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v1[j][r] = v0[j][r] * sigmoid_fast(v0[j][r]);
+    } else if (act_o == ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v1[j][r] = fmaxf(v0[j][r], 0.0f);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v1[j] = v0[j];
+    }
+    if (dsti >= 0) {
+        float* dst = bufs + dsti * bufsz;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = VECN ? nb + 2 * c + j : nb + 16 * j + c;
+            if (n < N) *reinterpret_cast<floatx4*>(dst + (dk0 + n) * CH_ROWS + 4 * q) = v1[j];
+        }
+    }
+    // global stores: (uniform base of this member) + 32-bit byte offset (host checks E * B * ldo * 4 < 2^32)
+    gcbytes b0 = p_o0 + mrow * ldo * 4, b1 = p_o1 + mrow * ldo * 4;
+    typedef __attribute__((address_space(1))) float* gfp;
+    typedef __attribute__((address_space(1))) floatx2* gf2p;
+    if (VECN && (ldo & 1) == 0) {                 // a lane's 2 tiles are 2 adjacent columns: b64 stores
         const int n = nb + 2 * c;
         if (n < N) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + 4 * q + r;
                 if (row >= B) continue;
-                const long o = ((long)e * B + row) * st.ldo + n;
-                if (s0) *reinterpret_cast<__attribute__((address_space(1))) floatx2*>(out0 + o) = floatx2{v0[0][r], v0[1 % NT][r]};
-                if (s1) *reinterpret_cast<__attribute__((address_space(1))) floatx2*>(out1 + o) = floatx2{v1[0][r], v1[1 % NT][r]};
+                const unsigned o = 4u * (unsigned)(row * ldo + n);
+                if (s0) *(gf2p)(b0 + o) = floatx2{v0[0][r], v0[1 % NT][r]};
+                if (s1) *(gf2p)(b1 + o) = floatx2{v1[0][r], v1[1 % NT][r]};
             }
         }
     } else {
@@ -352,9 +393,9 @@ __device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, i
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + 4 * q + r;
                 if (row >= B) continue;
-                const long o = ((long)e * B + row) * st.ldo + n;
-                if (s0) out0[o] = v0[j][r];
-                if (s1) out1[o] = v1[j][r];
+                const unsigned o = 4u * (unsigned)(row * ldo + n);
+                if (s0) *(gfp)(b0 + o) = v0[j][r];
+                if (s1) *(gfp)(b1 + o) = v1[j][r];
             }
         }
     }
@@ -1090,6 +1131,8 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
     if (p0 != PROG_BWD_CP) { pf_net(ctx->ff); if (a.ny == 2) pf_net(ctx->back); }
     const size_t lds = CH_MAXSTAGE * sizeof(ChainStage) + 3 * (size_t)t->chain_bufsz * sizeof(float);
     CADM_REQUIRE(lds <= 160 * 1024, "training chain: layer too wide for the LDS-resident activation tile");
+    CADM_REQUIRE((long long)B * (t->chain_bufsz / CH_ROWS) * 4 < (1LL << 32),
+                 "training chain: batch of %d rows too large for 32-bit per-member offsets", B);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
