@@ -231,6 +231,8 @@ def main():
         if world == 1:
             out["train_step"] = train_step_bench("cuda:%d" % local_rank)
         print(json.dumps(out))
+    torch.cuda.synchronize(dev)
+    eng.close()                 # destroys the in-library RCCL communicator before the process group goes away
     if dist is not None:
         dist.destroy_process_group()
 
