@@ -150,6 +150,11 @@ class MLPEnsembleCEMDynamicsModel(object):
         """reference :344-367.  CEM: returns the whole plan [m,H,A]; RS: the first action [m,A]
         (ints [m] for discrete envs).  Continuous outputs are clipped to [-1,1]."""
         self._push_stats()
+        m = int(np.shape(obs)[0])
+        if m == 0:      # an empty batch of environments: the reference's graph returns empty arrays
+            if cem_init_mean is not None:
+                return np.zeros((0, self.n_forwards, self.action_space_dims), np.float32)
+            return np.zeros((0,), np.int32) if self.discrete else np.zeros((0, self.action_space_dims), np.float32)
         call = self._next_call()
         shard = _planner.Shard.from_dist(self.n_candidates, self._group)
         if shard.world > 1 and self.engine.dist_world == 1 and not self._dist_failed:

@@ -97,6 +97,9 @@ def test_cadm_random_shooting_and_errors(gpu):
     o = rng.standard_normal((2, 18))
     a = model.get_action(o, 0.1 * rng.standard_normal((2, 180)), rng.uniform(-1, 1, (2, 60)))
     assert a.shape == (2, 6) and np.abs(a).max() <= 1.0
+    # empty batch of environments (m = 0): empty result, like the reference's dynamic-m graph
+    assert model.get_action(o[:0], np.zeros((0, 180)), np.zeros((0, 60))).shape == (0, 6)
+    assert model.get_action(o[:0], np.zeros((0, 180)), np.zeros((0, 60)), np.zeros((0, 8, 6)), np.zeros((0, 8, 6))).shape == (0, 8, 6)
     with pytest.raises(NotImplementedError):
         CaDMModel(**_cadm_kwargs(hidden_nonlinearity="relu"))
     with pytest.raises(ValueError):
