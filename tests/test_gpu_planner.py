@@ -358,3 +358,50 @@ def test_other_hidden_widths(gpu, hid):
     assert_close(_np(rows), r_ref, 2e-4, "returns, hidden=%d" % hid)
     plan = eng.cem_plan(prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], 64, seed=1, call=1)
     assert np.isfinite(_np(plan)).all()
+
+
+@pytest.mark.parametrize("env", ["halfcheetah", "ant"])
+def test_rollout_closed_form_known_answer(gpu, env):
+    """All dynamics weights zero: the heads are their biases, so the whole 30-step recurrence has a closed form that
+    needs no MLP -- an oracle-independent pin of the head math (denormalise, two softplus clamps, exp), the particle ->
+    member map, the eps indexing, obs_postproc ([pred0, obs1: + pred1:], half_cheetah_env.py:52-56 / ant_env.py:55-59)
+    and the reward accumulation (obs0 - 0.1 |a|^2, resp. obs0 - 0.005 |a|^2 + 0.05, on the PRE-step state)."""
+    E, p, m, n, H = 5, 10, 2, 48, 30
+    prob = synth.make_problem(env=env, context=True, E=E, m=m, H=H, seed=31)
+    rng = np.random.default_rng(8)
+    D, A = prob["D"], prob["A"]
+    ff = {k: (np.zeros_like(v) if "weight" in k else v) for k, v in prob["ff"].items()}
+    ff["output_mu_bias"] = 0.3 * rng.standard_normal((E, 1, D))
+    ff["output_logvar_bias"] = rng.uniform(-12.0, 2.0, (E, 1, D))          # crosses both soft clamps (-10, 0.5)
+    prob = dict(prob, ff=ff)
+    eng = make_engine(prob, p=p)
+    actions = rng.uniform(-1, 1, (m, n, H, A))
+    eps = rng.standard_normal((H, m, n, p, D))
+    ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"])
+    rows, traj = eng.rollout_returns(prob["obs"], ctx, actions, eps=eps, it=0, want_traj=True)
+    rows, traj = _np(rows), _np(traj)                                                    # [m, n, p], [H, m, n, p, D]
+    st = prob["stats"]
+    dmean, dstd = st["delta_mean"].astype(np.float64), st["delta_std"].astype(np.float64)
+    sp = lambda x: np.logaddexp(0.0, x)
+    member = np.arange(p) // (p // E)                                                    # core/utils.py:445-455
+    mu = ff["output_mu_bias"][member, 0]                                                 # [p, D]
+    lv = ff["output_logvar_bias"][member, 0]
+    lv = 0.5 - sp(0.5 - lv)                                                              # core/utils.py:356 (max_logvar = 0.5)
+    lv = -10.0 + sp(lv + 10.0)                                                           # :357 (min_logvar = -10)
+    sd = np.exp((lv + 2.0 * np.log(dstd)) / 2.0)                                         # :360-363
+    delta = (mu * (dstd + 1e-10) + dmean)[None, None, None] + eps * sd[None, None, None]  # [H, m, n, p, D]
+    o0 = np.broadcast_to(prob["obs"][:, None, None, 0], (m, n, p)).astype(np.float64)    # dim 0 of the start state
+    ctrl = (actions ** 2).sum(-1)                                                        # [m, n, H]
+    ret = np.zeros((m, n, p))
+    cur0 = o0
+    for t in range(H):
+        if env == "halfcheetah":
+            ret += cur0 - 0.1 * ctrl[:, :, t, None]
+        else:
+            ret += cur0 - 0.005 * ctrl[:, :, t, None] + 0.05
+        cur0 = delta[t, :, :, :, 0]                                                      # next obs[0] = pred[0]
+    assert_close(rows, ret, 2e-5, "%s closed-form returns" % env)
+    # the state itself: dim 0 is replaced by the prediction, the others integrate it
+    want = np.cumsum(delta, axis=0) + prob["obs"][None, :, None, None, :]
+    want[..., 0] = delta[..., 0]
+    assert_close(traj, want, 2e-5, "%s closed-form trajectory" % env)
