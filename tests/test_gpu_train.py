@@ -230,3 +230,26 @@ def test_chain_kernel_shapes(gpu, env, E, B, hid, cph):
             scale = max(np.abs(g_ref).max(), 1e-12)
             err = np.abs(g_hip - g_ref).max() / scale
             assert err < 2e-3, "%s/%s gradient off: rel-to-max err %.3e (max |g| %.3e)" % (net, name, err, scale)
+
+
+def test_first_adam_step_moves_every_trained_parameter_by_lr(gpu):
+    """Oracle-independent pin of the TF1 Adam epilogue: from zero moments the first update is
+    lr * sqrt(1-b2)/(1-b1) * (1-b1) g / (sqrt((1-b2) g^2) + eps) = lr * sign(g) * |g| / (|g| + eps / sqrt(1-b2)),
+    i.e. every parameter with a gradient well above 3e-7 moves by lr (the context encoder's first layer sees gradients of a
+    few 1e-6: 0.9 lr), none by more, and parameters without a gradient
+    (output_logvar bias of the backward net, dynamics.py:213-240) stay put."""
+    env, E, B, lr = "halfcheetah", 5, 128, 1e-3
+    prob = synth.make_problem(env=env, context=True, E=E, trained_like=True, with_back=True, seed=60)
+    eng = make_engine(prob, p=E)
+    eng.train_configure(lr, WD, CWD, 1.0, 0.5, max_batch=B)
+    batch = synth.make_train_batch(prob, B=B, seed=7)
+    before = {n: {k: v.clone() for k, v in eng.nets[n].items()} for n in eng.net_names()}
+    eng.train_step(_dev_batch(eng, batch, True, True), train=True)
+    for net in eng.net_names():
+        for name, w0 in before[net].items():
+            d = (eng.nets[net][name] - w0).abs().cpu().numpy().ravel()
+            if net == "backward_model" and name in ("output_logvar_bias", "max_logvar", "min_logvar"):
+                assert d.max() == 0.0, "%s/%s has no gradient and must not move" % (net, name)
+                continue
+            assert d.max() <= lr * (1 + 1e-3), "%s/%s moved by %.3e > lr" % (net, name, d.max())   # fp32 rounding of w - lr at |w| ~ 10
+            assert np.median(d) >= 0.8 * lr, "%s/%s: median |step| %.3e, expected ~lr" % (net, name, np.median(d))
