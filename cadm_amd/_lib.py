@@ -109,6 +109,12 @@ def load():
         raise CadmError(
             "libcadm_hip.so is not built (%s missing). Run `python -c \"import __graft_entry__ as g; "
             "g.build()\"` or `make -C cadm_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64: it has to be in the process BEFORE this library's dependency on
+    # libamdhip64.so is resolved, or two HIP runtimes coexist and the second one sees no device
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
