@@ -1,4 +1,5 @@
-"""Determinism / stability soak: repeated plans must be bit-identical, twin engines trained on the same batches must stay\nbit-identical (ragged batch sizes included).  python tools/soak.py [seconds]"""
+"""Determinism / stability soak: repeated plans must be bit-identical, twin engines trained on the same batches must stay
+bit-identical (ragged batch sizes included).  python tools/soak.py [seconds]"""
 import sys, os, time
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, torch
