@@ -831,12 +831,24 @@ int launch(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipStream_t
     return launch_noise<G, CADM_NOISE_PHILOX>(ctx, a, rows_per_member, s);
 }
 
+// Context widths compiled in: 0 (vanilla PE-TS) and 10 (the reference default `--context_out_dim`,
+// run_cadm_pets.py:135); override with  make CTXS="0 10 16"  (one more instantiation per env and hidden width each).
+#ifndef CADM_CTX_LIST
+#define CADM_CTX_LIST 0, 10
+#endif
+#define CADM_STR2(...) #__VA_ARGS__
+#define CADM_STR(...) CADM_STR2(__VA_ARGS__)
+template <int ENV, int HID, int... CS>
+int dispatch_ctx_list(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) {
+    int rc = CADM_EINVAL;
+    bool hit = false;
+    ((ctx->C == CS ? (hit = true, rc = launch<RC<ENV, CS, HID, 1>>(ctx, a, rpm, s), 0) : 0), ...);
+    if (!hit) cadm_set_error("rollout: context_out_dim %d not compiled in (built with CTXS = " CADM_STR(CADM_CTX_LIST) ")", ctx->C);
+    return rc;
+}
 template <int ENV, int HID>
 int dispatch_ctx(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) {
-    if (ctx->C == 0) return launch<RC<ENV, 0, HID, 1>>(ctx, a, rpm, s);
-    if (ctx->C == 10) return launch<RC<ENV, 10, HID, 1>>(ctx, a, rpm, s);
-    cadm_set_error("rollout: context_out_dim %d not compiled in (supported: 0, 10)", ctx->C);
-    return CADM_EINVAL;
+    return dispatch_ctx_list<ENV, HID, CADM_CTX_LIST>(ctx, a, rpm, s);
 }
 
 }  // namespace
@@ -846,8 +858,6 @@ int dispatch_ctx(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) {
 #ifndef CADM_HID_LIST
 #define CADM_HID_LIST 200
 #endif
-#define CADM_STR2(...) #__VA_ARGS__
-#define CADM_STR(...) CADM_STR2(__VA_ARGS__)
 template <int ENV, int... HIDS>
 int dispatch_hid(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) {
     int rc = CADM_EINVAL;
