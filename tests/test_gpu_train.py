@@ -191,6 +191,7 @@ SHAPES = [  # env, E, B, hidden_sizes, cp_hidden_sizes: every load shape of the 
     ("ant", 9, 33, (128,) * 2, (256, 128, 64)),            # E > 8: two members per XCD slot; K0 = 45 (odd)
     ("cartpole", 7, 40, (136,) * 2, (72, 36)),             # widths that are multiples of 4 but not of 16 / 32
     ("halfcheetah", 4, 50, (200,) * 4, (30, 22)),          # E = 4: two XCDs per member; even-only cp widths (b64 but not b128)
+    ("halfcheetah", 2, 20, (512,) * 2, (256, 128, 64)),    # widest compiled hidden width: 16 weight blocks per k loop
 ]
 
 
