@@ -84,6 +84,7 @@ SIGNATURES = {
     "cadm_dist_unique_id": (_i, [C.c_char_p]),
     "cadm_dist_init": (_i, [_P, C.c_char_p, _i, _i]),
     "cadm_dist_destroy": (_i, [_P]),
+    "cadm_dist_info": (_i, [_P, C.POINTER(_i), C.POINTER(_i)]),
 }
 
 _lib = None

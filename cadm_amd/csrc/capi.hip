@@ -1,5 +1,6 @@
 // extern "C" entry points of libcadm_hip.so (see include/cadm_hip.h for the contract).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -74,12 +75,23 @@ extern "C" int cadm_ctx_create(const cadm_config* cfg, cadm_ctx** out) {
     c->go = make_geo(c->HID, (c->D + 7) / 8, 1, c->D);
     c->wstream_member_floats = c->g0.layer_floats() + (size_t)(c->NH - 1) * c->gh.layer_floats() + c->go.layer_floats();
     c->bstream_member_floats = c->g0.bias_floats() + (size_t)(c->NH - 1) * c->gh.bias_floats() + c->go.bias_floats();
+    c->xg = make_xdl_geo(c->K0, c->HID, c->D, c->NH);
+    {
+        const char* sel = getenv("CADM_ROLLOUT");
+        c->use_xdl = !(sel && strcmp(sel, "f32") == 0);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
+    }
+    hipError_t e4 = hipMalloc(&c->xw, (size_t)c->xg.member_frags() * CADM_XDL_FRAG_BYTES * c->E);
+    hipError_t e5 = hipMalloc(&c->xb, (size_t)c->xg.bias_tiles() * 256 * sizeof(float) * c->E);
+    hipError_t e6 = hipMalloc(&c->xflag, sizeof(int));
     hipError_t e1 = hipMalloc(&c->wstream, c->wstream_member_floats * c->E * sizeof(float));
     hipError_t e2 = hipMalloc(&c->bstream, c->bstream_member_floats * c->E * sizeof(float));
     const size_t nst = 2 * (size_t)c->P + 2 * c->A + 4 * (size_t)c->D + 2 * (size_t)(c->D + c->A) * cfg->history_length;
     hipError_t e3 = hipMalloc(&c->st.buf, nst * sizeof(float));
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-        cadm_set_error("cadm_ctx_create: hipMalloc failed (%s)", hipGetErrorString(e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3));
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess) {
+        const hipError_t bad = e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4 != hipSuccess ? e4 : e5 != hipSuccess ? e5 : e6;
+        cadm_set_error("cadm_ctx_create: hipMalloc failed (%s)", hipGetErrorString(bad));
         cadm_ctx_destroy(c);
         return CADM_ENOMEM;
     }
@@ -101,6 +113,9 @@ extern "C" int cadm_ctx_destroy(cadm_ctx* ctx) {
     cadm_dist_destroy(ctx);
     if (ctx->wstream) (void)hipFree(ctx->wstream);
     if (ctx->bstream) (void)hipFree(ctx->bstream);
+    if (ctx->xw) (void)hipFree(ctx->xw);
+    if (ctx->xb) (void)hipFree(ctx->xb);
+    if (ctx->xflag) (void)hipFree(ctx->xflag);
     if (ctx->st.buf) (void)hipFree(ctx->st.buf);
     if (ctx->cp_scratch) (void)hipFree(ctx->cp_scratch);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);

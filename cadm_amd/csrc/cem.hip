@@ -378,11 +378,10 @@ int cadm_launch_refit(cadm_ctx* ctx, const float* cand_returns, const float* row
     const size_t lds = lds_keys + (size_t)KG * HA * sizeof(float);
     CADM_REQUIRE(lds <= 156 * 1024 && npow2 <= 16384,
                  "cadm_cem_refit: n_candidates %d exceeds the in-LDS sort capacity (16384)", n);
-    static bool attr_set = false;
-    if (!attr_set) {
-        CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&cem_refit_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        attr_set = true;
+    const void* fn = reinterpret_cast<const void*>(&cem_refit_kernel);
+    if (!ctx->attr_done.count(fn)) {    // per ctx = per device
+        CADM_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        ctx->attr_done.insert(fn);
     }
     hipLaunchKernelGGL(cem_refit_kernel, dim3(m), dim3(1024), lds, stream, cand_returns, rows, ctx->p, G, n_local, actions,
                        m, ctx->H, ctx->A, ctx->cfg.num_elites, ctx->cfg.alpha, npow2, mean_in, var_in, mean_out, var_out,

@@ -4,9 +4,11 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/cadm_hip.h"
+#include "xdl_geo.h"
 
 // ---------------------------------------------------------------------------------------------
 // error plumbing (no exceptions cross the C ABI)
@@ -96,6 +98,14 @@ struct cadm_ctx {
     float* bstream = nullptr;    // [E][ L0 | hidden x (NH-1) | OUT ] D-layout bias tiles
     size_t wstream_member_floats = 0, bstream_member_floats = 0;
     bool packed = false;
+    // split-f16 ("xdl") planner stream (xdl_geo.h): the production rollout kernel
+    XdlGeo xg;
+    unsigned short* xw = nullptr;   // [E][member_frags] fragments of 2 KB
+    float* xb = nullptr;            // [E][bias_tiles][64][4] D-layout bias tiles
+    int* xflag = nullptr;           // device flag: a weight did not fit the f16 range
+    bool use_xdl = true;            // CADM_ROLLOUT=f32 selects the fp32-MFMA kernel (developer comparison)
+    int n_cus = 256;
+    std::unordered_set<const void*> attr_done;   // kernels whose dynamic-LDS attribute is set on THIS ctx's device
     NormStats st;
     TrainState* train = nullptr;
     // scratch for the context encoder
@@ -113,6 +123,7 @@ struct cadm_ctx {
 
 // kernels' host launchers (one per translation unit)
 int cadm_pack_streams(cadm_ctx* ctx, hipStream_t s);
+int cadm_pack_xdl(cadm_ctx* ctx, hipStream_t s);
 int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, const float* ctx_vec,
                         const float* actions, const float* eps, int norm_actions, uint32_t seed,
                         uint32_t call, int it, int cand_offset, int n_global, int m, int n_local,

@@ -13,6 +13,7 @@ typedef int (*fn_init_rank2)(void**, int, IdBlob, int);
 typedef int (*fn_destroy)(void*);
 typedef int (*fn_allgather)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef const char* (*fn_errstr)(int);
+typedef int (*fn_comm_int)(void*, int*);
 
 struct Rccl {
     void* h = nullptr;
@@ -21,6 +22,7 @@ struct Rccl {
     fn_destroy destroy = nullptr;
     fn_allgather allgather = nullptr;
     fn_errstr errstr = nullptr;
+    fn_comm_int count = nullptr, user_rank = nullptr;
 } g_rccl;
 
 int load_rccl() {
@@ -37,6 +39,8 @@ int load_rccl() {
     g_rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
     g_rccl.allgather = (fn_allgather)dlsym(h, "ncclAllGather");
     g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+    g_rccl.count = (fn_comm_int)dlsym(h, "ncclCommCount");
+    g_rccl.user_rank = (fn_comm_int)dlsym(h, "ncclCommUserRank");
     if (!g_rccl.get_id || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allgather) {
         cadm_set_error("librccl lacks the expected nccl* symbols");
         return CADM_EINVAL;
@@ -82,6 +86,17 @@ extern "C" int cadm_dist_destroy(cadm_ctx* ctx) {
     ctx->nranks = 1;
     ctx->rank = 0;
     return CADM_OK;
+}
+
+extern "C" int cadm_dist_info(cadm_ctx* ctx, int* nranks_out, int* rank_out) {
+    CADM_REQUIRE(ctx && nranks_out && rank_out, "cadm_dist_info: null argument");
+    *nranks_out = 1;
+    *rank_out = 0;
+    if (!ctx->comm) return CADM_OK;                         // single-GPU planner: no communicator
+    CADM_REQUIRE(g_rccl.count && g_rccl.user_rank, "cadm_dist_info: librccl lacks ncclCommCount / ncclCommUserRank");
+    int rc = check_nccl(g_rccl.count(ctx->comm, nranks_out), "ncclCommCount");
+    if (rc) return rc;
+    return check_nccl(g_rccl.user_rank(ctx->comm, rank_out), "ncclCommUserRank");
 }
 
 // [count] floats per rank -> [nranks * count] on every rank (ncclFloat32 = 7)

@@ -118,6 +118,8 @@ int cadm_pack_streams(cadm_ctx* ctx, hipStream_t s) {
     for (int l = 1; l < NH; ++l) pack(ctx->gh, ctx->ff[l], nullptr);
     pack(ctx->go, ctx->ff[NH], &ctx->ff[NH + 1]);
     CADM_CHECK_HIP(hipGetLastError());
+    const int rc = cadm_pack_xdl(ctx, s);
+    if (rc) return rc;
     ctx->packed = true;
     return CADM_OK;
 }

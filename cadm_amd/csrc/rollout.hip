@@ -25,6 +25,12 @@ int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, 
     a.w_l0_b = (unsigned)(ctx->g0.layer_floats() * sizeof(float));
     a.w_lh_b = (unsigned)(ctx->gh.layer_floats() * sizeof(float));
     a.w_lo_b = (unsigned)(ctx->go.layer_floats() * sizeof(float));
+    a.xw = ctx->xw;
+    a.xw_bytes = (unsigned)((size_t)ctx->xg.member_frags() * CADM_XDL_FRAG_BYTES * ctx->E);
+    a.xw_member_b = (unsigned)((size_t)ctx->xg.member_frags() * CADM_XDL_FRAG_BYTES);
+    for (int w = 0, off = 0; w < 4; ++w) { a.xw_wave_b[w] = (unsigned)off; off += ctx->xg.wave_frags(w) * CADM_XDL_FRAG_BYTES; }
+    a.xb = ctx->xb;
+    a.xb_member = (size_t)ctx->xg.bias_tiles() * 256;
     a.bmember = ctx->bstream_member_floats;
     a.b_l0 = ctx->g0.bias_floats();
     a.b_lh = ctx->gh.bias_floats();

@@ -7,6 +7,10 @@ struct RolloutArgs {
     unsigned wbytes;                  // size of the whole weight stream buffer (all members)
     unsigned wmember_b;               // bytes per member
     unsigned w_l0_b, w_lh_b, w_lo_b;  // layer stream sizes (bytes): L0, hidden, OUT
+    const unsigned short* xw;         // split-f16 fragment stream (xdl kernel)
+    unsigned xw_bytes, xw_member_b, xw_wave_b[4];
+    const float* xb;                  // its bias tiles
+    size_t xb_member;
     size_t bmember;                   // bias floats per member
     size_t b_l0, b_lh;                // bias tile sizes (floats): L0/hidden, (OUT follows)
     const float *obs, *obs_rows, *ctx_vec, *actions, *eps;

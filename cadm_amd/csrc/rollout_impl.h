@@ -21,6 +21,8 @@
 
 #include "common.h"
 #include "rollout_args.h"
+#include "rollout_env.h"
+#include "rollout_xdl.h"
 
 #ifdef CADM_PHASE_TIMING
 #define NPH 24
@@ -34,116 +36,6 @@
 #endif
 
 namespace {
-
-typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
-
-template <int... Js, class F>
-__device__ __forceinline__ void static_for(std::integer_sequence<int, Js...>, F&& f) {
-    (f(std::integral_constant<int, Js>{}), ...);
-}
-
-constexpr int cmax(int a, int b) { return a > b ? a : b; }
-constexpr int rup(int a, int b) { return (a + b - 1) / b * b; }
-
-// ---------------------------------------------------------------------------------------------
-// env closures, compile-time per env kind.
-// The rollout state is tracked per DIM PAIR (2dp, 2dp+1): these tables say which input features
-// a dim feeds and which part of the reward a pair contributes.
-// ---------------------------------------------------------------------------------------------
-// features computed from obs dim d: index f[] in the preprocessed vector and op[] (0 id, 1 sin, 2 cos)
-template <int ENV> __device__ __forceinline__ int dim_feats(int d, int (&f)[2], int (&op)[2]) {
-    f[0] = f[1] = 0; op[0] = op[1] = 0;
-    if constexpr (ENV == CADM_ENV_HALFCHEETAH) {      // half_cheetah_env.py:46-50: [o1, sin o2, cos o2, o3:]
-        if (d == 0) return 0;
-        if (d == 1) { f[0] = 0; return 1; }
-        if (d == 2) { f[0] = 1; op[0] = 1; f[1] = 2; op[1] = 2; return 2; }
-        f[0] = d; return 1;
-    } else if constexpr (ENV == CADM_ENV_ANT) {       // ant_env.py:52-53: o1:
-        if (d == 0) return 0;
-        f[0] = d - 1; return 1;
-    } else {                                          // identity preproc
-        f[0] = d; return 1;
-    }
-}
-
-// obs_postproc (half_cheetah_env.py:52-56, ant_env.py:55-59: [pred0, obs1: + pred1:]; others obs + pred)
-template <int ENV> __device__ __forceinline__ float postproc(int d, float o, float delta) {
-    if constexpr (ENV == CADM_ENV_HALFCHEETAH || ENV == CADM_ENV_ANT) return d == 0 ? delta : o + delta;
-    else return o + delta;
-}
-
-// action term of the reward, state independent: precomputed per (row, t)
-template <int ENV> __device__ __forceinline__ float ctrl_term(const float* a, int A) {
-    if constexpr (ENV == CADM_ENV_PENDULUM) {     // classic_control.py:214 (gym PendulumEnv.max_torque = 2)
-        const float tq = fminf(fmaxf(a[0], -2.0f), 2.0f);
-        return tq * tq;
-    } else if constexpr (ENV == CADM_ENV_CARTPOLE) {
-        return 0.0f;
-    } else {
-        float s = 0.0f;
-        for (int i = 0; i < A; ++i) s += a[i] * a[i];
-        return s;
-    }
-}
-
-// Contribution of dim pair dp = (o0, o1) to the step reward; a row's reward is the sum over its pairs
-// (one non-zero contributor for halfcheetah / ant, so their summation order equals the reference's).
-// Obs are the PRE-step state, except cartpole whose reward reads the NEXT state.
-template <int ENV> __device__ __forceinline__ float reward_part(int dp, float o0, float o1, float ctrl) {
-    if constexpr (ENV == CADM_ENV_HALFCHEETAH) {          // half_cheetah_env.py:82-88
-        return dp == 0 ? o0 - 0.1f * ctrl : 0.0f;
-    } else if constexpr (ENV == CADM_ENV_ANT) {           // ant_env.py:89-98
-        return dp == 0 ? ((o0 + (-0.005f * ctrl)) + 0.0f) + 0.05f : 0.0f;
-    } else if constexpr (ENV == CADM_ENV_SLIM_HUMANOID) { // slim_humanoid_env.py:95-111: dims 22 and 1
-        if (dp == 11) return (16.666666666666668f * o0 - 0.1f * ctrl) - 0.0f;
-        if (dp == 0) return (o1 > 1.0f && o1 < 2.0f) ? 5.0f : 0.0f;
-        return 0.0f;
-    } else if constexpr (ENV == CADM_ENV_CARTPOLE) {      // classic_control.py:154-166: dims 0 and 2
-        const float th = 0.20943951023931953f;            // 12 * 2 * pi / 360
-        if (dp == 0) return 1.0f - ((o0 > 2.4f ? 1.f : 0.f) + (o0 < -2.4f ? 1.f : 0.f)) * 1.0f;
-        if (dp == 1) return -((o0 > th ? 1.f : 0.f) + (o0 < -th ? 1.f : 0.f)) * 1.0f;
-        return 0.0f;
-    } else {                                              // pendulum, classic_control.py:209-218
-        if (dp == 0) {
-            const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
-            const float theta = atan2f(o1, o0);
-            float m = fmodf(theta + PI_F, TWO_PI_F);
-            if (m != 0.0f && m < 0.0f) m += TWO_PI_F;     // floormod
-            const float tn = m - PI_F;
-            return -(tn * tn + 0.001f * ctrl);
-        }
-        if (dp == 1) return -(0.1f * (o0 * o0));
-        return 0.0f;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// fast scalar math for the per-row head (absolute error ~1e-7 on logvar, see DESIGN.md numerics)
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void sincos_cw(float x, float* sn, float* cs) {
-    const float k = rintf(x * 0.63661977236758134f);                       // x / (pi/2)
-    float r = fmaf(-k, 1.5707962513e+00f, x);                              // pi/2 split in three parts
-    r = fmaf(-k, 7.5497894159e-08f, r);
-    r = fmaf(-k, 5.3903029534e-15f, r);
-    const float z = r * r;                                                 // cephes sinf / cosf minimax on [-pi/4, pi/4]
-    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
-    ps = fmaf(ps, z, -1.6666654611e-1f);
-    ps = fmaf(ps * z, r, r);
-    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
-    pc = fmaf(pc, z, 4.166664568298827e-2f);
-    pc = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
-    const int q = (int)k;
-    const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
-    *sn = (q & 2) ? -s0 : s0;
-    *cs = ((q + 1) & 2) ? -c0 : c0;
-}
-
-__device__ __forceinline__ float softplus_fast(float x) {     // tf.nn.softplus thresholds (+-13.94)
-    const float ex = __expf(fminf(x, 20.0f));
-    const float mid = __builtin_amdgcn_logf(1.0f + ex) * 0.69314718055994531f;   // v_log_f32 is log2
-    const float lo = x < -13.942385f ? ex : mid;
-    return x > 13.942385f ? x : lo;
-}
 
 template <int ENV_, int C_, int HID_, int MT_>
 struct RC {
@@ -352,26 +244,6 @@ __device__ __forceinline__ void zero_acc(floatx4 (&a)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) a[i] = floatx4{0.f, 0.f, 0.f, 0.f};
 }
-
-template <int R0, int R1>
-__device__ __forceinline__ void philox_rounds(uint32_t (&c)[4], uint32_t (&k)[2]) {
-#pragma unroll
-    for (int r = R0; r < R1; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
-        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
-        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
-        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        const uint32_t n0 = hi1 ^ c[1] ^ k[0], n2 = hi0 ^ c[3] ^ k[1];
-        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
-        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
-    }
-}
-
-// NOISE: how the Gaussian head's eps is obtained -- compile-time so that no runtime branch (and no
-// merged-register s_waitcnt vmcnt(0)) lands inside the software-pipelined MFMA sweeps.
-#define CADM_NOISE_PHILOX 0   // drawn on device (production)
-#define CADM_NOISE_INJECT 1   // read from the caller's eps tensor (parity tests)
-#define CADM_NOISE_NONE 2     // deterministic model (dynamics.py:43): delta = denormalised mu
 
 template <class G, int NOISE>
 __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
@@ -813,11 +685,10 @@ int launch_noise(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipSt
         cadm_set_error("rollout: horizon %d needs %zu B of LDS (> 160 KiB)", a.H, lds);
         return CADM_EINVAL;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<G, NOISE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    const void* fn = reinterpret_cast<const void*>(&rollout_kernel<G, NOISE>);
+    if (!ctx->attr_done.count(fn)) {    // per ctx = per device (the attribute is a per-device property)
+        CADM_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->attr_done.insert(fn);
     }
     hipLaunchKernelGGL((rollout_kernel<G, NOISE>), dim3(args.wgs_per_member * ctx->E), dim3(256), lds, s, args);
     CADM_CHECK_HIP(hipGetLastError());
@@ -842,7 +713,7 @@ template <int ENV, int HID, int... CS>
 int dispatch_ctx_list(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) {
     int rc = CADM_EINVAL;
     bool hit = false;
-    ((ctx->C == CS ? (hit = true, rc = launch<RC<ENV, CS, HID, 1>>(ctx, a, rpm, s), 0) : 0), ...);
+    ((ctx->C == CS ? (hit = true, rc = ctx->use_xdl ? xdl_launch<XC<ENV, CS, HID>>(ctx, a, rpm, s) : launch<RC<ENV, CS, HID, 1>>(ctx, a, rpm, s), 0) : 0), ...);
     if (!hit) cadm_set_error("rollout: context_out_dim %d not compiled in (built with CTXS = " CADM_STR(CADM_CTX_LIST) ")", ctx->C);
     return rc;
 }

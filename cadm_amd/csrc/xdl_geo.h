@@ -1,0 +1,57 @@
+// Geometry of the split-f16 ("xdl") rollout weight stream, shared by the packer (host + pack kernel) and the
+// rollout kernel so that the two can never disagree.  See DESIGN.md "rollout kernel".
+//
+//   * A dense layer is evaluated transposed (OUT^T = W^T * IN^T) with v_mfma_f32_16x16x32_f16: the weights are
+//     the A operand (16 output units x 32 input features), 16 data rows are the B / D columns.
+//   * fp32 accuracy on the f16 matrix pipe: every fp32 value v is split as  v = v1 + 2^-11 * v2,
+//     v1 = f16_rn(v), v2 = f16_rn((v - v1) * 2^11)  (the 2^11 keeps the low part a NORMAL f16 number), and a
+//     product  w * x  is evaluated as  w1*x1  (accumulator HI)  +  2^-11 * (w2*x1 + w1*x2)  (accumulator LO);
+//     the dropped term w2*x2 is <= 2^-22 |w x|.  3 MFMAs at 16x the fp32-MFMA rate instead of 8.
+//   * An output tile is 16 units; the K dimension of the layers that consume a hidden layer is cut in chunks of
+//     32 = one PAIR of producer tiles, so a lane's D fragments (units 4g..4g+3 of tiles 2c, 2c+1) ARE its B fragment
+//     for chunk c: activations cross layers through LDS without any cross-lane movement.
+//   * Hidden tiles are distributed over the 4 waves contiguously (wave w: BASE + (w < EXTRA) tiles); head tiles
+//     (8 obs dims: mu0 mu1 lv0 lv1 per lane) go to the waves with the fewest hidden tiles first.
+//   * A "fragment" = one (tile, chunk) of weights = 2 split parts x 64 lanes x 16 B = 2 KB.  Per (member, wave) the
+//     stream stores the fragments in EXACTLY the order that wave consumes them during one rollout step:
+//     [layer 0][hidden 1 .. NH-1][head]; inside a layer tiles go in groups of two, chunk-major inside a group
+//     (xdl_frag_index), so the kernel addresses the stream linearly.
+#pragma once
+
+#define CADM_XDL_FRAG_BYTES 2048
+
+struct XdlGeo {
+    int K0, HID, D, NH;
+    int NC0, NT, NCH, NTO, BASE, EXTRA, NTOW;
+    __host__ __device__ int ntw(int w) const { return BASE + (w < EXTRA ? 1 : 0); }
+    __host__ __device__ int tstart(int w) const { return w * BASE + (w < EXTRA ? w : EXTRA); }
+    __host__ __device__ int head_tile(int w, int s) const { return (3 - w) + 4 * s; }          // slot s of wave w (valid if < NTO)
+    __host__ __device__ int nhead(int w) const {
+        int n = 0;
+        for (int s = 0; s < NTOW; ++s) n += head_tile(w, s) < NTO ? 1 : 0;
+        return n;
+    }
+    __host__ __device__ int wave_frags(int w) const { return ntw(w) * NC0 + (NH - 1) * ntw(w) * NCH + nhead(w) * NCH; }
+    __host__ __device__ int member_frags() const { return wave_frags(0) + wave_frags(1) + wave_frags(2) + wave_frags(3); }
+    __host__ __device__ int bias_tiles() const { return NH * NT + NTO; }
+};
+
+inline XdlGeo make_xdl_geo(int K0, int HID, int D, int NH) {
+    XdlGeo g;
+    g.K0 = K0; g.HID = HID; g.D = D; g.NH = NH;
+    g.NC0 = (K0 + 31) / 32;
+    g.NT = (HID + 15) / 16;
+    g.NCH = (g.NT + 1) / 2;
+    g.NTO = (D + 7) / 8;
+    g.BASE = g.NT / 4;
+    g.EXTRA = g.NT % 4;
+    g.NTOW = (g.NTO + 3) / 4;
+    return g;
+}
+
+// position of fragment (local tile ti, chunk c) in a layer's consumption order, for a wave with ntw tiles
+__host__ __device__ constexpr int xdl_frag_index(int ntw, int nchl, int ti, int c) {
+    const int g = ti / 2;
+    const int gs = (ntw - 2 * g) < 2 ? (ntw - 2 * g) : 2;
+    return 2 * g * nchl + c * gs + (ti - 2 * g);
+}

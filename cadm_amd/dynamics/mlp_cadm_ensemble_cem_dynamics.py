@@ -13,7 +13,8 @@ Differences a caller can see (all opt-in except the first):
     its class selects the compiled-in closures (cadm_amd/envs.py);
   * extra kwargs: `reference_quirks` (default True: reproduce the context-layout quirks Q1/Q2
     of core/utils.py:434-435), `seed` (device Philox key; the reference never seeds TF),
-    `device`, `process_group` (shard candidates over the ranks of a torch.distributed group);
+    `device`, `process_group` (OPT-IN: shard candidates over the ranks of that torch.distributed group; every
+    rank must then call get_action with the same observations -- None, the default, never shards);
   * `predict(obs, act, cp_obs, cp_act)` -- thin alias the north-star asks for: one-step mean
     prediction of every ensemble member (the reference has no public predict).
 """
@@ -139,12 +140,49 @@ class MLPEnsembleCEMDynamicsModel(object):
         if self._stats_dirty:
             keys = ("obs_mean", "obs_std", "act_mean", "act_std", "delta_mean", "delta_std", "cp_obs_mean",
                     "cp_obs_std", "cp_act_mean", "cp_act_std", "back_delta_mean", "back_delta_std")
-            self.engine.set_stats(dict(zip(keys, self.get_normalization_stats())))
+            self.engine.set_stats(dict(zip(keys, self._stats12())))
             self._stats_dirty = False
 
     def _next_call(self):
         self._call += 1
         return self._call & 0xFFFFFFFF
+
+    def _check_planner_inputs(self, obs, cp_obs, cp_act, cem_init_mean, cem_init_var):
+        """Host-side shape checks (the reference would raise a TF shape error; raw device pointers would not)."""
+        D, A, Hh, H = self.obs_space_dims, self.action_space_dims, self.history_length, self.n_forwards
+        shp = lambda x: tuple(int(v) for v in x.shape)
+        m = shp(obs)[0]
+        want = {"obs": (obs, (m, D)), "cem_init_mean": (cem_init_mean, (m, H, A)), "cem_init_var": (cem_init_var, (m, H, A))}
+        if self.context_out_dim > 0:
+            want["cp_obs"] = (cp_obs, (m, D * Hh))
+            want["cp_act"] = (cp_act, (m, A * Hh))
+            if cp_obs is None or cp_act is None:
+                raise ValueError("get_action: cp_obs and cp_act are required for a context model")
+        for name, (x, expect) in want.items():
+            if x is not None and shp(x) != expect:
+                raise ValueError("get_action: %s has shape %r, expected %r" % (name, shp(x), expect))
+        if (cem_init_mean is None) != (cem_init_var is None):
+            raise ValueError("get_action: cem_init_mean and cem_init_var must be given together")
+
+    def _sharding(self):
+        """Candidate shard of this rank + whether the in-library RCCL path is usable on EVERY rank of the group."""
+        shard = _planner.Shard.from_group(self.n_candidates, self._group)
+        if shard.world > 1 and self.engine.dist_world == 1 and not self._dist_failed:
+            import torch.distributed as dist
+            ok = 1.0
+            try:       # in-library RCCL communicator: the whole sharded planner stays on the stream
+                self.engine.dist_init(self._group)
+            except Exception as exc:
+                ok = 0.0
+                logger.log("cadm_amd: in-library RCCL init failed on this rank (%s)" % exc)
+            # every rank must take the SAME path, or some would wait in ncclAllGather and others in torch's collective
+            flag = torch.tensor([ok], device=self.engine.device if dist.get_backend(self._group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._group)
+            if float(flag.item()) < 1.0:
+                self._dist_failed = True
+                self.engine.dist_destroy()
+                logger.log("cadm_amd: a rank failed in-library RCCL init; all ranks use torch.distributed all_gather")
+        return shard, (shard.world == 1 or self.engine.dist_world == shard.world)
 
     def get_action(self, obs, cp_obs, cp_act, cem_init_mean=None, cem_init_var=None):
         """reference :344-367.  CEM: returns the whole plan [m,H,A]; RS: the first action [m,A]
@@ -155,17 +193,13 @@ class MLPEnsembleCEMDynamicsModel(object):
             if cem_init_mean is not None:
                 return np.zeros((0, self.n_forwards, self.action_space_dims), np.float32)
             return np.zeros((0,), np.int32) if self.discrete else np.zeros((0, self.action_space_dims), np.float32)
+        self._check_planner_inputs(obs, cp_obs, cp_act, cem_init_mean, cem_init_var)
         call = self._next_call()
-        shard = _planner.Shard.from_dist(self.n_candidates, self._group)
-        if shard.world > 1 and self.engine.dist_world == 1 and not self._dist_failed:
-            try:       # in-library RCCL communicator: the whole sharded planner stays on the stream
-                self.engine.dist_init(self._group)
-            except Exception as exc:   # fall back to torch.distributed collectives between the kernel calls
-                self._dist_failed = True
-                logger.log("cadm_amd: in-library RCCL init failed (%s); using torch.distributed all_gather" % exc)
-        fused = shard.world == 1 or self.engine.dist_world == shard.world
+        shard, fused = self._sharding()
         if not any(isinstance(x, torch.Tensor) for x in (obs, cp_obs, cp_act, cem_init_mean, cem_init_var)):
             obs, cp_obs, cp_act, cem_init_mean, cem_init_var = self.engine.stage((obs, cp_obs, cp_act, cem_init_mean, cem_init_var))
+        if shard.world > 1:
+            _planner.check_replicated([self.engine._t(x) for x in (obs, cp_obs, cp_act, cem_init_mean) if x is not None], shard)
         if cem_init_mean is not None:
             if fused:
                 action = self.engine.cem_plan(obs, cp_obs, cp_act, cem_init_mean, cem_init_var, self.n_candidates,
@@ -197,7 +231,7 @@ class MLPEnsembleCEMDynamicsModel(object):
         E = self.ensemble_size
         tile = lambda x: None if x is None else np.tile(np.asarray(x, dtype=np.float32)[None], (E, 1, 1))
         mu, lv = self.engine.predict_heads(tile(obs), tile(act), tile(cp_obs), tile(cp_act))
-        stats = self.get_normalization_stats()
+        stats = self._stats12()
         dmean, dstd = np.asarray(stats[4], np.float32), np.asarray(stats[5], np.float32)
         delta = mu.cpu().numpy() * (dstd + 1e-10) + dmean
         nxt = self.env.obs_postproc(np.broadcast_to(np.asarray(obs, np.float32)[None], delta.shape), delta)
@@ -396,6 +430,10 @@ class MLPEnsembleCEMDynamicsModel(object):
 
     def get_normalization_stats(self):
         """reference :604-645."""
+        return self._stats12()
+
+    def _stats12(self):
+        """The 12 statistic vectors in STAT_KEYS order (what the engine consumes)."""
         D, A, P, Hh = self.obs_space_dims, self.action_space_dims, self.proc_obs_space_dims, self.history_length
         if self.normalize_input:
             if self.normalization is None:
@@ -404,9 +442,11 @@ class MLPEnsembleCEMDynamicsModel(object):
             om, os_ = nz["obs"]
             dm, ds = nz["delta"]
             am, as_ = (np.zeros((A,)), np.ones((A,))) if self.discrete else nz["act"]
-            com, cos = (np.zeros((D * Hh,)), np.ones((D * Hh,))) if self.state_diff else nz["cp_obs"]
-            cam, cas = (np.zeros((A * Hh,)), np.ones((A * Hh,))) if self.discrete else nz["cp_act"]
-            bm, bs = nz["back_delta"]
+            # the reference's VANILLA model saves only obs / delta / act (mlp_ensemble_cem_dynamics.py:343-351): a model
+            # without history window / backward net never reads the other three, so they default to (0, 1)
+            com, cos = (np.zeros((D * Hh,)), np.ones((D * Hh,))) if (self.state_diff or "cp_obs" not in nz) else nz["cp_obs"]
+            cam, cas = (np.zeros((A * Hh,)), np.ones((A * Hh,))) if (self.discrete or "cp_act" not in nz) else nz["cp_act"]
+            bm, bs = nz["back_delta"] if "back_delta" in nz else (np.zeros((D,)), np.ones((D,)))
         else:
             om, os_ = np.zeros((P,)), np.ones((P,))
             am, as_ = np.zeros((A,)), np.ones((A,))

@@ -5,6 +5,8 @@ Same constructor kwargs (:25-45) and methods: get_action(obs, cem_init_mean, cem
 (:191-207), fit(obs, act, obs_next, ...) (:209-323), save/load (:325-341).  Shares the HIP
 path of the CaDM model with context_dim = 0 and no backward model.
 """
+from collections import OrderedDict
+
 import numpy as np
 
 from .mlp_cadm_ensemble_cem_dynamics import MLPEnsembleCEMDynamicsModel as _CaDMModel
@@ -35,6 +37,22 @@ class MLPEnsembleCEMDynamicsModel(_CaDMModel):
 
     def get_context_pred(self, *a, **k):
         raise AttributeError("the vanilla model has no context encoder")
+
+    def compute_normalization(self, obs, act, delta, *unused):
+        """reference :343-351: the vanilla model keeps obs / delta / act statistics only.  (The extra positional
+        arguments are what the shared `fit` passes for the CaDM model; a vanilla model has no history / backward net.)"""
+        assert obs.shape[0] == delta.shape[0] == act.shape[0]
+        proc_obs = self.env.obs_preproc(obs)
+        n = OrderedDict()
+        n["obs"] = (np.mean(proc_obs, axis=0), np.std(proc_obs, axis=0))
+        n["delta"] = (np.mean(delta, axis=0), np.std(delta, axis=0))
+        n["act"] = (np.mean(act, axis=0), np.std(act, axis=0))
+        self.normalization = n
+        self._stats_dirty = True
+
+    def get_normalization_stats(self):
+        """reference :353-373: (obs_mean, obs_std, act_mean, act_std, delta_mean, delta_std)."""
+        return self._stats12()[:6]
 
     def fit(self, obs, act, obs_next, epochs=1000, compute_normalization=True, valid_split_ratio=None,
             rolling_average_persitency=None, verbose=False, log_tabular=False, max_logging=5000, rng=None):

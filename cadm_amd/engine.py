@@ -399,6 +399,16 @@ class HipEngine:
             check(self.lib.cadm_dist_init(self._ctx, ident, world, rank), "cadm_dist_init")
         self.dist_world, self.dist_rank = world, rank
 
+    def dist_destroy(self):
+        check(self.lib.cadm_dist_destroy(self._ctx), "cadm_dist_destroy")
+        self.dist_world, self.dist_rank = 1, 0
+
+    def dist_info(self):
+        """(nranks, rank) as RCCL itself reports them for the ctx's communicator (ncclCommCount / ncclCommUserRank)."""
+        n, r = ct.c_int(0), ct.c_int(0)
+        check(self.lib.cadm_dist_info(self._ctx, ct.byref(n), ct.byref(r)), "cadm_dist_info")
+        return int(n.value), int(r.value)
+
     # ------------------------------------------------------------------ in-library kernel timing
     def profile_enable(self, on=True):
         check(self.lib.cadm_profile_enable(self._ctx, int(on)), "cadm_profile_enable")

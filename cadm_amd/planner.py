@@ -27,11 +27,30 @@ class Shard:
         self.offset = rank * self.n_local
 
     @staticmethod
-    def from_dist(n, group=None):
+    def from_group(n, group):
+        """Shard over the ranks of an EXPLICIT torch.distributed group.  Sharding is opt-in: a process that merely has
+        torch.distributed initialised (parallel samplers planning for different observations, say) must not have its
+        candidates mixed with other ranks'.  Every rank of `group` must call the planner with identical observations,
+        weights and statistics (replicated state; checked by `check_replicated`)."""
+        if group is None:
+            return Shard(n)
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
-            return Shard(n, dist.get_rank(group), dist.get_world_size(group), group)
-        return Shard(n)
+        return Shard(n, dist.get_rank(group), dist.get_world_size(group), group)
+
+
+def check_replicated(tensors, shard):
+    """Cheap guard for sharded planning: the per-rank checksum of the replicated inputs must agree across ranks
+    (one tiny MIN/MAX all-reduce); raises instead of silently ranking candidates rolled out from different states."""
+    if shard.world == 1:
+        return
+    import torch.distributed as dist
+    s = torch.stack([t.double().sum() for t in tensors if t is not None])
+    lo, hi = s.clone(), s.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=shard.group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=shard.group)
+    if not torch.equal(lo, hi):
+        raise RuntimeError("candidate-sharded planning needs identical obs / history / warm start on every rank of the "
+                           "group (checksums differ: %s vs %s)" % (lo.tolist(), hi.tolist()))
 
 
 def gather_cand_returns(cand_local, shard):

@@ -22,37 +22,31 @@ class MPCController(object):
     def vectorized(self):
         return True
 
-    def get_action(self, observation, init_mean=None, init_var=None):      # reference :43-53
-        if observation.ndim == 1:
-            observation = observation[None]
+    def _plan(self, observations, cp=None, init=None):
+        """The one dispatch point: history (cp_obs, cp_act) goes to the model only for a context model, the CEM warm
+        start (mean, var) only when planning with CEM; random shooting takes neither."""
+        args = [observations]
+        if self.context:
+            args += list(cp if cp is not None else (None, None))
         if self.use_cem:
-            action = self.get_cem_gpu_action(observation, init_mean, init_var)
-        else:
-            action = self.get_rs_gpu_action(observation)
-        return action, dict()
+            args += list(init if init is not None else (None, None))
+        return self.dynamics_model.get_action(*args)
 
-    def get_actions(self, observations, cp_obs=None, cp_act=None, init_mean=None, init_var=None):  # :55-69
-        if self.context:
-            if self.use_cem:
-                actions = self.get_cem_gpu_action(observations, init_mean, init_var, cp_obs, cp_act)
-            else:
-                actions = self.get_rs_gpu_action(observations, cp_obs, cp_act)
-        else:
-            if self.use_cem:
-                actions = self.get_cem_gpu_action(observations, init_mean, init_var)
-            else:
-                actions = self.get_rs_gpu_action(observations)
-        return actions, dict()
+    # ---- the reference's entry points (mpc_controller.py:43-90), all thin views of _plan ----
+    def get_action(self, observation, init_mean=None, init_var=None):
+        observation = observation[None] if observation.ndim == 1 else observation
+        return self._plan(observation, None, (init_mean, init_var)), dict()
 
-    def get_rs_gpu_action(self, observations, cp_obs=None, cp_act=None):   # :78-83
-        if self.context:
-            return self.dynamics_model.get_action(observations, cp_obs, cp_act)
-        return self.dynamics_model.get_action(observations)
+    def get_actions(self, observations, cp_obs=None, cp_act=None, init_mean=None, init_var=None):
+        return self._plan(observations, (cp_obs, cp_act), (init_mean, init_var)), dict()
 
-    def get_cem_gpu_action(self, observations, init_mean, init_var, cp_obs=None, cp_act=None):  # :85-90
-        if self.context:
-            return self.dynamics_model.get_action(observations, cp_obs, cp_act, init_mean, init_var)
-        return self.dynamics_model.get_action(observations, init_mean, init_var)
+    def get_rs_gpu_action(self, observations, cp_obs=None, cp_act=None):
+        assert not self.use_cem
+        return self._plan(observations, (cp_obs, cp_act))
+
+    def get_cem_gpu_action(self, observations, init_mean, init_var, cp_obs=None, cp_act=None):
+        assert self.use_cem
+        return self._plan(observations, (cp_obs, cp_act), (init_mean, init_var))
 
 
 class CEMWarmStart(object):

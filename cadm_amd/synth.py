@@ -6,7 +6,7 @@ reference initialiser trunc_normal(sigma = 1/(2 sqrt(in))), bias 0
 (:338-339); norm stats mu ~ N(0,1), sigma ~ U(0.5,2); obs ~ N(0,1);
 cp_obs ~ 0.1 N(0,1); cp_act ~ U(-1,1); CEM init mean 0, var 0.25
 (/root/reference/cadm/samplers/sampler.py:52-53).
-numpy only -- used by bench.py, __graft_entry__.smoke() and tests.
+numpy only (make_engine imports the HIP engine lazily) -- used by bench.py, __graft_entry__.smoke(), tools/ and tests.
 """
 from collections import OrderedDict
 
@@ -127,3 +127,19 @@ def make_train_batch(prob, B=256, seed=1):
     b["cp_obs"] = 0.1 * rng.standard_normal((E, B, D * Hh))
     b["cp_act"] = rng.uniform(-1, 1, (E, B, A * Hh))
     return b
+
+
+def make_engine(prob, p, H=None, deterministic=False, quirks=True, device=None, **kw):
+    """HipEngine loaded with a synthetic problem's weights and statistics (product code: no oracle involved)."""
+    from .engine import HipEngine
+    eng = HipEngine(prob["env"], prob["E"], p, prob["D"], prob["A"], prob["P"], prob["C"], prob["hidden_sizes"],
+                    prob["H"] if H is None else H, deterministic=deterministic, discrete=prob["discrete"],
+                    reference_quirks=quirks, history_length=prob["Hh"], cp_hidden_sizes=prob["cp_hidden_sizes"],
+                    back_model=prob.get("back") is not None, device=device, **kw)
+    if prob["cp"] is not None:
+        eng.set_net("context_model", prob["cp"])
+    eng.set_net("ff_model", prob["ff"])
+    if prob.get("back") is not None:
+        eng.set_net("backward_model", prob["back"])
+    eng.set_stats(prob["stats"])
+    return eng

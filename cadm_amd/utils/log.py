@@ -1,26 +1,32 @@
-"""Minimal stand-in for the reference's logger calls made from the hot path
-(/root/reference/cadm/logger/logger.py `log` / `logkv`; the logger itself is out of scope,
-SURVEY.md section 2 row 10).  If the reference package is importable its logger is used."""
+"""Logger seam of the hot path: `log(msg)` / `logkv(key, val)` as the reference's `cadm.logger.logger` offers them
+(/root/reference/cadm/logger/logger.py; the logger itself is out of scope).
+
+The product never imports the reference package.  A caller that runs inside the reference tree hands ITS logger over
+once (`set_logger(cadm.logger.logger)`); without one, messages go to stderr and key/values are kept in a
+dict (`getkvs()`).
+"""
 import sys
 
 _kv = {}
+_sink = None
 
-try:  # drop-in inside the reference tree
-    from cadm.logger import logger as _ref_logger  # type: ignore
-except Exception:  # pragma: no cover - the reference is not importable in this image
-    _ref_logger = None
+
+def set_logger(logger):
+    """Inject an object with `log(msg)` and `logkv(key, val)` (None restores the default)."""
+    global _sink
+    _sink = logger
 
 
 def log(msg):
-    if _ref_logger is not None:
-        _ref_logger.log(msg)
+    if _sink is not None:
+        _sink.log(msg)
     else:
         print(msg, file=sys.stderr)
 
 
 def logkv(key, val):
-    if _ref_logger is not None:
-        _ref_logger.logkv(key, val)
+    if _sink is not None:
+        _sink.logkv(key, val)
     else:
         _kv[key] = val
 

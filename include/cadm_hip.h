@@ -232,6 +232,8 @@ int cadm_history_update(cadm_ctx* ctx, const float* obs, const float* next_obs, 
 int cadm_dist_unique_id(char out_id[128]);
 int cadm_dist_init(cadm_ctx* ctx, const char id[128], int nranks, int rank);
 int cadm_dist_destroy(cadm_ctx* ctx);
+/* (nranks, rank) as RCCL reports them for the ctx's communicator (ncclCommCount / ncclCommUserRank); (1, 0) without one. */
+int cadm_dist_info(cadm_ctx* ctx, int* nranks_out, int* rank_out);
 
 /* In-library timing of the dominant kernel (the rollout): when enabled, every
  * cadm_rollout_returns launch is bracketed by hipEvents on the launch stream.

@@ -18,19 +18,7 @@ def oracle_problem(prob, dtype):
     return o
 
 
-def make_engine(prob, p, H=None, deterministic=False, quirks=True, device=None, **kw):
-    from cadm_amd.engine import HipEngine
-    eng = HipEngine(prob["env"], prob["E"], p, prob["D"], prob["A"], prob["P"], prob["C"], prob["hidden_sizes"],
-                    prob["H"] if H is None else H, deterministic=deterministic, discrete=prob["discrete"],
-                    reference_quirks=quirks, history_length=prob["Hh"], cp_hidden_sizes=prob["cp_hidden_sizes"],
-                    back_model=prob.get("back") is not None, device=device, **kw)
-    if prob["cp"] is not None:
-        eng.set_net("context_model", prob["cp"])
-    eng.set_net("ff_model", prob["ff"])
-    if prob.get("back") is not None:
-        eng.set_net("backward_model", prob["back"])
-    eng.set_stats(prob["stats"])
-    return eng
+make_engine = synth.make_engine   # product code (cadm_amd/synth.py); re-exported for the tests
 
 
 def trunc_z(rng, shape):

@@ -36,7 +36,7 @@ def _worker(rank, world, port, out_dir):
     E, p, m, n, H = 5, 5, 2, 64, 4
     prob = synth.make_problem(env="halfcheetah", E=E, m=m, H=H, seed=7)
     eng = OracleEngine(oracle_problem(prob, np.float32), prob, p, H, num_elites=16)
-    shard = hplanner.Shard.from_dist(n)
+    shard = hplanner.Shard.from_group(n, dist.group.WORLD)
     assert (shard.world, shard.rank, shard.n_local, shard.offset) == (world, rank, n // world, rank * (n // world))
     plan = hplanner.cem_plan(eng, prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], n,
                              seed=11, call=3, shard=shard)

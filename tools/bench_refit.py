@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from cadm_amd import synth
-from helpers import make_engine
+from cadm_amd.synth import make_engine
 
 prob = synth.make_problem(env="halfcheetah", context=True, E=5, seed=0)
 eng = make_engine(prob, p=20)

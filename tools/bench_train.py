@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from cadm_amd import synth
-from helpers import make_engine
+from cadm_amd.synth import make_engine
 
 WD = (0.000025, 0.00005, 0.000075, 0.000075, 0.0001)
 CWD = (0.000025, 0.00005, 0.000075)

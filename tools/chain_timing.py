@@ -12,7 +12,7 @@ import torch
 
 from cadm_amd import synth
 from cadm_amd._lib import check
-from helpers import make_engine
+from cadm_amd.synth import make_engine
 
 
 def main():

@@ -14,7 +14,7 @@ import torch
 
 from cadm_amd import synth
 from cadm_amd._lib import check
-from helpers import make_engine
+from cadm_amd.synth import make_engine
 
 NAMES = ["assembly", "bar0", "L0 mfma", "L0 epi", "bar1", "hid rebuild", "hid mfma", "hid epi", "hid bar",
          "out noise", "out rebuild", "out mfma", "out part wr", "bar5", "head epi", "bar6"]

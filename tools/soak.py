@@ -4,7 +4,7 @@ import sys, os, time
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, torch
 from cadm_amd import synth
-from helpers import make_engine
+from cadm_amd.synth import make_engine
 t_end = time.time() + float(sys.argv[1]) if len(sys.argv) > 1 else time.time() + 30
 prob = synth.make_problem(env="halfcheetah", context=True, E=5, m=1, H=30, trained_like=True, with_back=True, seed=3)
 engA, engB = make_engine(prob, p=20), make_engine(prob, p=20)
