@@ -5,6 +5,17 @@
 
 #include "common.h"
 
+#ifdef CADM_PHASE_TIMING
+#define NPH 24
+#define TS_DECL unsigned long long ts_acc[NPH] = {}; unsigned long long ts_last = __builtin_amdgcn_s_memtime();
+#define TS(i) { const unsigned long long ts_now = __builtin_amdgcn_s_memtime(); ts_acc[i] += ts_now - ts_last; ts_last = ts_now; }
+#define TS_DUMP if (a.tbuf && blockIdx.x == 0 && lane == 0) { for (int i = 0; i < NPH; ++i) a.tbuf[wave * NPH + i] = ts_acc[i]; }
+#else
+#define TS_DECL
+#define TS(i)
+#define TS_DUMP
+#endif
+
 namespace {
 
 typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));

@@ -29,7 +29,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 #ifndef CADM_XDL_RING
-#define CADM_XDL_RING 8
+#define CADM_XDL_RING 4
 #endif
 
 template <int ENV_, int C_, int HID_>
@@ -44,6 +44,9 @@ struct XC {
     static constexpr int BASE = NT / 4, EXTRA = NT % 4;
     static constexpr int NTOW = (NTO + 3) / 4;            // head tile slots per wave
     static constexpr int R = CADM_XDL_RING;               // ring depth (fragments)
+    // products per 16x16x32 block: hi += w1 x1, lo += w2 x1 + w1 x2 [, ll += w2 x2].  The dropped w2 x2 term is 2^-22 of a
+    // product; wide layers (K > 256) accumulate enough of them to show at the 1e-5 parity bar, so they take the 4th product.
+    static constexpr int NPROD = HID > 256 ? 4 : 3;
     static constexpr int NP = (D + 1) / 2, NPI = (NP + 15) / 16, NAI = (A + 15) / 16;
     static_assert(BASE >= 1, "hidden width too small for the 4-wave tile split");
     // LDS carve (bytes)
@@ -53,7 +56,34 @@ struct XC {
     static constexpr int OFULL = ACTB + 2 * NCH * 1024;            // [NTO][64] x float4
     static constexpr int STATS = OFULL + NTO * 1024;               // floats
     static constexpr int ST_OBS_MEAN = 0, ST_OBS_DEN = P, ST_ACT_MEAN = 2 * P, ST_ACT_DEN = 2 * P + A;
-    static constexpr int CTRL = STATS + rup((2 * P + 2 * A) * 4, 16);   // + 16 * H floats (dynamic)
+    // per feature-slot constants (head statistics, derived-feature slots): read from LDS in every state phase instead of
+    // being held in ~26 registers across the MFMA sweeps
+    static constexpr int TABW = 28;                                     // floats per (pair slot, fg) entry
+    static constexpr int TAB = STATS + rup((2 * P + 2 * A) * 4, 16);
+    static constexpr int CTRL = TAB + NPI * 16 * TABW * 4;              // + 16 * H floats (dynamic)
+    // Bias tiles (fp32, D layout) live in LDS when they fit next to the rest (a bias read from global memory in a tile's
+    // epilogue would sit BEHIND the ring's weight loads in the in-order vmcnt queue and drain the whole ring);
+    // otherwise they are fetched at the start of a sweep, ahead of that sweep's ring loads.
+#ifndef CADM_XDL_RES
+#define CADM_XDL_RES 1
+#endif
+    // register-resident weights (loaded once per workgroup, never re-read from L2): hidden layer 1 on every wave and
+    // the head tiles on the waves that own BASE hidden tiles -- ~224 of a wave's 512 registers at HID = 200.
+    // AGPR budget: 256 = resident fragments (8 each) + the ring (the compiler keeps it in AGPRs) + what hipcc parks
+    // there itself; RES_FRAGS leaves room for those (tests/test_abi.py checks the ISA for AGPR<->VGPR shuffles of
+    // resident fragments, which would also be an undetected MFMA operand hazard).
+#ifndef CADM_XDL_RES_FRAGS
+#define CADM_XDL_RES_FRAGS 28       // waves with BASE hidden tiles
+#endif
+#ifndef CADM_XDL_RES_FRAGS_X
+#define CADM_XDL_RES_FRAGS_X 24     // waves with BASE + 1 hidden tiles (more accumulators / epilogue state live)
+#endif
+    // (wide layers keep their whole B operand, 16 * NCH registers, live: no room for resident weights)
+    static constexpr bool ASM_MFMA = CADM_XDL_RES && NCH <= 8;     // asm MFMAs (AGPR-resident operands) vs builtins
+    static constexpr int res_frags(int ntw) { return (!CADM_XDL_RES || NCH > 8) ? 0 : ntw == BASE ? CADM_XDL_RES_FRAGS : CADM_XDL_RES_FRAGS_X; }
+    static constexpr int MAX_NH_LDS = 4;
+    static constexpr int BIAS_BYTES = (MAX_NH_LDS * NT + NTO) * 1024;
+    static constexpr bool BIAS_LDS = CTRL + 16 * 64 * 4 + BIAS_BYTES <= 150 * 1024;
 };
 
 template <class G>
@@ -71,70 +101,179 @@ __device__ __forceinline__ floatx4 xmfma(uintx4 a, f16x8 b, floatx4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), b, c, 0, 0, 0);
 }
 
+// Register-RESIDENT fragments live in AGPRs for the whole kernel.  hipcc treats an AGPR-held MFMA operand as a VGPR value
+// "spilled to AGPR" and reloads it (4 x v_accvgpr_read) before every use, so the resident path names the register class
+// itself: the load writes AGPRs ("=a") and the MFMA reads its A operand from them ("a").  The compiler sees neither the
+// load (the caller waits with an explicit vmcnt(0)) nor the MFMA's latency (callers keep the accumulator's first VALU
+// read a whole chunk of MFMAs away, or pad with xdl_result_nops).
+__device__ __forceinline__ void xres_load(uintx4& dst, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void xmfma_res(floatx4& acc, const uintx4& w, const f16x8& x) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+}
+// Streamed fragments (ring registers, VGPRs) go through the same asm form so that ALL MFMAs of a sweep keep their
+// accumulators in VGPRs: a mix of asm and builtin MFMAs makes hipcc shuttle accumulators between VGPRs and AGPRs
+// right behind an MFMA whose latency it cannot see.  (Loads feeding the asm are still tracked: hipcc places the
+// s_waitcnt for any register an asm statement reads.)
+// ASM = false (geometries without resident fragments): plain builtin, hipcc then handles every hazard itself.
+template <bool ASM>
+__device__ __forceinline__ void xmfma_ring(floatx4& acc, const uintx4& w, const f16x8& x) {
+    if constexpr (ASM) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+    else acc = xmfma(w, x, acc);
+}
+// Hazard padding the compiler cannot place for asm MFMAs.  The accumulators are "+v" operands of the padding statement,
+// so every instruction that defines them (the zeroing moves) stays before it and every reader (the epilogue) after it.
+__device__ __forceinline__ void xdl_result_nops(floatx4& a, floatx4& b, floatx4& c) {      // XDL write -> VALU read (4-pass op)
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c));
+}
+__device__ __forceinline__ void xdl_operand_nops(floatx4& a, floatx4& b, floatx4& c) {     // VALU write -> XDL read as srcC
+    asm volatile("s_nop 4" : "+v"(a), "+v"(b), "+v"(c));
+}
+
 // split an fp32 value for the f16 pipe: hi = f16(v), lo = f16((v - hi) * 2^11)
 __device__ __forceinline__ void xsplit(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
     lo = (_Float16)fmaf((float)hi, -2048.0f, v * 2048.0f);
 }
 
+// Epilogue of a hidden tile: bias, swish, f16 split, store as (half of) a B fragment of the next layer.  Cut in STAGES of
+// mutually independent instructions (stage s of every value before stage s+1 of any): a wave issues in order, so a VALU
+// op waiting for its predecessor's result (v_exp -> v_add -> v_rcp ..) would hold up the MFMAs queued behind it.
+template <class G>
+struct XHiddenEpi {
+    static constexpr int NSTAGE = 7;
+    struct State { floatx4 b, v, s; f16x4 h1, h2; };
+    unsigned char* xsmem;
+    const float* xb;
+    int bias_off;
+    int layer, out, tstart, lane;
+    template <int S>
+    __device__ __forceinline__ void stage(int ti, const floatx4& hi, const floatx4& lo, const floatx4& ll, State& st) const {
+        if constexpr (S == 0) {            // bias tile of this output tile
+            const int bt = (layer * G::NT + tstart + ti) * 64 + lane;
+            // (a select between an LDS and a global POINTER would become a flat load with a full vmcnt/lgkmcnt drain)
+            if constexpr (G::BIAS_LDS) st.b = *reinterpret_cast<const floatx4*>(xsmem + bias_off + bt * 16);
+            else st.b = *reinterpret_cast<const floatx4*>(xb + bt * 4);
+        } else if constexpr (S == 1) {     // pre-activation (hi + 2^-11 lo + bias), f16-range clamp, exp2 argument
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pre = fmaf(lo[r], 4.8828125e-4f, hi[r] + st.b[r]);
+                if constexpr (G::NPROD == 4) pre = fmaf(ll[r], 2.384185791015625e-7f, pre);
+                st.v[r] = fminf(pre, 60000.0f);
+                st.s[r] = st.v[r] * -1.4426950408889634f;
+            }
+        } else if constexpr (S == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st.s[r] = __builtin_amdgcn_exp2f(st.s[r]);
+        } else if constexpr (S == 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st.s[r] = __builtin_amdgcn_rcpf(1.0f + st.s[r]);
+        } else if constexpr (S == 4) {     // swish (dynamics.py:23) and the high f16 part
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st.v[r] = st.v[r] * st.s[r]; st.h1[r] = (_Float16)st.v[r]; }
+        } else if constexpr (S == 5) {     // low part: (h - hi) * 2^11, exact in fp32
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st.h2[r] = (_Float16)fmaf((float)st.h1[r], -2048.0f, st.v[r] * 2048.0f);
+        } else {
+            const int Tg = tstart + ti;
+            unsigned char* dst = xsmem + out + ((Tg >> 1) * 64 + lane) * 16 + (Tg & 1) * 8;
+            *reinterpret_cast<f16x4*>(dst) = st.h1;
+            *reinterpret_cast<f16x4*>(dst + G::NCH * 1024) = st.h2;
+        }
+    }
+};
+
 // One hidden-type layer sweep of this wave: NTW tiles x NCHL chunks, tiles two at a time.
-//   ring holds fragments 0..R-1 of this layer on entry and 0..R-1 of the NEXT layer (nx_nf of them exist) on exit.
-//   epi(ti, hi, lo) consumes a finished tile.
-template <class G, int NTW, int NCHL, class Epi>
-__device__ __forceinline__ void xdl_sweep(XRing<G>& ring, __amdgpu_buffer_rsrc_t rsrc, unsigned wcur, unsigned wnext,
-                                          int nx_nf, const unsigned char* lds_in, int lane, Epi&& epi) {
-    constexpr int R = G::R, NF = NTW * NCHL, NFPAD = rup(NF, R);
+//   The first NRES fragments (consumption order) are register-resident (res[j][part], AGPRs, loaded once per workgroup);
+//   the other NFS = NF - NRES come through the ring: it holds streamed fragments 0..R-1 of this layer on entry and 0..R-1
+//   of the NEXT streamed layer (nx_nf of them exist) on exit.  wcur = byte offset of this layer's first STREAMED fragment.
+//   The epilogue of a tile group runs stage by stage between the MFMAs of the NEXT group (f16 MFMAs hide independent
+//   VALU work of the same wave); only the last group's epilogue is exposed.
+template <class G, int NTW, int NCHL, int NRES, class Epi>
+__device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2], __amdgpu_buffer_rsrc_t rsrc, unsigned wcur,
+                                          unsigned wnext, int nx_nf, const unsigned char* lds_in, int lane, const Epi& epi) {
+    constexpr int R = G::R, NF = NTW * NCHL, NFS = NF - NRES, NFSPAD = rup(NFS, R);
+    static_assert(NRES >= 0 && NRES <= NF, "bad resident fragment count");
     f16x8 X1[NCHL], X2[NCHL];
 #pragma unroll
     for (int c = 0; c < NCHL; ++c) {
         X1[c] = *reinterpret_cast<const f16x8*>(lds_in + ((0 * NCHL + c) * 64 + lane) * 16);
         X2[c] = *reinterpret_cast<const f16x8*>(lds_in + ((1 * NCHL + c) * 64 + lane) * 16);
     }
-    auto prefetch = [&](auto jc) {      // after time slot j: refill its ring slot
-        constexpr int j = decltype(jc)::value;
-        constexpr int jj = j + R;
-        if constexpr (jj < NF) {
-            xring_load<j % R>(ring, rsrc, wcur + jj * CADM_XDL_FRAG_BYTES, lane);
-        } else if constexpr (jj >= NFPAD) {
-            if (jj - NFPAD < nx_nf) xring_load<j % R>(ring, rsrc, wnext + (jj - NFPAD) * CADM_XDL_FRAG_BYTES, lane);
+    auto prefetch = [&](auto jsc) {      // after streamed time slot js: refill its ring slot
+        constexpr int js = decltype(jsc)::value;
+        constexpr int jj = js + R;
+        if constexpr (jj < NFS) {
+            xring_load<js % R>(ring, rsrc, wcur + jj * CADM_XDL_FRAG_BYTES, lane);
+        } else if constexpr (jj >= NFSPAD) {
+            if (jj - NFSPAD < nx_nf) xring_load<js % R>(ring, rsrc, wnext + (jj - NFSPAD) * CADM_XDL_FRAG_BYTES, lane);
         }
     };
-    constexpr int NG = (NTW + 1) / 2;
+    constexpr int NG = (NTW + 1) / 2, NST = Epi::NSTAGE;
+    constexpr int NPR = G::NPROD;
+    floatx4 hi[2][2], lo[2][2], ll[2][2];   // [group parity][tile of the group]: the previous group's pair is being finished
+    typename Epi::State pst[2];             // as side work while this group's accumulates (no register moves in between)
+    // stage s of the side epilogue goes to chunk 0 (s = 0: only the bias load, no accumulator read) or to chunks >= 1,
+    // i.e. at least one chunk of MFMAs after the accumulators were last written (the compiler cannot see asm MFMA latency)
+    auto stage_chunk = [](int st) constexpr { return st == 0 || NCHL == 1 ? 0 : 1 + (st - 1) * (NCHL - 1) / (NST - 1); };
     static_for(std::make_integer_sequence<int, NG>{}, [&](auto gc) {
-        constexpr int g = decltype(gc)::value;
+        constexpr int g = decltype(gc)::value, gp = g & 1, pp = gp ^ 1;
         constexpr int gs = (NTW - 2 * g) < 2 ? (NTW - 2 * g) : 2;
-        floatx4 hi[gs], lo[gs];
+        constexpr int pgs = g > 0 ? 2 : 0;                       // tiles of the previous group (groups before the last are full)
 #pragma unroll
-        for (int k = 0; k < gs; ++k) { hi[k] = floatx4{0.f, 0.f, 0.f, 0.f}; lo[k] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+        for (int k = 0; k < gs; ++k) {
+            hi[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f}; lo[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f}; ll[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < gs; ++k) xdl_operand_nops(hi[gp][k], lo[gp][k], ll[gp][k]);      // VALU-zeroed accumulators -> MFMA srcC
         static_for(std::make_integer_sequence<int, NCHL>{}, [&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int j0 = 2 * g * NCHL + c * gs;
-#pragma unroll
-            for (int k = 0; k < gs; ++k) hi[k] = xmfma(ring.w[(j0 + k) % R][0], X1[c], hi[k]);
-#pragma unroll
-            for (int k = 0; k < gs; ++k) lo[k] = xmfma(ring.w[(j0 + k) % R][1], X1[c], lo[k]);
-#pragma unroll
-            for (int k = 0; k < gs; ++k) lo[k] = xmfma(ring.w[(j0 + k) % R][0], X2[c], lo[k]);
-            static_for(std::make_integer_sequence<int, gs>{}, [&](auto kc) {
-                prefetch(std::integral_constant<int, j0 + decltype(kc)::value>{});
+            static_for(std::make_integer_sequence<int, NPR * gs>{}, [&](auto mc) {      // hi(k).. lo(k).. lo'(k).. [ll(k)..]
+                constexpr int k = decltype(mc)::value % gs, prod = decltype(mc)::value / gs, j = j0 + k;
+                floatx4& acc = prod == 0 ? hi[gp][k] : prod == 3 ? ll[gp][k] : lo[gp][k];
+                const f16x8& x = prod >= 2 ? X2[c] : X1[c];
+                constexpr int part = (prod == 1 || prod == 3) ? 1 : 0;
+                if constexpr (j < NRES) xmfma_res(acc, res[j][part], x);
+                else xmfma_ring<G::ASM_MFMA>(acc, ring.w[(j - NRES) % R][part], x);
             });
-        });
+            static_for(std::make_integer_sequence<int, gs>{}, [&](auto kc) {
+                constexpr int j = j0 + decltype(kc)::value;
+                if constexpr (j >= NRES) prefetch(std::integral_constant<int, j - NRES>{});
+            });
+            static_for(std::make_integer_sequence<int, NST>{}, [&](auto sc) {
+                constexpr int st = decltype(sc)::value;
+                if constexpr (pgs > 0 && stage_chunk(st) == c) {
 #pragma unroll
-        for (int k = 0; k < gs; ++k) epi(2 * g + k, hi[k], lo[k]);
+                    for (int k = 0; k < pgs; ++k) epi.template stage<st>(2 * (g - 1) + k, hi[pp][k], lo[pp][k], ll[pp][k], pst[k]);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);      // pin the software pipeline: no load hoisting across chunks
+        });
+        if constexpr (g == NG - 1) {                // the last group's epilogue has no MFMAs left to hide behind
+#pragma unroll
+            for (int k = 0; k < gs; ++k) xdl_result_nops(hi[gp][k], lo[gp][k], ll[gp][k]);
+            static_for(std::make_integer_sequence<int, NST>{}, [&](auto sc) {
+#pragma unroll
+                for (int k = 0; k < gs; ++k) epi.template stage<decltype(sc)::value>(2 * g + k, hi[gp][k], lo[gp][k], ll[gp][k], pst[k]);
+            });
+        }
     });
-    static_for(std::make_integer_sequence<int, NFPAD - NF>{}, [&](auto jc) {
-        prefetch(std::integral_constant<int, NF + decltype(jc)::value>{});
+    static_for(std::make_integer_sequence<int, NFSPAD - NFS>{}, [&](auto jc) {
+        prefetch(std::integral_constant<int, NFS + decltype(jc)::value>{});
     });
 }
 
-template <class G, int NOISE>
-__global__ __launch_bounds__(256) void rollout_xdl_kernel(const RolloutArgs a) {
+template <class G, int NOISE, int NTW>
+__device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsmem) {
     constexpr int D = G::D, A = G::A, P = G::P, C = G::C, K0 = G::K0, NC0 = G::NC0, NCH = G::NCH, NTO = G::NTO;
     constexpr int NP = G::NP, NPI = G::NPI, NAI = G::NAI, ENV = G::ENV, R = G::R;
-    extern __shared__ __attribute__((aligned(16))) unsigned char xsmem[];
     float* stats = reinterpret_cast<float*>(xsmem + G::STATS);
     float* ctrl_s = reinterpret_cast<float*>(xsmem + G::CTRL);
     float* ofull = reinterpret_cast<float*>(xsmem + G::OFULL);
+    const int bias_off = G::CTRL + rup(16 * a.H * 4, 16);      // LDS byte offset of the bias tiles (BIAS_LDS only)
+    const bool bias_lds = G::BIAS_LDS && a.bias_lds;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -155,34 +294,41 @@ __global__ __launch_bounds__(256) void rollout_xdl_kernel(const RolloutArgs a) {
         stats[G::ST_ACT_DEN + i] = 1.0f / (a.act_std[i] + 1e-10f);
     }
     for (int i = tid; i < (G::OFULL - G::XIN) / 16; i += 256) reinterpret_cast<uintx4*>(xsmem + G::XIN)[i] = uintx4{0u, 0u, 0u, 0u};
+    if (bias_lds) {
+        const uintx4* src = reinterpret_cast<const uintx4*>(a.xb + (size_t)(blockIdx.x / a.wgs_per_member) * a.xb_member);
+        for (int i = tid; i < (a.NH * G::NT + NTO) * 64; i += 256) reinterpret_cast<uintx4*>(xsmem + bias_off)[i] = src[i];
+    }
 
-    float st_dmean[NPI][2], st_dden[NPI][2], st_dl2s[NPI][2], st_mx[NPI][2], st_mn[NPI][2];
-    int fx_off[NPI][2][2], fx_op[NPI][2][2];
-    float fx_mean[NPI][2][2], fx_inv[NPI][2][2];
-    // byte offset (part 0) of input feature f of row arow inside x_in
-    auto xin_off = [&](int f) { return ((f >> 5) * 64 + ((f & 31) >> 3) * 16 + arow) * 16 + (f & 7) * 2; };
+    // byte offset (part 0) of input feature f of row 0 inside x_in; row arow adds arow * 16
+    auto xin_base = [&](int f) { return ((f >> 5) * 64 + ((f & 31) >> 3) * 16) * 16 + (f & 7) * 2; };
+    const int arow16 = arow * 16;
+    auto xin_off = [&](int f) { return xin_base(f) + arow16; };
+    float* tab = reinterpret_cast<float*>(xsmem + G::TAB);
+    if (arow == 0) {
 #pragma unroll
-    for (int pi = 0; pi < NPI; ++pi) {
-        const int dp = fg + 16 * pi;
+        for (int pi = 0; pi < NPI; ++pi) {
+            float* te = tab + (pi * 16 + fg) * G::TABW;
+            const int dp = fg + 16 * pi;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int d = 2 * dp + h;
-            const int dc = d < D ? d : 0;
-            st_dmean[pi][h] = a.delta_mean[dc];
-            st_dden[pi][h] = a.delta_std[dc] + 1e-10f;
-            st_dl2s[pi][h] = 2.0f * logf(a.delta_std[dc]);              // core/utils.py:360
-            st_mx[pi][h] = a.maxlv[dc];
-            st_mn[pi][h] = a.minlv[dc];
-            int ff[2], fop[2];
-            const int nf = d < D ? dim_feats<ENV>(d, ff, fop) : 0;
+            for (int h = 0; h < 2; ++h) {
+                const int d = 2 * dp + h;
+                const int dc = d < D ? d : 0;
+                te[0 + h] = a.delta_mean[dc];
+                te[2 + h] = a.delta_std[dc] + 1e-10f;
+                te[4 + h] = 2.0f * logf(a.delta_std[dc]);              // core/utils.py:360
+                te[6 + h] = a.maxlv[dc];
+                te[8 + h] = a.minlv[dc];
+                int ff[2], fop[2];
+                const int nf = d < D ? dim_feats<ENV>(d, ff, fop) : 0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const bool on = i < nf;
-                const int f = on ? ff[i] : 0;
-                fx_off[pi][h][i] = on ? xin_off(f) : -1;
-                fx_op[pi][h][i] = on ? fop[i] : 0;
-                fx_mean[pi][h][i] = a.obs_mean[f];
-                fx_inv[pi][h][i] = 1.0f / (a.obs_std[f] + 1e-10f);
+                for (int i = 0; i < 2; ++i) {
+                    const bool on = i < nf;
+                    const int f = on ? ff[i] : 0;
+                    te[10 + 2 * h + i] = a.obs_mean[f];
+                    te[14 + 2 * h + i] = 1.0f / (a.obs_std[f] + 1e-10f);
+                    te[18 + 2 * h + i] = __builtin_bit_cast(float, on ? xin_base(f) : -1);
+                    te[22 + 2 * h + i] = __builtin_bit_cast(float, on ? fop[i] : 0);
+                }
             }
         }
     }
@@ -208,6 +354,39 @@ __global__ __launch_bounds__(256) void rollout_xdl_kernel(const RolloutArgs a) {
     const unsigned w_l0 = wbase, w_h1 = w_l0 + l0_nf * CADM_XDL_FRAG_BYTES;
     const unsigned w_hd = w_h1 + (a.NH - 1) * lh_nf * CADM_XDL_FRAG_BYTES;
 
+    // layer ids: 0 = layer 0, 1 .. NH-1 = hidden, NH = head.  Register-resident layers are absent from the ring's stream.
+    // Resident fragments: the first NRES1 of hidden layer 1 and, if registers are left, the whole head (a head is all or
+    // nothing: its slots are guarded at run time).  The STREAMED part of a layer is the tail of its stream region.
+    constexpr int NRES1 = G::res_frags(NTW) < NTW * NCH ? G::res_frags(NTW) : NTW * NCH;
+    constexpr bool RESO = G::res_frags(NTW) - NRES1 >= G::NTOW * NCH;
+    auto lay_res = [&](int l) { return l == 1 ? NRES1 : (RESO && l == a.NH) ? hd_nf : 0; };
+    auto lay_off = [&](int l) {          // first streamed fragment of layer l
+        return (l == 0 ? w_l0 : l < a.NH ? w_h1 + (l - 1) * lh_nf * CADM_XDL_FRAG_BYTES : w_hd) + lay_res(l) * CADM_XDL_FRAG_BYTES;
+    };
+    auto lay_nf = [&](int l) { return (l == 0 ? l0_nf : l < a.NH ? lh_nf : hd_nf) - lay_res(l); };
+    auto next_streamed = [&](int l) {    // next layer (cyclically over steps) with a streamed part; layer 0 always has one
+        do { l = l == a.NH ? 0 : l + 1; } while (lay_nf(l) == 0);
+        return l;
+    };
+    uintx4 resH[NRES1 > 0 ? NRES1 : 1][2], resO[RESO ? G::NTOW * NCH : 1][2];
+    if constexpr (NRES1 > 0) {
+        const unsigned h1 = w_h1;          // layer 1's region starts with its resident fragments
+#pragma unroll
+        for (int q = 0; q < NRES1; ++q) {
+            xres_load(resH[q][0], rsrc, lane * 16, h1 + q * CADM_XDL_FRAG_BYTES);
+            xres_load(resH[q][1], rsrc, lane * 16 + 1024, h1 + q * CADM_XDL_FRAG_BYTES);
+        }
+    }
+    if constexpr (RESO) {
+#pragma unroll
+        for (int q = 0; q < G::NTOW * NCH; ++q) {
+            // (slots of a head tile this wave does not own load in-bounds garbage that is never used)
+            const unsigned so = q < hd_nf ? w_hd + q * CADM_XDL_FRAG_BYTES : wbase;
+            xres_load(resO[q][0], rsrc, lane * 16, so);
+            xres_load(resO[q][1], rsrc, lane * 16 + 1024, so);
+        }
+    }
+    if constexpr (NRES1 > 0 || RESO) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     XRing<G> ring;
     static_for(std::make_integer_sequence<int, R>{}, [&](auto sc) {
         constexpr int s = decltype(sc)::value;
@@ -252,6 +431,7 @@ __global__ __launch_bounds__(256) void rollout_xdl_kernel(const RolloutArgs a) {
         for (int t = fg; t < H; t += 16) ctrl_s[arow * H + t] = ctrl_term<ENV>(a.actions + abase + t * A, A);
         float ret = 0.0f;
         __syncthreads();
+        TS_DECL
 
         for (int t = 0; t <= H; ++t) {
             // ===== state update from step t-1's head (:348-365,463-466) + reward (:469-471) + input assembly (:442-460) =====
@@ -259,16 +439,22 @@ __global__ __launch_bounds__(256) void rollout_xdl_kernel(const RolloutArgs a) {
             for (int pi = 0; pi < NPI; ++pi) {
                 const int dp = fg + 16 * pi;
                 if (dp < NP) {
+                    floatx4 tq[7];
+#pragma unroll
+                    for (int q = 0; q < 7; ++q) tq[q] = *reinterpret_cast<const floatx4*>(tab + (pi * 16 + fg) * G::TABW + 4 * q);
+                    auto tv = [&](int w) { return tq[w >> 2][w & 3]; };
+                    // (bit_cast of an ext-vector ELEMENT expression is miscompiled by hipcc 7.2: go through a scalar)
+                    auto ti_ = [&](int w) { const float fv = tq[w >> 2][w & 3]; return __float_as_int(fv); };
                     if (t > 0) {
                         const int jt = dp >> 2, lt = (dp & 3) * 16 + arow;
                         const floatx4 v = *reinterpret_cast<const floatx4*>(ofull + (jt * 64 + lt) * 4);   // (mu0, mu1, lv0, lv1)
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            float delta = v[h] * st_dden[pi][h] + st_dmean[pi][h];              // denormalize, :349
+                            float delta = v[h] * tv(2 + h) + tv(0 + h);                          // denormalize, :349
                             if constexpr (NOISE != CADM_NOISE_NONE) {
-                                float lv = st_mx[pi][h] - softplus_fast(st_mx[pi][h] - v[2 + h]);   // :356
-                                lv = st_mn[pi][h] + softplus_fast(lv - st_mn[pi][h]);               // :357
-                                const float sd = __expf((lv + st_dl2s[pi][h]) * 0.5f);              // :360-363
+                                float lv = tv(6 + h) - softplus_fast(tv(6 + h) - v[2 + h]);          // :356
+                                lv = tv(8 + h) + softplus_fast(lv - tv(8 + h));                      // :357
+                                const float sd = __expf((lv + tv(4 + h)) * 0.5f);                    // :360-363
                                 delta = delta + pz[pi][h] * sd;                                     // :365
                             }
                             po[pi][h] = postproc<ENV>(2 * dp + h, po[pi][h], delta);                // :466
@@ -289,13 +475,14 @@ __global__ __launch_bounds__(256) void rollout_xdl_kernel(const RolloutArgs a) {
                         for (int h = 0; h < 2; ++h) {
                             float sn = 0.0f, cs = 0.0f;
                             if constexpr (ENV == CADM_ENV_HALFCHEETAH) {                 // the one trig pair (obs dim 2)
-                                if (fx_op[pi][h][0] != 0) sincos_cw(po[pi][h], &sn, &cs);
+                                if (ti_(22 + 2 * h) != 0) sincos_cw(po[pi][h], &sn, &cs);
                             }
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {
-                                if (fx_off[pi][h][i] >= 0) {
-                                    const float pv = fx_op[pi][h][i] == 1 ? sn : fx_op[pi][h][i] == 2 ? cs : po[pi][h];
-                                    put_x(fx_off[pi][h][i], (pv - fx_mean[pi][h][i]) * fx_inv[pi][h][i]);   // :450-451
+                                const int off = ti_(18 + 2 * h + i), op = ti_(22 + 2 * h + i);
+                                if (off >= 0) {
+                                    const float pv = op == 1 ? sn : op == 2 ? cs : po[pi][h];
+                                    put_x(off + arow16, (pv - tv(10 + 2 * h + i)) * tv(14 + 2 * h + i));   // :450-451
                                 }
                             }
                         }
@@ -335,50 +522,42 @@ __global__ __launch_bounds__(256) void rollout_xdl_kernel(const RolloutArgs a) {
                     box_muller(u01(pc[0]), u01(pc[1]), pz[pi][0], pz[pi][1]);
                 }
             }
+            TS(0)
             __syncthreads();
+            TS(1)
 
             // ================= dense layers =================
-            auto layers = [&](auto ntw_c) {
-                constexpr int NTW = decltype(ntw_c)::value;
+            {
                 int act_out = G::ACTA, act_in = G::XIN;      // LDS byte offsets (not pointers: keeps every access a ds_ op)
                 // hidden epilogue: bias, swish, f16 split, store as the next layer's B operand
-                auto hidden_epi = [&](const float* btiles, int out) {
-                    return [=](int ti, floatx4 hi, floatx4 lo) {
-                        const int Tg = tstart + ti;
-                        const floatx4 b = *reinterpret_cast<const floatx4*>(btiles + (Tg * 64 + lane) * 4);
-                        f16x4 h1, h2;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float v = fmaf(lo[r], 4.8828125e-4f, hi[r] + b[r]);
-                            v = fminf(v, 60000.0f);
-                            const float hv = swish_f(v);
-                            _Float16 x1, x2;
-                            xsplit(hv, x1, x2);
-                            h1[r] = x1; h2[r] = x2;
-                        }
-                        unsigned char* dst = xsmem + out + ((Tg >> 1) * 64 + lane) * 16 + (Tg & 1) * 8;
-                        *reinterpret_cast<f16x4*>(dst) = h1;
-                        *reinterpret_cast<f16x4*>(dst + NCH * 1024) = h2;
-                    };
-                };
+                auto hidden_epi = [&](int layer, int out) { return XHiddenEpi<G>{xsmem, xb, bias_off, layer, out, tstart, lane}; };
                 // layer 0
-                xdl_sweep<G, NTW, NC0>(ring, rsrc, w_l0, w_h1, lh_nf, xsmem + act_in, lane, hidden_epi(xb, act_out));
+                {
+                    const int nx = next_streamed(0);
+                    xdl_sweep<G, NTW, NC0, 0>(ring, nullptr, rsrc, w_l0, lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
+                                              hidden_epi(0, act_out));
+                }
+                TS(2)
                 __syncthreads();
-                // hidden layers 1 .. NH-1
-                for (int l = 1; l < a.NH; ++l) {
+                TS(3)
+                // hidden layers 1 .. NH-1: the first three are unrolled (distinct resident registers), the rest loop
+                auto hidden = [&](int l, auto res_c) {
+                    constexpr int NRES = decltype(res_c)::value;
                     act_in = act_out;
                     act_out = (act_in == G::ACTA) ? G::ACTB : G::ACTA;
-                    const unsigned wc = w_h1 + (l - 1) * lh_nf * CADM_XDL_FRAG_BYTES;
-                    const bool last = l + 1 == a.NH;
-                    xdl_sweep<G, NTW, NCH>(ring, rsrc, wc, last ? w_hd : wc + lh_nf * CADM_XDL_FRAG_BYTES, last ? hd_nf : lh_nf,
-                                           xsmem + act_in, lane, hidden_epi(xb + (size_t)l * G::NT * 256, act_out));
+                    const int nx = next_streamed(l);
+                    xdl_sweep<G, NTW, NCH, NRES>(ring, resH, rsrc, lay_off(l), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
+                                                 hidden_epi(l, act_out));
+                    if (l == 1) { TS(4) } else if (l == 2) { TS(8) } else { TS(9) }
                     __syncthreads();
-                }
+                    TS(5)
+                };
+                if (1 < a.NH) hidden(1, std::integral_constant<int, NRES1>{});
+                for (int l = 2; l < a.NH; ++l) hidden(l, std::integral_constant<int, 0>{});
                 act_in = act_out;
                 // ================= output heads (mu | logvar tiles) =================
                 {
                     constexpr int HNF = G::NTOW * NCH, HNFPAD = rup(HNF, R);
-                    const float* bo = xb + (size_t)a.NH * G::NT * 256;
                     f16x8 X1[NCH], X2[NCH];
                     if (nhead > 0) {
 #pragma unroll
@@ -390,41 +569,61 @@ __global__ __launch_bounds__(256) void rollout_xdl_kernel(const RolloutArgs a) {
                     static_for(std::make_integer_sequence<int, G::NTOW>{}, [&](auto sc) {
                         constexpr int s = decltype(sc)::value;
                         const int ht = (3 - wave) + 4 * s;
-                        floatx4 hi = floatx4{0.f, 0.f, 0.f, 0.f}, lo = floatx4{0.f, 0.f, 0.f, 0.f};
+                        floatx4 hi = floatx4{0.f, 0.f, 0.f, 0.f}, lo = floatx4{0.f, 0.f, 0.f, 0.f}, ll = floatx4{0.f, 0.f, 0.f, 0.f};
                         static_for(std::make_integer_sequence<int, NCH>{}, [&](auto cc) {
                             constexpr int c = decltype(cc)::value;
                             constexpr int jx = s * NCH + c;
                             if (s < nhead) {
-                                hi = xmfma(ring.w[jx % R][0], X1[c], hi);
-                                lo = xmfma(ring.w[jx % R][1], X1[c], lo);
-                                lo = xmfma(ring.w[jx % R][0], X2[c], lo);
+                                if constexpr (c == 0) xdl_operand_nops(hi, lo, ll);
+                                if constexpr (RESO) {
+                                    xmfma_res(hi, resO[jx][0], X1[c]);
+                                    xmfma_res(lo, resO[jx][1], X1[c]);
+                                    xmfma_res(lo, resO[jx][0], X2[c]);
+                                    if constexpr (G::NPROD == 4) xmfma_res(ll, resO[jx][1], X2[c]);
+                                } else {
+                                    xmfma_ring<G::ASM_MFMA>(hi, ring.w[jx % R][0], X1[c]);
+                                    xmfma_ring<G::ASM_MFMA>(lo, ring.w[jx % R][1], X1[c]);
+                                    xmfma_ring<G::ASM_MFMA>(lo, ring.w[jx % R][0], X2[c]);
+                                    if constexpr (G::NPROD == 4) xmfma_ring<G::ASM_MFMA>(ll, ring.w[jx % R][1], X2[c]);
+                                }
                             }
                             constexpr int jj = jx + R;
-                            if (jj < HNF) {
+                            if constexpr (RESO) {
+                            } else if (jj < HNF) {
                                 if (jj < hd_nf) xring_load<jx % R>(ring, rsrc, w_hd + jj * CADM_XDL_FRAG_BYTES, lane);
                             } else if constexpr (jj >= HNFPAD) {
                                 if (jj - HNFPAD < l0_nf) xring_load<jx % R>(ring, rsrc, w_l0 + (jj - HNFPAD) * CADM_XDL_FRAG_BYTES, lane);
                             }
                         });
                         if (s < nhead) {
-                            const floatx4 b = *reinterpret_cast<const floatx4*>(bo + (ht * 64 + lane) * 4);
+                            xdl_result_nops(hi, lo, ll);
+                            const int bt = (a.NH * G::NT + ht) * 64 + lane;
+                            floatx4 b;
+                            if constexpr (G::BIAS_LDS) b = *reinterpret_cast<const floatx4*>(xsmem + bias_off + bt * 16);
+                            else b = *reinterpret_cast<const floatx4*>(xb + bt * 4);
                             floatx4 v;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = fmaf(lo[r], 4.8828125e-4f, hi[r] + b[r]);
+                            for (int r = 0; r < 4; ++r) {
+                                v[r] = fmaf(lo[r], 4.8828125e-4f, hi[r] + b[r]);
+                                if constexpr (G::NPROD == 4) v[r] = fmaf(ll[r], 2.384185791015625e-7f, v[r]);
+                            }
                             *reinterpret_cast<floatx4*>(ofull + (ht * 64 + lane) * 4) = v;
                         }
                     });
-                    static_for(std::make_integer_sequence<int, HNFPAD - HNF>{}, [&](auto jc) {
-                        constexpr int jx = HNF + decltype(jc)::value;
-                        constexpr int jj = jx + R;
-                        if (jj - HNFPAD < l0_nf) xring_load<jx % R>(ring, rsrc, w_l0 + (jj - HNFPAD) * CADM_XDL_FRAG_BYTES, lane);
-                    });
+                    if constexpr (!RESO) {
+                        static_for(std::make_integer_sequence<int, HNFPAD - HNF>{}, [&](auto jc) {
+                            constexpr int jx = HNF + decltype(jc)::value;
+                            constexpr int jj = jx + R;
+                            if (jj - HNFPAD < l0_nf) xring_load<jx % R>(ring, rsrc, w_l0 + (jj - HNFPAD) * CADM_XDL_FRAG_BYTES, lane);
+                        });
+                    }
                 }
-            };
-            if (G::EXTRA > 0 && wave < G::EXTRA) layers(std::integral_constant<int, G::BASE + 1>{});
-            else layers(std::integral_constant<int, G::BASE>{});
+            }
+            TS(6)
             __syncthreads();
+            TS(7)
         }
+        TS_DUMP
 
         // ---- a row's return = sum of its threads' reward parts, in fixed slot order ----
         float* ret_s = reinterpret_cast<float*>(xsmem + G::OFULL);
@@ -442,6 +641,16 @@ __global__ __launch_bounds__(256) void rollout_xdl_kernel(const RolloutArgs a) {
 }
 
 template <class G, int NOISE>
+__global__ __launch_bounds__(256) void rollout_xdl_kernel(const RolloutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsmem_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // waves [0, EXTRA) own one hidden tile more than the others: two specialisations of the whole body, chosen per wave
+    // (a scalar branch; every wave executes the same number of barriers)
+    if (G::EXTRA > 0 && wave < G::EXTRA) xdl_run<G, NOISE, G::BASE + 1>(a, xsmem_raw);
+    else xdl_run<G, NOISE, G::BASE>(a, xsmem_raw);
+}
+
+template <class G, int NOISE>
 int xdl_launch_noise(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipStream_t s) {
     RolloutArgs args = a;
     const int tiles = (rows_per_member + 15) / 16;
@@ -450,9 +659,12 @@ int xdl_launch_noise(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, h
     if (per_member < 1) per_member = 1;
     args.wgs_per_member = tiles < per_member ? tiles : per_member;
     args.rows_per_member = rows_per_member;
-    const size_t lds = (size_t)G::CTRL + (size_t)16 * a.H * sizeof(float);
+    size_t lds = (size_t)G::CTRL + (size_t)rup(16 * a.H * 4, 16);
+    const size_t bias_b = (size_t)(a.NH * G::NT + G::NTO) * 1024;
+    args.bias_lds = G::BIAS_LDS;
+    if (G::BIAS_LDS) lds += bias_b;
     if (lds > 160 * 1024) {
-        cadm_set_error("rollout: horizon %d needs %zu B of LDS (> 160 KiB)", a.H, lds);
+        cadm_set_error("rollout: horizon %d with %d hidden layers needs %zu B of LDS (> 160 KiB)", a.H, a.NH, lds);
         return CADM_EINVAL;
     }
     const void* fn = reinterpret_cast<const void*>(&rollout_xdl_kernel<G, NOISE>);

@@ -16,6 +16,7 @@ from cadm_amd import synth
 from cadm_amd._lib import check
 from cadm_amd.synth import make_engine
 
+XDL_NAMES = ["state+noise", "bar", "L0 sweep", "bar", "hidden 1 sweep", "hidden bars", "head sweep", "bar", "hidden 2 sweep", "hidden 3+ sweep"]
 NAMES = ["assembly", "bar0", "L0 mfma", "L0 epi", "bar1", "hid rebuild", "hid mfma", "hid epi", "hid bar",
          "out noise", "out rebuild", "out mfma", "out part wr", "bar5", "head epi", "bar6"]
 
@@ -34,10 +35,11 @@ def main():
     for _ in range(3):
         eng.rollout_returns(prob["obs"], ctx, acts, seed=1, call=1)
     torch.cuda.synchronize()
-    t = tbuf.cpu().numpy().reshape(4, 24)[:, :len(NAMES)].astype(np.float64) / cfg["H"]
+    names = NAMES if os.environ.get("CADM_ROLLOUT") == "f32" else XDL_NAMES
+    t = tbuf.cpu().numpy().reshape(4, 24)[:, :len(names)].astype(np.float64) / cfg["H"]
     print("cycles per step (s_memtime ticks), workgroup 0, per wave:")
     print("%-14s %9s %9s %9s %9s" % ("phase", "wave0", "wave1", "wave2", "wave3"))
-    for i, nm in enumerate(NAMES):
+    for i, nm in enumerate(names):
         print("%-14s %9.0f %9.0f %9.0f %9.0f" % (nm, *t[:, i]))
     print("%-14s %9.0f %9.0f %9.0f %9.0f" % ("TOTAL", *t.sum(1)))
 
