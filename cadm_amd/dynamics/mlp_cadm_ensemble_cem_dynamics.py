@@ -33,6 +33,73 @@ from ..utils import log as logger
 _ACTIVATIONS = (None, "relu", "tanh", "sigmoid", "softmax", "swish")   # reference :17-24
 
 
+class FitIndexStream(object):
+    """Every random index `fit` consumes, in the order the reference draws them from the global `np.random`
+    (/root/reference/cadm/dynamics/mlp_cadm_ensemble_cem_dynamics.py:444, :465, :472-474 + :483):
+
+        permutation(N)             -> [N]        train / validation split of the windows
+        bootstrap(E, n_train)      -> [E, n]     each member's bootstrap sample of training rows (E > 1 only)
+        epoch_order(E, n_train)    -> [E, n]     `shuffle_rows`: per-member argsort of uniforms, once per epoch
+
+    The default draws them on the host from a numpy Generator.  A caller (or a parity test) may pass any object with
+    these three methods as `fit(..., index_stream=...)`, e.g. `ReplayIndexStream` with arrays captured elsewhere."""
+
+    def __init__(self, rng):
+        self.rng = rng
+
+    def permutation(self, n):
+        return self.rng.permutation(n)
+
+    def bootstrap(self, E, n_train):
+        return self.rng.integers(0, n_train, size=(E, n_train))
+
+    def epoch_order(self, E, n_train):
+        return np.argsort(self.rng.uniform(size=(E, n_train)), axis=-1)
+
+
+class RecordingIndexStream(object):
+    """Wraps a stream and keeps what it handed out (`.log`: list of (kind, array))."""
+
+    def __init__(self, inner):
+        self.inner, self.log = inner, []
+
+    def _rec(self, kind, arr):
+        self.log.append((kind, np.array(arr)))
+        return arr
+
+    def permutation(self, n):
+        return self._rec("permutation", self.inner.permutation(n))
+
+    def bootstrap(self, E, n_train):
+        return self._rec("bootstrap", self.inner.bootstrap(E, n_train))
+
+    def epoch_order(self, E, n_train):
+        return self._rec("epoch_order", self.inner.epoch_order(E, n_train))
+
+
+class ReplayIndexStream(object):
+    """Replays a recorded log; raises if `fit` asks for something else than what was recorded."""
+
+    def __init__(self, log):
+        self.log, self.pos = list(log), 0
+
+    def _next(self, kind, shape):
+        if self.pos >= len(self.log) or self.log[self.pos][0] != kind or tuple(self.log[self.pos][1].shape) != tuple(shape):
+            raise ValueError("index stream exhausted or out of order at draw %d (%s %r)" % (self.pos, kind, shape))
+        arr = self.log[self.pos][1]
+        self.pos += 1
+        return arr
+
+    def permutation(self, n):
+        return self._next("permutation", (n,))
+
+    def bootstrap(self, E, n_train):
+        return self._next("bootstrap", (E, n_train))
+
+    def epoch_order(self, E, n_train):
+        return self._next("epoch_order", (E, n_train))
+
+
 class MLPEnsembleCEMDynamicsModel(object):
     """Probabilistic-ensemble MLP dynamics model with a context encoder and a CEM / RS planner."""
 
@@ -250,8 +317,10 @@ class MLPEnsembleCEMDynamicsModel(object):
 
     def fit(self, obs, act, obs_next, cp_obs, cp_act, future_bool, epochs=1000, compute_normalization=True,
             valid_split_ratio=None, rolling_average_persitency=None, verbose=False, log_tabular=False,
-            max_logging=5000, rng=None):
-        """reference :382-569.  `rng` (numpy Generator) replaces the reference's global np.random."""
+            max_logging=5000, rng=None, index_stream=None):
+        """reference :382-569.  `rng` (numpy Generator) replaces the reference's global np.random; `index_stream`
+        (see FitIndexStream) replaces the draws themselves.  `self.last_fit_trace` keeps the per-step training losses
+        and per-epoch validation losses [mse, back_mse, recon] of the call."""
         D, A, F, Hh = self.obs_space_dims, self.action_space_dims, self.future_length, self.history_length
         assert obs.ndim == 2 and obs.shape[1] == D * F
         assert obs_next.ndim == 2 and obs_next.shape[1] == D * F
@@ -264,7 +333,8 @@ class MLPEnsembleCEMDynamicsModel(object):
         if rolling_average_persitency is None:
             rolling_average_persitency = self.rolling_average_persitency
         assert 1 > valid_split_ratio >= 0
-        rng = rng if rng is not None else np.random.default_rng(self.seed + 7919 * (self._call + 1))
+        if index_stream is None:
+            index_stream = FitIndexStream(rng if rng is not None else np.random.default_rng(self.seed + 7919 * (self._call + 1)))
 
         obs = obs.reshape(-1, D)
         obs_next = obs_next.reshape(-1, D)
@@ -289,14 +359,14 @@ class MLPEnsembleCEMDynamicsModel(object):
 
         N = ds["obs"].shape[0]
         n_valid = min(int(N * valid_split_ratio), max_logging)
-        perm = rng.permutation(N)
+        perm = np.asarray(index_stream.permutation(N))
         # The reference explodes every window into F rows on the host (`_preprocess_inputs`, :676-696: reshape, tile the
         # history F times, mask by future_bool) and feeds numpy batches.  Here the windowed dataset goes to HBM once and
         # a row is the pair (window, future offset): batches gather straight from the windows, the history is never tiled.
         dev = self._upload_dataset(ds)
         train_rows = self._row_index(ds["future_bool"], perm[n_valid:])
         valid_rows = self._row_index(ds["future_bool"], perm[:n_valid]) if n_valid > 0 else None
-        return self._fit_loop(dev, train_rows, valid_rows, epochs, rolling_average_persitency, verbose, log_tabular, rng)
+        return self._fit_loop(dev, train_rows, valid_rows, epochs, rolling_average_persitency, verbose, log_tabular, index_stream)
 
     _BATCH_KEYS = ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
 
@@ -323,7 +393,7 @@ class MLPEnsembleCEMDynamicsModel(object):
         out["cp_act"] = dev["cp_act"][w]
         return out
 
-    def _fit_loop(self, dev, train_rows, valid_rows, epochs, persistency, verbose, log_tabular, rng):
+    def _fit_loop(self, dev, train_rows, valid_rows, epochs, persistency, verbose, log_tabular, stream):
         """Epoch / batch loop (reference :460-569): bootstrap indices, shuffle_rows, one fused
         fwd/bwd/Adam step per batch, validation, rolling-average early stop."""
         self._ensure_train()
@@ -332,12 +402,11 @@ class MLPEnsembleCEMDynamicsModel(object):
         row_f = torch.as_tensor(train_rows[1], device=eng.device)
         n_train = int(row_w.shape[0])
         if E > 1:
-            bootstrap_idx = rng.integers(0, n_train, size=(E, n_train))       # :465
+            bootstrap_idx = np.asarray(stream.bootstrap(E, n_train))            # :465
         else:
             bootstrap_idx = np.tile(np.arange(n_train, dtype="int64"), (E, 1))  # :467
-        didx = torch.as_tensor(bootstrap_idx, device=eng.device)
-        gen = torch.Generator(device=eng.device)     # per-epoch shuffles run on the device, seeded from the caller's rng
-        gen.manual_seed(int(rng.integers(0, 2 ** 62)))
+        didx = torch.as_tensor(bootstrap_idx.astype(np.int64), device=eng.device)
+        trace = self.last_fit_trace = dict(train=[], valid=[])
         dev_valid = None
         if valid_rows is not None and valid_rows[0].shape[0] > 0:
             vw = torch.as_tensor(valid_rows[0], device=eng.device)
@@ -347,17 +416,21 @@ class MLPEnsembleCEMDynamicsModel(object):
         epoch = -1
         for epoch in range(epochs):
             t0 = time.time()
-            # shuffle_rows (:472-474,483): independent permutation of every member's index row (argsort of uniforms)
-            order = torch.argsort(torch.rand(didx.shape, generator=gen, device=eng.device), dim=-1)
+            # shuffle_rows (:472-474,483): independent permutation of every member's index row (argsort of uniforms);
+            # drawn on the host so that the whole index stream is injectable -- [E, n_train] int64 per epoch
+            order = torch.as_tensor(np.asarray(stream.epoch_order(E, n_train)).astype(np.int64), device=eng.device)
             didx = torch.gather(didx, 1, order)
             losses = []
             for b in range(int(np.ceil(n_train / self.batch_size))):
                 bi = didx[:, b * self.batch_size:(b + 1) * self.batch_size]    # [E,B] row ids
                 # the step reads its rows through (row id -> window, offset) inside the kernels: no gathered batch
                 losses.append(eng.train_step_rows(dev, self.future_length, row_w, row_f, bi, train=True))
-            tl = torch.stack(losses).mean(0).cpu().numpy() if losses else np.zeros(3)
+            step_losses = torch.stack(losses).cpu().numpy() if losses else np.zeros((0, 3))
+            trace["train"].extend(step_losses)
+            tl = step_losses.mean(0) if losses else np.zeros(3)
             if dev_valid is not None:
                 v_mse, v_back, v_recon = eng.train_step(dev_valid, train=False).cpu().numpy()
+                trace["valid"].append((v_mse, v_back, v_recon))
                 if verbose:
                     logger.log("Training DynamicsModel - finished epoch %i --"
                                "[Training] mse loss: %.4f  back mse loss: %.4f  recon loss:  %.4f "

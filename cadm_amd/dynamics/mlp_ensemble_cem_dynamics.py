@@ -55,7 +55,7 @@ class MLPEnsembleCEMDynamicsModel(_CaDMModel):
         return self._stats12()[:6]
 
     def fit(self, obs, act, obs_next, epochs=1000, compute_normalization=True, valid_split_ratio=None,
-            rolling_average_persitency=None, verbose=False, log_tabular=False, max_logging=5000, rng=None):
+            rolling_average_persitency=None, verbose=False, log_tabular=False, max_logging=5000, rng=None, index_stream=None):
         """reference :209-323 (single-step samples, no history window)."""
         N = obs.shape[0]
         D, A = self.obs_space_dims, self.action_space_dims
@@ -65,4 +65,4 @@ class MLPEnsembleCEMDynamicsModel(_CaDMModel):
         return super().fit(obs, act, obs_next, np.zeros((N, 0)), np.zeros((N, 0)), np.ones((N, 1)), epochs=epochs,
                            compute_normalization=compute_normalization, valid_split_ratio=valid_split_ratio,
                            rolling_average_persitency=rolling_average_persitency, verbose=verbose,
-                           log_tabular=log_tabular, max_logging=max_logging, rng=rng)
+                           log_tabular=log_tabular, max_logging=max_logging, rng=rng, index_stream=index_stream)

@@ -45,3 +45,14 @@ def assert_close(a, b, rtol=1e-5, what=""):
     bad = np.abs(a - b) > bound
     assert not bad.any(), "%s: %d/%d elements off, worst |diff|=%.3e (bound %.3e), rel_err=%.3e" % (
         what, int(bad.sum()), bad.size, float(np.abs(a - b).max()), float(bound.flat[np.abs(a - b).argmax()]), rel_err(a, b))
+
+
+def floor_reliance(a, b, rtol=1e-5):
+    """How much of `assert_close`'s verdict leans on its rms floor: (elements that violate the PURE relative bound
+    |a-b| <= rtol*|b|, total elements, largest |b|/rms among those).  Elements far below the tensor's rms are sums that
+    cancelled: no fp32 evaluation order reproduces them to 1e-5 of themselves."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = max(float(np.sqrt(np.mean(b * b))), 1e-30)
+    bad = np.abs(a - b) > rtol * np.abs(b)
+    worst = float((np.abs(b)[bad] / scale).max()) if bad.any() else 0.0
+    return int(bad.sum()), int(bad.size), worst

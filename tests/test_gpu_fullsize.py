@@ -1,4 +1,4 @@
-"""BASELINE.json's full sizes (cfg1..cfg4; cfg5's per-GPU share is cfg3's shape) through size-independent
+"""BASELINE.json's full sizes (cfg1..cfg5 and the reference's m = 10 launch shape) through size-independent
 properties: rows are independent, so (i) a random subset of candidates re-run through the CPU oracle must reproduce the
 corresponding returns of the full launch, (ii) candidate shards compose bit for bit, (iii) the fused planner is
 deterministic and equals the stepwise one, (iv) permuting candidates permutes the returns (noise-free model)."""
@@ -81,3 +81,92 @@ def test_full_size_candidate_permutation_equivariance(gpu):
     r0 = eng.rollout_returns(prob["obs"], ctx, actions, it=0)
     r1 = eng.rollout_returns(prob["obs"], ctx, actions[:, perm].contiguous(), it=0)
     np.testing.assert_array_equal(_np(r0[:, perm]), _np(r1))
+
+
+def test_cfg5_eight_candidate_shards_on_one_gpu(gpu):
+    """BASELINE configs[4]: cand = 8000 sharded 1000 per GPU over 8 GPUs.  One GPU plays the 8 ranks in turn
+    (`cand_offset = r * 1000, n_local = 1000`): the shards must concatenate to the unsharded launch bit for bit (injected
+    AND device-drawn noise -- the Philox counters are keyed by the GLOBAL row), 12 sampled candidates must match the
+    oracle, and the refit over the gathered [8, m, 1000] layout (what ncclAllGather delivers,
+    /root/reference/cadm/dynamics/core/utils.py:474-486 on the global return vector) must equal the unsharded refit."""
+    cfg = synth.CONFIGS["cfg5"]
+    E, p, n, H, G = cfg["E"], cfg["p"], cfg["n"], cfg["H"], 8
+    nl = n // G
+    prob = synth.make_problem(env=cfg["env"], context=True, E=E, m=1, H=H, trained_like=True, seed=81)
+    eng = make_engine(prob, p=p)
+    ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"])
+    mean, var = eng._t(prob["init_mean"]), eng._t(prob["init_var"])
+    actions = eng.sample_actions(mean, var, n, seed=5, call=2, it=0)                      # every rank draws all 8000
+    eps = torch.randn((H, 1, n, p, prob["D"]), device=eng.device)
+    full = eng.rollout_returns(prob["obs"], ctx, actions, eps=eps, it=0)                  # [1, 8000, 20]
+    full_rng = eng.rollout_returns(prob["obs"], ctx, actions, seed=5, call=2, it=0)
+    parts, parts_rng = [], []
+    for r in range(G):
+        parts.append(eng.rollout_returns(prob["obs"], ctx, actions, eps=eps[:, :, r * nl:(r + 1) * nl].contiguous(), it=0,
+                                         cand_offset=r * nl, n_local=nl))
+        parts_rng.append(eng.rollout_returns(prob["obs"], ctx, actions, seed=5, call=2, it=0, cand_offset=r * nl, n_local=nl))
+    np.testing.assert_array_equal(_np(torch.cat(parts, dim=1)), _np(full))
+    np.testing.assert_array_equal(_np(torch.cat(parts_rng, dim=1)), _np(full_rng))
+    # sampled candidates vs the oracle
+    rng = np.random.default_rng(6)
+    sub = np.sort(rng.choice(n, size=12, replace=False))
+    a_sub, e_sub = _np(actions)[:, sub], _np(eps)[:, :, sub]
+    res = {}
+    for dt in (np.float32, np.float64):
+        o = oracle_problem(prob, dt)
+        T = oplanner.context_table_indexed(onets.context_forward(o["cp"], o["cp_obs"], o["cp_act"], o["st"]), 0)
+        res[dt] = oplanner.rollout_indexed(o["env"], o["ff"], o["st"], o["obs"], T, a_sub.astype(dt), e_sub.astype(dt), E, p, False)
+    band = max(8 * rel_err(res[np.float32], res[np.float64]), 2e-5)
+    assert rel_err(_np(full)[:, sub], res[np.float32]) <= band
+    # refit: gathered [G, m, n_local] layout == unsharded [m, n]
+    cand_full = eng.particle_mean(full)                                                   # [1, 8000]
+    gathered = torch.stack([eng.particle_mean(x) for x in parts], dim=0)                  # [8, 1, 1000]
+    m1, v1, m2, v2 = mean.clone(), var.clone(), mean.clone(), var.clone()
+    el1 = eng.cem_refit(cand_full, actions, m1, v1, G=1, want_elites=True)
+    el2 = eng.cem_refit(gathered, actions, m2, v2, G=G, want_elites=True)
+    np.testing.assert_array_equal(_np(el1), _np(el2))
+    np.testing.assert_array_equal(_np(m1), _np(m2))
+    np.testing.assert_array_equal(_np(v1), _np(v2))
+    nm, nv, idx = oplanner.elite_refit(_np(mean), _np(var), _np(actions), _np(cand_full))
+    np.testing.assert_array_equal(_np(el1), idx)
+
+
+def test_production_shape_m10(gpu):
+    """The reference's launch shape: m = 10 vectorised envs (/root/reference/run_scripts/run_cadm_pets.py:201,
+    cadm/samplers/sampler.py:109-113) x cand 200 x part 20 x E 5, H 30.  Quirk Q2 (core/utils.py:433-439) only bites at
+    m > 1 on ODD CEM iterations: sampled (env, candidate) rows against the oracle on it = 1 and it = 2, candidate shards
+    compose bit for bit, and the fused planner is deterministic and equals the per-iteration composition."""
+    E, p, n, H, m = 5, 20, 200, 30, 10
+    prob = synth.make_problem(env="halfcheetah", context=True, E=E, m=m, H=H, trained_like=True, seed=83)
+    eng = make_engine(prob, p=p)
+    ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"])
+    mean, var = eng._t(prob["init_mean"]), eng._t(prob["init_var"])
+    rng = np.random.default_rng(7)
+    sub = np.sort(rng.choice(n, size=6, replace=False))
+    for it in (1, 2):
+        actions = eng.sample_actions(mean, var, n, seed=3, call=1, it=it)                 # [10, 200, 30, 6]
+        eps = torch.randn((H, m, n, p, prob["D"]), device=eng.device)
+        rows = eng.rollout_returns(prob["obs"], ctx, actions, eps=eps, it=it)             # [10, 200, 20]
+        a_sub, e_sub = _np(actions)[:, sub], _np(eps)[:, :, sub]
+        res = {}
+        for dt in (np.float32, np.float64):
+            o = oracle_problem(prob, dt)
+            T = oplanner.context_table_indexed(onets.context_forward(o["cp"], o["cp_obs"], o["cp_act"], o["st"]), it)
+            res[dt] = oplanner.rollout_indexed(o["env"], o["ff"], o["st"], o["obs"], T, a_sub.astype(dt), e_sub.astype(dt), E, p, False)
+        band = max(8 * rel_err(res[np.float32], res[np.float64]), 2e-5)
+        assert rel_err(_np(rows)[:, sub], res[np.float32]) <= band, "it=%d: %.2e (band %.2e)" % (it, rel_err(_np(rows)[:, sub], res[np.float32]), band)
+        h = n // 2
+        parts = [eng.rollout_returns(prob["obs"], ctx, actions, eps=eps[:, :, g * h:(g + 1) * h].contiguous(), it=it,
+                                     cand_offset=g * h, n_local=h) for g in range(2)]
+        np.testing.assert_array_equal(_np(torch.cat(parts, dim=1)), _np(rows))
+    # Q2 must actually matter at this shape: the odd-iteration layout differs from the even one
+    o = oracle_problem(prob, np.float32)
+    octx = onets.context_forward(o["cp"], o["cp_obs"], o["cp_act"], o["st"])
+    assert not np.array_equal(oplanner.context_table_indexed(octx, 0), oplanner.context_table_indexed(octx, 1))
+    args = (prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], n)
+    a = eng.cem_plan(*args, seed=11, call=4)
+    b = eng.cem_plan(*args, seed=11, call=4)
+    c = hplanner.cem_plan(eng, *args, seed=11, call=4)
+    np.testing.assert_array_equal(_np(a), _np(b))
+    np.testing.assert_array_equal(_np(a), _np(c))
+    assert _np(a).shape == (m, H, 6) and np.abs(_np(a)).max() <= 1.0

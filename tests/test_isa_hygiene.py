@@ -1,0 +1,82 @@
+"""Build-time check of the generated gfx950 code of the production rollout kernels (no GPU needed).
+
+The register-resident weight fragments of `rollout_xdl_kernel` are pinned to AGPRs through inline-asm operand constraints
+(cadm_amd/csrc/rollout_xdl.h).  If hipcc ever runs out of registers there it parks a resident fragment in VGPRs / scratch
+and copies it back with `v_accvgpr_write` right in front of the asm MFMA that reads it -- an operand hazard the compiler
+cannot see through inline asm (stale operands, silently wrong rollouts).  So the shipped library itself is disassembled
+and every asm-MFMA geometry must be free of AGPR<->VGPR shuffles and of scratch traffic."""
+import os
+import re
+import struct
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "cadm_amd", "libcadm_hip.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _code_objects(path):
+    """gfx950 ELF images inside the library's .hip_fatbin (clang offload bundles, one per translation unit)."""
+    data = open(path, "rb").read()
+    out, pos = [], 0
+    while True:
+        i = data.find(MAGIC, pos)
+        if i < 0:
+            return out
+        n = struct.unpack_from("<Q", data, i + len(MAGIC))[0]
+        off = i + len(MAGIC) + 8
+        for _ in range(n):
+            o, s, ts = struct.unpack_from("<QQQ", data, off)
+            triple = data[off + 24:off + 24 + ts]
+            off += 24 + ts
+            if b"gfx950" in triple and s > 0:
+                out.append(data[i + o:i + o + s])
+        pos = i + len(MAGIC)
+
+
+def _kernels(image):
+    """{demangled-ish symbol: instruction text} of the xdl rollout kernels of one code object."""
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(image)
+        f.flush()
+        txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, check=True).stdout
+    out, name, buf = {}, None, []
+    for line in txt.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            if name is not None:
+                out[name] = buf
+            name, buf = (m.group(1), []) if "rollout_xdl_kernel" in m.group(1) else (None, [])
+        elif name is not None:
+            buf.append(line.strip())
+    if name is not None:
+        out[name] = buf
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump not available")
+def test_resident_fragments_never_leave_agprs():
+    assert os.path.exists(LIB), "libcadm_hip.so is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    images = _code_objects(LIB)
+    assert len(images) >= 5, "expected the per-env rollout code objects in the library, found %d" % len(images)
+    checked = 0
+    for img in images:
+        for sym, ins in _kernels(img).items():
+            # XC<ENV, C, HID>: geometries with HID <= 256 use the asm MFMA path with AGPR-resident fragments
+            m = re.search(r"2XCILi(\d+)ELi(\d+)ELi(\d+)EEE", sym)
+            assert m, sym
+            hid = int(m.group(3))
+            n_mfma = sum(1 for x in ins if x.startswith("v_mfma_f32_16x16x32_f16"))
+            assert n_mfma > 40, "%s: only %d f16 MFMAs -- wrong kernel?" % (sym, n_mfma)
+            if hid > 256:
+                continue
+            bad = [x for x in ins if x.startswith(("v_accvgpr_write", "v_accvgpr_read", "scratch_"))]
+            assert not bad, "%s: %d AGPR shuffles / scratch accesses (e.g. %s): resident fragments were spilled" % (sym, len(bad), bad[0])
+            res = [x for x in ins if x.startswith("v_mfma_f32_16x16x32_f16") and re.search(r", a\[\d+:\d+\], v\[", x)]
+            assert len(res) > 20, "%s: no MFMA reads its A operand from AGPRs -- residency is off" % sym
+            checked += 1
+    assert checked >= 5 * 2 * 3      # 5 envs x {C = 0, 10} x 3 noise modes at least for HID = 200
