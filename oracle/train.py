@@ -257,3 +257,82 @@ def early_stop_trace(v_recon, persistency):
             break
         prev = rolling                           # :564
     return last, trace
+
+
+# ----------------------------------------------------------------------------
+# fit(): the whole host loop, on an injected index stream
+# ----------------------------------------------------------------------------
+def fit_reference(env, env_name, nets, data, stream, cfg, epochs, batch_size, valid_split_ratio=0.2,
+                  max_logging=5000, persistency=0.99, dtype=torch.float64, lr=1e-3):
+    """Restatement of `MLPEnsembleCEMDynamicsModel.fit` for ONE call on an empty dataset
+    (/root/reference/cadm/dynamics/mlp_cadm_ensemble_cem_dynamics.py:382-569): targets (:399-407), dataset columns
+    (:409-425), normalisation over the first-step columns (:428-440), window split (:442-453), `_preprocess_inputs`
+    (:455-459), bootstrap indices (:463-467), per-epoch `shuffle_rows` (:472-474,483), one Adam step per batch
+    (:486-513), validation on identical indices for every member (:469-470,516-537) and the rolling-average early stop
+    (:541-564).  Every random draw comes from `stream` (permutation / bootstrap / epoch_order -- the order the reference
+    consumes `np.random`).
+
+    env: oracle.envs spec (numpy closures); nets: dict(ff=, back=, cp=) of OrderedDicts of numpy arrays (back / cp may be
+    None); data: dict(obs, act, obs_next, cp_obs, cp_act, future_bool) windowed as the reference's fit() takes them;
+    cfg: the `train_losses` cfg + state_diff, discrete.
+    Returns dict(train=[per-step (mse, back_mse, recon)], valid=[per-epoch], params={net: {name: numpy}}, stats=dict,
+    epochs_run)."""
+    D, A = env.obs_dim, env.act_dim
+    obs, act, obs_next = data["obs"], data["act"], data["obs_next"]
+    cp_obs, cp_act, future_bool = data["cp_obs"], data["cp_act"], data["future_bool"]
+    F = future_bool.shape[1]
+    Hh = cp_obs.shape[1] // D if D else 0
+    o1, on1 = obs.reshape(-1, D), obs_next.reshape(-1, D)
+    delta = env.targ_proc(o1, on1).reshape(-1, F * D)                    # :401,405
+    back_delta = env.targ_proc(on1, o1).reshape(-1, F * D)               # :402,407
+    norm = compute_normalization(env, obs[:, :D], act[:, :A], delta[:, :D], cp_obs, cp_act, back_delta[:, :D])   # :428-440
+    stats_np = normalization_stats(norm, D, A, Hh, cfg.get("discrete", False), cfg.get("state_diff", True))
+    st = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in stats_np.items()}
+
+    N = obs.shape[0]
+    n_valid = min(int(N * valid_split_ratio), max_logging)              # :443
+    perm = np.asarray(stream.permutation(N))                            # :444
+    tr, va = perm[n_valid:], perm[:n_valid]
+    cols = lambda idx: preprocess_inputs(obs[idx], act[idx], delta[idx], cp_obs[idx], cp_act[idx], future_bool[idx],
+                                         obs_next[idx], back_delta[idx], D, A, Hh, F)
+    names = ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
+    train = dict(zip(names, cols(tr)))
+    valid = dict(zip(names, cols(va))) if n_valid > 0 else None
+    n_train = train["obs"].shape[0]
+    E = next(iter(nets["ff"].values())).shape[0]
+    if E > 1:
+        bidx = np.asarray(stream.bootstrap(E, n_train))                 # :465
+    else:
+        bidx = np.tile(np.arange(n_train), (E, 1))                      # :467
+
+    params = {k: (None if v is None else to_torch(v, dtype, requires_grad=True)) for k, v in nets.items()}
+    adam = TF1Adam(lr=lr)
+    tb = lambda d, idx: {k: torch.tensor(np.asarray(v[idx]), dtype=dtype) for k, v in d.items()}
+    out_train, out_valid = [], []
+    rolling, prev = None, None
+    epochs_run = 0
+    for epoch in range(epochs):
+        epochs_run = epoch + 1
+        order = np.asarray(stream.epoch_order(E, n_train))              # shuffle_rows, :472-474
+        bidx = bidx[np.arange(E)[:, None], order]                       # :483
+        for b in range(int(np.ceil(n_train / batch_size))):
+            idx = bidx[:, b * batch_size:(b + 1) * batch_size]          # :487  [E, B]
+            res = train_losses(env_name, params["ff"], params.get("back"), params.get("cp"), st, tb(train, idx), cfg)
+            out_train.append((float(res["mse"].detach()), float(res["back_mse"].detach()), float(res["recon"].detach())))
+            adam.step(params, grads_of(res["loss"], params))            # :508-510
+        if valid is not None and valid["obs"].shape[0] > 0:
+            vidx = np.tile(np.arange(valid["obs"].shape[0]), (E, 1))    # :469-470
+            with torch.no_grad():
+                res = train_losses(env_name, params["ff"], params.get("back"), params.get("cp"), st, tb(valid, vidx), cfg)
+            v = float(res["recon"])
+            out_valid.append((float(res["mse"]), float(res["back_mse"]), v))
+            if rolling is None:                                         # :544-549
+                rolling, prev = 1.5 * v, 2 * v
+                if v < 0:
+                    rolling, prev = v / 1.5, v / 2
+            rolling = persistency * rolling + (1.0 - persistency) * v   # :551-552
+            if prev < rolling:                                          # :554-556
+                break
+        prev = rolling                                                  # :564
+    final = {k: (None if v is None else OrderedDict((n, t.detach().numpy().copy()) for n, t in v.items())) for k, v in params.items()}
+    return dict(train=out_train, valid=out_valid, params=final, stats=stats_np, epochs_run=epochs_run)

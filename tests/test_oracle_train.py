@@ -1,6 +1,7 @@
 """CPU: pins the oracle's training restatement: TF1 Adam closed form, which variables get a
 gradient, and fit()'s host-side data path."""
 import numpy as np
+import pytest
 import torch
 
 from cadm_amd import synth
@@ -85,3 +86,66 @@ def test_preprocess_inputs_and_stats():
     s = ot.normalization_stats(norm, D, A, Hh, discrete=False, state_diff=True)
     assert np.all(s["cp_obs_mean"] == 0) and np.all(s["cp_obs_std"] == 1)      # state_diff forces (0,1)
     np.testing.assert_allclose(s["obs_std"], env.obs_preproc(obs[:, :D]).std(0))   # population std (ddof = 0)
+
+
+@pytest.mark.parametrize("env_name,state_diff,normalize_input", [("halfcheetah", True, True), ("halfcheetah", False, True),
+                                                                 ("cartpole", True, True), ("halfcheetah", True, False)])
+def test_model_normalization_stats_match_the_oracle(env_name, state_diff, normalize_input):
+    """`compute_normalization` / `get_normalization_stats` of the drop-in class against the oracle restatement of
+    /root/reference/cadm/dynamics/mlp_cadm_ensemble_cem_dynamics.py:590-645 -- population statistics in float64, cp_obs
+    forced to (0, 1) under state_diff (:616-618), action statistics forced to (0, 1) for discrete envs (:610-612,622-624),
+    everything (0, 1) without normalize_input (:627-644).  Host-only: the methods never touch the engine."""
+    from cadm_amd.dynamics.mlp_cadm_ensemble_cem_dynamics import MLPEnsembleCEMDynamicsModel
+    from cadm_amd.envs import make_env_spec
+    from oracle import envs as oenvs
+    spec = make_env_spec(env_name)
+    env = oenvs.make_env(env_name)
+    D, A, Hh = env.obs_dim, env.act_dim, 4
+    rng = np.random.default_rng(12)
+    N = 200
+    obs, delta, back = rng.standard_normal((N, D)) * 3 + 1, rng.standard_normal((N, D)), rng.standard_normal((N, D))
+    act = rng.uniform(-1, 1, (N, A))
+    cp_obs, cp_act = rng.standard_normal((N, D * Hh)) * 0.3, rng.uniform(-1, 1, (N, A * Hh))
+    m = object.__new__(MLPEnsembleCEMDynamicsModel)              # host-side methods only: no engine, no GPU
+    m.env, m.normalize_input, m.state_diff = spec, normalize_input, state_diff
+    m.discrete = env.discrete
+    m.obs_space_dims, m.action_space_dims, m.proc_obs_space_dims, m.history_length = D, A, env.proc_obs_dim, Hh
+    m.normalization = None
+    m.compute_normalization(obs, act, delta, cp_obs, cp_act, back)
+    got = m.get_normalization_stats()
+    keys = ("obs_mean", "obs_std", "act_mean", "act_std", "delta_mean", "delta_std", "cp_obs_mean", "cp_obs_std",
+            "cp_act_mean", "cp_act_std", "back_delta_mean", "back_delta_std")
+    if normalize_input:
+        want = ot.normalization_stats(ot.compute_normalization(env, obs, act, delta, cp_obs, cp_act, back), D, A, Hh,
+                                          env.discrete, state_diff)
+    else:
+        P = env.proc_obs_dim
+        want = dict(obs_mean=np.zeros(P), obs_std=np.ones(P), act_mean=np.zeros(A), act_std=np.ones(A), delta_mean=np.zeros(D),
+                    delta_std=np.ones(D), cp_obs_mean=np.zeros(D * Hh), cp_obs_std=np.ones(D * Hh), cp_act_mean=np.zeros(A * Hh),
+                    cp_act_std=np.ones(A * Hh), back_delta_mean=np.zeros(D), back_delta_std=np.ones(D))
+    for k, v in zip(keys, got):
+        np.testing.assert_array_equal(np.asarray(v, np.float64), np.asarray(want[k], np.float64), err_msg=k)
+
+
+def test_vanilla_model_reads_a_reference_layout_three_key_norm_stats_file(tmp_path):
+    """the reference's vanilla model saves only obs / delta / act statistics
+    (/root/reference/cadm/dynamics/mlp_ensemble_cem_dynamics.py:343-351); its stats accessor returns the 6-tuple (:353-373)."""
+    import joblib
+    from collections import OrderedDict
+    from cadm_amd.dynamics.mlp_ensemble_cem_dynamics import MLPEnsembleCEMDynamicsModel as Vanilla
+    from cadm_amd.envs import make_env_spec
+    rng = np.random.default_rng(1)
+    norm = OrderedDict(obs=(rng.standard_normal(18), rng.uniform(0.5, 2, 18)), delta=(rng.standard_normal(18), rng.uniform(0.5, 2, 18)),
+                       act=(rng.standard_normal(6), rng.uniform(0.5, 2, 6)))
+    joblib.dump(norm, str(tmp_path / "params_norm_stats"))
+    m = object.__new__(Vanilla)
+    m.env, m.normalize_input, m.state_diff, m.discrete = make_env_spec("halfcheetah"), True, False, False
+    m.obs_space_dims, m.action_space_dims, m.proc_obs_space_dims, m.history_length = 18, 6, 18, 0
+    m.normalization = joblib.load(str(tmp_path / "params_norm_stats"))
+    six = m.get_normalization_stats()
+    assert len(six) == 6
+    np.testing.assert_array_equal(six[0], norm["obs"][0]); np.testing.assert_array_equal(six[3], norm["act"][1])
+    twelve = m._stats12()                     # what the engine consumes: the missing three default to (0, 1) of width 0 / D
+    assert len(twelve) == 12 and twelve[6].shape == (0,) and twelve[10].shape == (18,) and float(twelve[11].min()) == 1.0
+    m.compute_normalization(rng.standard_normal((50, 18)), rng.standard_normal((50, 6)), rng.standard_normal((50, 18)))
+    assert list(m.normalization) == ["obs", "delta", "act"]
