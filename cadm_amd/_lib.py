@@ -81,6 +81,7 @@ SIGNATURES = {
     "cadm_debug_set_timing_buffer": (_i, [_P, _P]),
     "cadm_warm_start_shift": (_i, [_P, _P, _i, _P, _P, _P]),
     "cadm_history_update": (_i, [_P, _P, _P, _P, _P, _i, _i, _P, _P, _P, _P, _P]),
+    "cadm_build_windows": (_i, [_P, _P, _P, _P, _i, _i, _i, _i, _i, _P, _P, _P, _i, _i, _P, _P, _P, _P, _P, _P, _P]),
     "cadm_dist_unique_id": (_i, [C.c_char_p]),
     "cadm_dist_init": (_i, [_P, C.c_char_p, _i, _i]),
     "cadm_dist_destroy": (_i, [_P]),

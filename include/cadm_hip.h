@@ -221,6 +221,19 @@ int cadm_history_update(cadm_ctx* ctx, const float* obs, const float* next_obs, 
                         const int32_t* done, int m, int state_diff, int32_t* counts_io, float* hist_obs_io,
                         float* hist_act_io, float* prev_sol_io, void* stream);
 
+/* Training-set builder of the context model: device twin of the `context` branch of
+ * ModelSampleProcessor.process_samples (cadm/samplers/model_sample_processor.py:58-100).  All paths' steps are concatenated:
+ * obs [T,D], act [T,A], cp_obs [T,Dh], cp_act [T,Ah] of 4- or 8-byte elements (elem_bytes; float32 or the reference's
+ * float64 -- the kernel only moves words, results are bit-exact); path_off [P+1] = first step of every path (int32);
+ * a path of len steps yields n = max(len, F+1) - 1 rows (short paths are zero-padded, :62-68); row_path / row_step [N] name
+ * the path and step of every output row (N = sum of n).  Writes concat_obs / concat_next_obs [N,F*D], concat_act [N,F*A],
+ * concat_bool [N,F] (1.0 / 0.0 of the element type, including the reference's "row 0 of every path is masked" quirk,
+ * :85-86) and the rows' history windows cp_obs_out [N,Dh], cp_act_out [N,Ah].  Needs no ctx; asynchronous on `stream`. */
+int cadm_build_windows(const void* obs, const void* act, const void* cp_obs, const void* cp_act, int elem_bytes, int D, int A,
+                       int Dh, int Ah, const int32_t* path_off, const int32_t* row_path, const int32_t* row_step, int N, int F,
+                       void* concat_obs, void* concat_act, void* concat_next_obs, void* concat_bool, void* cp_obs_out,
+                       void* cp_act_out, void* stream);
+
 /* Multi-GPU planning: candidates shard contiguously over the ranks of an RCCL communicator owned by the
  * ctx (one process per GPU).  The reference is single-device (cadm/trainers/mb_trainer.py:103-107); this
  * adds exactly one collective per CEM iteration -- ncclAllGather of the per-candidate returns
