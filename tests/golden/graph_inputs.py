@@ -1,0 +1,81 @@
+"""Deterministic INPUTS of the graph-wiring golden (shared by tests/golden/make_graph_golden.py, which feeds them to the
+reference's graph builder, and by the tests, which feed the same numbers to the oracle and to the HIP path).
+Everything here is input data: weights in variable-creation order, statistics, observations, and the random draws in the
+order and shapes the reference's graph consumes them."""
+import numpy as np
+
+CASES = {   # name: dict(env, E, p, m, n, H, hidden, cp_hidden, C, Hh, seed)
+    "hc_cadm_m2": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=10, m=2, n=56, H=3, hidden=(128,) * 4, cp_hidden=(24, 16, 8),
+                       C=10, Hh=3, B=2, seed=101),
+    "hc_cadm_m3": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=5, m=3, n=52, H=4, hidden=(128,) * 4, cp_hidden=(16, 8),
+                       C=10, Hh=2, B=2, seed=202),
+}
+
+
+def trunc_normal(rng, shape):
+    z = rng.standard_normal(shape)
+    bad = np.abs(z) >= 2.0
+    while bad.any():
+        z[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(z) >= 2.0
+    return z
+
+
+class Draws:
+    """The graph's random ops, in call order: standard (truncated) normals as float32."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed + 7)
+        self.log = []
+
+    def truncated(self, shape):
+        z = trunc_normal(self.rng, tuple(int(s) for s in shape)).astype(np.float32)
+        self.log.append(("truncated_normal", z))
+        return z
+
+    def normal(self, shape):
+        z = self.rng.standard_normal(tuple(int(s) for s in shape)).astype(np.float32)
+        self.log.append(("normal", z))
+        return z
+
+
+class Weights:
+    """tf.compat.v1.get_variable / tf.Variable in creation order.  Initial values are 'trained-like' (gain 2, small random
+    biases) so that biases and head scales matter; the reference's initialisers only decide SHAPES here."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.vars = []      # (name, array)
+
+    def dense(self, name, shape):
+        if name.endswith("_weight"):
+            v = trunc_normal(self.rng, shape) * (2.0 / (2.0 * np.sqrt(shape[1])))
+        else:
+            v = 0.1 * self.rng.standard_normal(shape)
+        v = v.astype(np.float32)
+        self.vars.append((name, v))
+        return v
+
+    def plain(self, name, value):
+        v = np.asarray(value, np.float32)
+        self.vars.append((name, v))
+        return v
+
+
+def make_inputs(case):
+    c = CASES[case]
+    rng = np.random.default_rng(c["seed"] + 1)
+    D, A, P, Hh, m, H, E, B = c["D"], c["A"], c["P"], c["Hh"], c["m"], c["H"], c["E"], c["B"]
+    f32 = lambda x: np.asarray(x, np.float32)
+    ms = lambda k: (f32(rng.standard_normal(k)), f32(rng.uniform(0.5, 2.0, k)))
+    st = {}
+    st["obs_mean"], st["obs_std"] = ms(P)
+    st["act_mean"], st["act_std"] = ms(A)
+    st["delta_mean"], st["delta_std"] = ms(D)
+    st["cp_obs_mean"], st["cp_obs_std"] = f32(np.zeros(D * Hh)), f32(np.ones(D * Hh))     # state_diff (dynamics.py:616-618)
+    st["cp_act_mean"], st["cp_act_std"] = ms(A * Hh)
+    st["back_delta_mean"], st["back_delta_std"] = ms(D)
+    return dict(stats=st, obs=f32(rng.standard_normal((m, D))), cp_obs=f32(0.1 * rng.standard_normal((m, D * Hh))),
+                cp_act=f32(rng.uniform(-1, 1, (m, A * Hh))), init_mean=f32(np.zeros((m, H, A))), init_var=f32(np.full((m, H, A), 0.25)),
+                bs_obs=f32(rng.standard_normal((E, B, D))), bs_act=f32(rng.uniform(-1, 1, (E, B, A))),
+                bs_cp_obs=f32(0.1 * rng.standard_normal((E, B, D * Hh))), bs_cp_act=f32(rng.uniform(-1, 1, (E, B, A * Hh))))

@@ -1,0 +1,101 @@
+"""The planner graph's WIRING pinned to the reference's own graph-building code: tests/golden/graph_golden.npz was written
+by /root/reference/cadm/dynamics/core/utils.py itself, imported unchanged and executed on a numpy-eager `tensorflow`
+stand-in (tests/golden/make_graph_golden.py says exactly what that does and does not prove).  Inputs (weights in
+variable-creation order, statistics, observations, random draws in the order the graph consumes them) are regenerated from
+tests/golden/graph_inputs.py; the oracle -- both formulations -- and the HIP planner must reproduce the reference's plan."""
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import graph_inputs as gi  # noqa: E402
+from oracle import envs as oenvs  # noqa: E402
+from oracle import nets as onets  # noqa: E402
+from oracle import planner as oplanner  # noqa: E402
+
+GOLD = np.load(os.path.join(HERE, "golden", "graph_golden.npz"))
+
+
+def rebuild(case):
+    """Inputs exactly as the generator fed them to the reference: (cp params, ff params, stats/inputs, z, eps_canonical)."""
+    c = gi.CASES[case]
+    W = gi.Weights(c["seed"])
+    nets = {"context_model": OrderedDict(), "ff_model": OrderedDict()}
+    for name, shp in zip(GOLD[case + "/var_names"], GOLD[case + "/var_shapes"]):
+        net, pname = str(name).split("/")
+        shape = tuple(int(s) for s in str(shp).split(","))
+        if pname.endswith(("_weight", "_bias")):
+            nets[net][pname] = W.dense(str(name), shape)
+        else:       # tf.Variable(np.ones([1, D]) / 2.) / tf.Variable(-np.ones([1, D]) * 10)  (core/utils.py:338-339)
+            nets[net][pname] = W.plain(str(name), np.ones(shape) / 2.0 if pname == "max_logvar" else -np.ones(shape) * 10)
+    draws = gi.Draws(c["seed"])
+    seq = []
+    for kind, shp in zip(GOLD[case + "/draw_kinds"], GOLD[case + "/draw_shapes"]):
+        shape = tuple(int(s) for s in str(shp).split(","))
+        seq.append((str(kind), draws.truncated(shape) if kind == "truncated_normal" else draws.normal(shape)))
+    E, p, m, n, H, D = c["E"], c["p"], c["m"], c["n"], c["H"], c["D"]
+    assert [k for k, _ in seq] == ["normal"] + (["truncated_normal"] + ["normal"] * H) * 5     # the graph's draw order
+    train_eps = seq[0][1]
+    z, eps = [], []
+    for it in range(5):
+        blk = seq[1 + it * (H + 1):1 + (it + 1) * (H + 1)]
+        z.append(blk[0][1])                                                       # [m, n, H, A]
+        # the graph draws the head noise in its member-major layout [E, (p/E)*m*n, D] = reshape of [p, m, n, D]
+        eps.append(np.stack([e.reshape(p, m, n, D).transpose(1, 2, 0, 3) for _, e in blk[1:]]))   # [H, m, n, p, D]
+    return c, nets, gi.make_inputs(case), np.stack(z), np.stack(eps), train_eps
+
+
+def test_variable_creation_order_is_the_checkpoint_order():
+    """save / load rely on tf.trainable_variables() = creation order (dynamics.py:266,571-588): context_model first, and
+    inside a dynamics net hidden_i_{weight,bias}, output_mu_*, output_logvar_*, max_logvar, min_logvar."""
+    from cadm_amd.engine import ctx_param_names, dyn_param_names
+    names = [str(x) for x in GOLD["hc_cadm_m2/var_names"]]
+    want = ["context_model/" + x for x in ctx_param_names(3)] + ["ff_model/" + x for x in dyn_param_names(4)]
+    assert names == want
+
+
+@pytest.mark.parametrize("case", sorted(gi.CASES))
+def test_oracle_reproduces_the_reference_graph(case):
+    c, nets, inp, z, eps, train_eps = rebuild(case)
+    env, st = oenvs.make_env(c["env"]), inp["stats"]
+    cp, ff = nets["context_model"], nets["ff_model"]
+    ctx = onets.context_forward(cp, inp["cp_obs"], inp["cp_act"], st)
+    np.testing.assert_allclose(ctx, GOLD[case + "/context"], rtol=1e-5, atol=1e-6)
+    # training-graph forward on the [E, B, .] batch (core/utils.py:372-381): heads before the noise
+    bs_cp = onets.context_forward_bs(cp, inp["bs_cp_obs"], inp["bs_cp_act"], st)
+    np.testing.assert_allclose(bs_cp, GOLD[case + "/bs_cp"], rtol=1e-5, atol=1e-6)
+    x = np.concatenate([onets.normalize(env.obs_preproc(inp["bs_obs"]), st["obs_mean"], st["obs_std"]),
+                        onets.normalize(inp["bs_act"], st["act_mean"], st["act_std"]), bs_cp], axis=-1)
+    out, mu, lv = onets.dynamics_forward(ff, x, st["delta_mean"], st["delta_std"], train_eps, False)
+    np.testing.assert_allclose(mu, GOLD[case + "/train_mu"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lv, GOLD[case + "/train_logvar"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out, GOLD[case + "/train_output"], rtol=1e-5, atol=1e-5)
+    # the unrolled CEM planner, both formulations of the oracle (literal tile/transpose/reshape chain and index-mapped)
+    for form in ("literal", "indexed"):
+        plan = oplanner.cem_plan(env, ff, cp, st, inp["obs"], inp["cp_obs"], inp["cp_act"], inp["init_mean"], inp["init_var"], z, eps,
+                                 c["E"], c["p"], formulation=form)
+        err = np.abs(plan - GOLD[case + "/plan"]).max()
+        assert err <= 1e-5, "%s formulation: plan differs from the reference graph's by %.2e" % (form, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(gi.CASES))
+def test_hip_planner_reproduces_the_reference_graph(gpu, case):
+    from cadm_amd import planner as hplanner
+    from cadm_amd.engine import HipEngine
+    c, nets, inp, z, eps, _ = rebuild(case)
+    eng = HipEngine(c["env"], c["E"], c["p"], c["D"], c["A"], c["P"], c["C"], c["hidden"], c["H"], history_length=c["Hh"],
+                    cp_hidden_sizes=c["cp_hidden"])
+    eng.set_net("context_model", nets["context_model"])
+    eng.set_net("ff_model", nets["ff_model"])
+    eng.set_stats(inp["stats"])
+    ctx = eng.context_forward(inp["cp_obs"], inp["cp_act"]).cpu().numpy()
+    np.testing.assert_allclose(ctx, GOLD[case + "/context"], rtol=2e-5, atol=2e-6)
+    plan = hplanner.cem_plan(eng, inp["obs"], inp["cp_obs"], inp["cp_act"], inp["init_mean"], inp["init_var"], c["n"],
+                             z=eng._t(z), eps=eng._t(eps)).cpu().numpy()
+    ref = np.clip(GOLD[case + "/plan"], -1.0, 1.0)            # get_action's clip (dynamics.py:365-366)
+    assert np.abs(plan - ref).max() <= 2e-4, np.abs(plan - ref).max()
