@@ -50,6 +50,7 @@ __global__ void history_update_kernel(const float* __restrict__ obs, const float
 extern "C" int cadm_warm_start_shift(cadm_ctx* ctx, const float* plan, int m, float* prev_sol_io, float* action_out,
                                      void* stream) {
     CADM_REQUIRE(ctx && plan && prev_sol_io && action_out && m > 0, "cadm_warm_start_shift: bad arguments");
+    CADM_ON_DEVICE(ctx);
     const int total = m * ctx->H * ctx->A;
     hipLaunchKernelGGL(warm_start_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, plan, m, ctx->H, ctx->A,
                        prev_sol_io, action_out);
@@ -62,6 +63,7 @@ extern "C" int cadm_history_update(cadm_ctx* ctx, const float* obs, const float*
                                    float* hist_act_io, float* prev_sol_io, void* stream) {
     CADM_REQUIRE(ctx && obs && next_obs && action && counts_io && hist_obs_io && hist_act_io && m > 0,
                  "cadm_history_update: bad arguments");
+    CADM_ON_DEVICE(ctx);
     CADM_REQUIRE(ctx->cfg.history_length > 0, "cadm_history_update: model has no history window");
     hipLaunchKernelGGL(history_update_kernel, dim3(m), dim3(64), 0, (hipStream_t)stream, obs, next_obs, action, done, ctx->D,
                        ctx->A, ctx->cfg.history_length, ctx->H, state_diff, counts_io, hist_obs_io, hist_act_io, prev_sol_io);

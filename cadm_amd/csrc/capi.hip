@@ -152,11 +152,13 @@ extern "C" int cadm_set_logvar_bounds(cadm_ctx* ctx, int net, float* max_logvar,
 
 extern "C" int cadm_repack(cadm_ctx* ctx, void* stream) {
     CADM_REQUIRE(ctx, "cadm_repack: null ctx");
+    CADM_ON_DEVICE(ctx);
     return cadm_pack_streams(ctx, (hipStream_t)stream);
 }
 
 extern "C" int cadm_set_norm_stats(cadm_ctx* ctx, const float* const host_stats[12], void* stream) {
     CADM_REQUIRE(ctx && host_stats, "cadm_set_norm_stats: null argument");
+    CADM_ON_DEVICE(ctx);
     const int Hh = ctx->cfg.history_length;
     float* dst[12] = {ctx->st.obs_mean, ctx->st.obs_std, ctx->st.act_mean, ctx->st.act_std, ctx->st.delta_mean,
                       ctx->st.delta_std, ctx->st.cp_obs_mean, ctx->st.cp_obs_std, ctx->st.cp_act_mean,
@@ -182,6 +184,7 @@ static int require_ready(cadm_ctx* ctx, const char* who) {
 extern "C" int cadm_context_forward(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs,
                                     float* ctx_out, void* stream) {
     CADM_REQUIRE(ctx && cp_obs && cp_act && ctx_out && m > 0, "cadm_context_forward: bad arguments");
+    CADM_ON_DEVICE(ctx);
     CADM_REQUIRE(ctx->C > 0, "cadm_context_forward: model has no context encoder");
     if (!ctx->st.set) { cadm_set_error("cadm_context_forward: normalisation stats not set"); return CADM_ESTATE; }
     return cadm_launch_context(ctx, cp_obs, cp_act, m, bs, ctx_out, (hipStream_t)stream);
@@ -192,6 +195,7 @@ extern "C" int cadm_rollout_returns(cadm_ctx* ctx, const float* obs, const float
                                     uint32_t call, int it, int cand_offset, int n_global, int m, int n_local,
                                     float* returns_rows, float* traj_out, void* stream) {
     CADM_REQUIRE(ctx && obs && actions && returns_rows, "cadm_rollout_returns: null argument");
+    CADM_ON_DEVICE(ctx);
     CADM_REQUIRE(m > 0 && n_local > 0 && cand_offset >= 0 && cand_offset + n_local <= n_global,
                  "cadm_rollout_returns: bad candidate range [%d, %d) of %d", cand_offset, cand_offset + n_local, n_global);
     CADM_REQUIRE(ctx->C == 0 || ctx_vec, "cadm_rollout_returns: ctx_vec required for a context model");
@@ -284,6 +288,7 @@ extern "C" int cadm_cem_plan(cadm_ctx* ctx, const float* obs, const float* cp_ob
                              uint32_t call, void* workspace, float* plan_out, void* stream) {
     CADM_REQUIRE(ctx && obs && init_mean && init_var && workspace && plan_out && m > 0 && n > 0,
                  "cadm_cem_plan: bad arguments");
+    CADM_ON_DEVICE(ctx);
     CADM_REQUIRE(ctx->C == 0 || (cp_obs && cp_act), "cadm_cem_plan: cp_obs/cp_act required for a context model");
     hipStream_t s = (hipStream_t)stream;
     PlanWs w;
@@ -323,6 +328,7 @@ extern "C" int cadm_rs_plan(cadm_ctx* ctx, const float* obs, const float* cp_obs
                             uint32_t seed, uint32_t call, void* workspace, float* action_out, int32_t* raw_best_out,
                             void* stream) {
     CADM_REQUIRE(ctx && obs && workspace && action_out && m > 0 && n > 0, "cadm_rs_plan: bad arguments");
+    CADM_ON_DEVICE(ctx);
     CADM_REQUIRE(ctx->C == 0 || (cp_obs && cp_act), "cadm_rs_plan: cp_obs/cp_act required for a context model");
     CADM_REQUIRE(!ctx->cfg.discrete || raw_best_out, "cadm_rs_plan: raw_best_out required for discrete actions");
     hipStream_t s = (hipStream_t)stream;

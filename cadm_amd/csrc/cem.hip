@@ -331,6 +331,7 @@ extern "C" int cadm_sample_actions(cadm_ctx* ctx, const float* mean, const float
                                    uint32_t seed, uint32_t call, int it, int m, int n_global,
                                    float* actions_out, void* stream) {
     CADM_REQUIRE(ctx && mean && var && actions_out && m > 0 && n_global > 0, "cadm_sample_actions: bad arguments");
+    CADM_ON_DEVICE(ctx);
     const size_t total = (size_t)m * n_global * ctx->H * ctx->A;
     hipLaunchKernelGGL(sample_actions_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, mean, var, z,
                        seed, call, it, m, n_global, ctx->H, ctx->A, ctx->cfg.lower_bound, ctx->cfg.upper_bound, actions_out);
@@ -341,6 +342,7 @@ extern "C" int cadm_sample_actions(cadm_ctx* ctx, const float* mean, const float
 extern "C" int cadm_sample_uniform(cadm_ctx* ctx, uint32_t seed, uint32_t call, int m, int n_global,
                                    float* actions_out, int32_t* raw_out, void* stream) {
     CADM_REQUIRE(ctx && actions_out && m > 0 && n_global > 0, "cadm_sample_uniform: bad arguments");
+    CADM_ON_DEVICE(ctx);
     const size_t total = (size_t)m * n_global * ctx->H * (ctx->cfg.discrete ? 1 : ctx->A);
     hipLaunchKernelGGL(sample_uniform_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, seed, call, m,
                        n_global, ctx->H, ctx->A, ctx->cfg.discrete, actions_out, raw_out);
@@ -351,6 +353,7 @@ extern "C" int cadm_sample_uniform(cadm_ctx* ctx, uint32_t seed, uint32_t call, 
 extern "C" int cadm_particle_mean(cadm_ctx* ctx, const float* returns_rows, int m, int n_local,
                                   float* cand_returns, void* stream) {
     CADM_REQUIRE(ctx && returns_rows && cand_returns && m > 0 && n_local > 0, "cadm_particle_mean: bad arguments");
+    CADM_ON_DEVICE(ctx);
     const int total = m * n_local;
     hipLaunchKernelGGL(particle_mean_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, returns_rows,
                        total, ctx->p, cand_returns);
@@ -394,6 +397,7 @@ extern "C" int cadm_cem_refit(cadm_ctx* ctx, const float* cand_returns, int G, i
                               int m, float* mean_io, float* var_io, int32_t* elites_out, void* stream) {
     CADM_REQUIRE(ctx && cand_returns && actions && mean_io && var_io && G > 0 && n_local > 0 && m > 0,
                  "cadm_cem_refit: bad arguments");
+    CADM_ON_DEVICE(ctx);
     return cadm_launch_refit(ctx, cand_returns, nullptr, G, n_local, actions, m, mean_io, var_io, mean_io, var_io, elites_out,
                              nullptr, (hipStream_t)stream);
 }
@@ -402,6 +406,7 @@ extern "C" int cadm_rs_select(cadm_ctx* ctx, const float* cand_returns, int G, i
                               int m, float* first_action_out, int32_t* best_out, void* stream) {
     CADM_REQUIRE(ctx && cand_returns && actions && first_action_out && G > 0 && n_local > 0 && m > 0,
                  "cadm_rs_select: bad arguments");
+    CADM_ON_DEVICE(ctx);
     hipLaunchKernelGGL(rs_select_kernel, dim3(m), dim3(256), 0, (hipStream_t)stream, cand_returns, G, n_local, actions,
                        m, ctx->H, ctx->A, first_action_out, best_out);
     CADM_CHECK_HIP(hipGetLastError());

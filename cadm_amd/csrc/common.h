@@ -121,6 +121,20 @@ struct cadm_ctx {
     int nranks = 1, rank = 0;
 };
 
+// Entry points launch on the ctx's device whatever device the caller's thread has current (two engines on different GPUs in
+// one process; the ctor's `device=` kwarg), and restore the caller's device on return.
+struct CadmDeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit CadmDeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~CadmDeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    CadmDeviceGuard(const CadmDeviceGuard&) = delete;
+    CadmDeviceGuard& operator=(const CadmDeviceGuard&) = delete;
+};
+#define CADM_ON_DEVICE(ctx) CadmDeviceGuard cadm_device_guard_((ctx)->device)
+
 // kernels' host launchers (one per translation unit)
 int cadm_pack_streams(cadm_ctx* ctx, hipStream_t s);
 int cadm_pack_xdl(cadm_ctx* ctx, hipStream_t s);

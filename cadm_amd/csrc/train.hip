@@ -952,6 +952,7 @@ static int ensure_state(cadm_ctx* ctx) {
 
 extern "C" int cadm_train_configure(cadm_ctx* ctx, const cadm_train_hparams* hp, int max_batch) {
     CADM_REQUIRE(ctx && hp, "cadm_train_configure: null argument");
+    CADM_ON_DEVICE(ctx);
     for (auto& d : ctx->ff) CADM_REQUIRE(d.W && d.b, "cadm_train_configure: ff_model weights not registered");
     if (ctx->cfg.back_model) for (auto& d : ctx->back) CADM_REQUIRE(d.W && d.b, "cadm_train_configure: backward_model weights not registered");
     if (ctx->C > 0) for (auto& d : ctx->cp) CADM_REQUIRE(d.W && d.b, "cadm_train_configure: context_model weights not registered");
@@ -966,6 +967,7 @@ extern "C" int cadm_train_configure(cadm_ctx* ctx, const cadm_train_hparams* hp,
 
 extern "C" int cadm_train_reset(cadm_ctx* ctx, void* stream) {
     CADM_REQUIRE(ctx && ctx->train, "cadm_train_reset: training not configured");
+    CADM_ON_DEVICE(ctx);
     TrainState* t = ctx->train;
     size_t total = 0;
     for (auto* v : {&t->a_ff, &t->a_bk, &t->a_cp}) for (auto& s : *v) total += 2 * s.n;
@@ -1301,6 +1303,7 @@ extern "C" int cadm_train_step_rows(cadm_ctx* ctx, const float* ds_obs, const fl
 extern "C" int cadm_predict(cadm_ctx* ctx, const float* obs, const float* act, const float* cp_obs, const float* cp_act,
                             int B, float* mu_out, float* logvar_out, void* stream) {
     CADM_REQUIRE(ctx && obs && act && mu_out && B > 0, "cadm_predict: bad arguments");
+    CADM_ON_DEVICE(ctx);
     CADM_REQUIRE(ctx->st.set, "cadm_predict: normalisation stats not set");
     CADM_REQUIRE(ctx->C == 0 || (cp_obs && cp_act), "cadm_predict: cp_obs / cp_act required (context model)");
     for (auto& d : ctx->ff) CADM_REQUIRE(d.W && d.b, "cadm_predict: ff_model weights not registered");
