@@ -28,7 +28,7 @@ int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, 
     a.xw = ctx->xw;
     a.xw_bytes = (unsigned)((size_t)ctx->xg.member_frags() * CADM_XDL_FRAG_BYTES * ctx->E);
     a.xw_member_b = (unsigned)((size_t)ctx->xg.member_frags() * CADM_XDL_FRAG_BYTES);
-    for (int w = 0, off = 0; w < 4; ++w) { a.xw_wave_b[w] = (unsigned)off; off += ctx->xg.wave_frags(w) * CADM_XDL_FRAG_BYTES; }
+    for (int w = 0, off = 0; w < CADM_XDL_WAVES; ++w) { a.xw_wave_b[w] = (unsigned)off; off += ctx->xg.wave_frags(w) * CADM_XDL_FRAG_BYTES; }
     a.xb = ctx->xb;
     a.xb_member = (size_t)ctx->xg.bias_tiles() * 256;
     a.bmember = ctx->bstream_member_floats;

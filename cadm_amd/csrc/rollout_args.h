@@ -8,7 +8,7 @@ struct RolloutArgs {
     unsigned wmember_b;               // bytes per member
     unsigned w_l0_b, w_lh_b, w_lo_b;  // layer stream sizes (bytes): L0, hidden, OUT
     const unsigned short* xw;         // split-f16 fragment stream (xdl kernel)
-    unsigned xw_bytes, xw_member_b, xw_wave_b[4];
+    unsigned xw_bytes, xw_member_b, xw_wave_b[8];
     const float* xb;                  // its bias tiles
     size_t xb_member;
     size_t bmember;                   // bias floats per member

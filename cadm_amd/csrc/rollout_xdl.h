@@ -9,15 +9,16 @@
 // f16 numbers (xdl_geo.h): 3 f16 MFMAs per 16x16x32 block with fp32 accumulation reproduce the fp32 product to 2^-22.
 //
 // Mapping:
-//   * workgroup = 4 waves (one per SIMD, 512 VGPRs each) = 16 rows of ONE ensemble member; a workgroup walks over
-//     row tiles grp, grp + wgs_per_member, ..  of its member (one tile at BASELINE cfg2);
+//   * workgroup = 8 waves (two per SIMD, 256 registers each) = 16 rows of ONE ensemble member; a workgroup walks over
+//     row tiles grp, grp + wgs_per_member, ..  of its member (one tile at BASELINE cfg2).  Two waves per SIMD: while one
+//     waits (LDS operand loads, the weight stream, an epilogue's exp/rcp chain) the other one's MFMAs run;
 //   * a layer is evaluated transposed, OUT^T = W^T IN^T: weights are the A operand (streamed from L2 in consumption
 //     order through a register ring), the 16 rows are the B / D columns.  A lane's D fragments of tiles (2c, 2c+1) are
 //     its B fragment of chunk c of the next layer: activations cross layers through LDS with lane-linear accesses;
-//   * wave w owns BASE + (w < EXTRA) hidden tiles and computes them two at a time over the whole K (the B operand of
-//     a layer sits in registers), so a tile pair's epilogue (bias, swish, f16 split, LDS store) runs in the shadow of
-//     the next pair's MFMAs;
-//   * the rollout state lives in registers of the 256 "feature threads" exactly as in the fp32 kernel.
+//   * wave w owns BASE + (w < EXTRA) hidden tiles and computes them two at a time over the whole K (the B operand is
+//     read chunk by chunk from LDS, three chunks ahead); a tile pair's epilogue (swish, f16 split, LDS store) runs in
+//     the shadow of the next pair's MFMAs or, for the last pair, of the SIMD's other wave;
+//   * the rollout state lives in registers of the 256 "feature threads" (waves 0-3) exactly as in the fp32 kernel.
 #include "rollout_args.h"
 #include "rollout_env.h"
 #include "xdl_geo.h"
@@ -41,14 +42,16 @@ struct XC {
     static constexpr int NT = (HID + 15) / 16;            // hidden tiles
     static constexpr int NCH = (NT + 1) / 2;              // chunks of a layer that consumes a hidden layer
     static constexpr int NTO = (D + 7) / 8;               // head tiles (8 dims: mu | lv)
-    static constexpr int BASE = NT / 4, EXTRA = NT % 4;
-    static constexpr int NTOW = (NTO + 3) / 4;            // head tile slots per wave
+    static constexpr int NW = CADM_XDL_WAVES, NTHR = NW * 64;
+    static constexpr int BASE = NT / NW, EXTRA = NT % NW;
+    static constexpr int NTOW = (NTO + NW - 1) / NW;      // head tile slots per wave
+    static_assert(NTOW == 1, "one head tile per wave at most (obs dim <= 64)");
     static constexpr int R = CADM_XDL_RING;               // ring depth (fragments)
     // products per 16x16x32 block: hi += w1 x1, lo += w2 x1 + w1 x2 [, ll += w2 x2].  The dropped w2 x2 term is 2^-22 of a
     // product; wide layers (K > 256) accumulate enough of them to show at the 1e-5 parity bar, so they take the 4th product.
     static constexpr int NPROD = HID > 256 ? 4 : 3;
     static constexpr int NP = (D + 1) / 2, NPI = (NP + 15) / 16, NAI = (A + 15) / 16;
-    static_assert(BASE >= 1, "hidden width too small for the 4-wave tile split");
+    static_assert(BASE >= 1, "hidden width too small for the 8-wave tile split (>= 128)");
     // LDS carve (bytes)
     static constexpr int XIN = 0;                                  // [2 parts][NC0][64 lanes] x 16 B
     static constexpr int ACTA = XIN + 2 * NC0 * 1024;              // [2][NCH][64] x 16 B
@@ -68,19 +71,20 @@ struct XC {
 #define CADM_XDL_RES 1
 #endif
     // register-resident weights (loaded once per workgroup, never re-read from L2): hidden layer 1 on every wave and
-    // the head tiles on the waves that own BASE hidden tiles -- ~224 of a wave's 512 registers at HID = 200.
-    // AGPR budget: 256 = resident fragments (8 each) + the ring (the compiler keeps it in AGPRs) + what hipcc parks
-    // there itself; RES_FRAGS leaves room for those (tests/test_abi.py checks the ISA for AGPR<->VGPR shuffles of
-    // resident fragments, which would also be an undetected MFMA operand hazard).
+    // the head tile on the waves that own BASE hidden tiles -- ~100 of a wave's 256 registers at HID = 200.
+    // RES_FRAGS leaves room for the ring, the accumulators and what hipcc parks in AGPRs itself
+    // (tests/test_isa_hygiene.py checks the ISA for AGPR<->VGPR shuffles of resident fragments, which would also be an
+    // undetected MFMA operand hazard).
 #ifndef CADM_XDL_RES_FRAGS
-#define CADM_XDL_RES_FRAGS 28       // waves with BASE hidden tiles
+#define CADM_XDL_RES_FRAGS 14       // waves with BASE hidden tiles
 #endif
 #ifndef CADM_XDL_RES_FRAGS_X
-#define CADM_XDL_RES_FRAGS_X 24     // waves with BASE + 1 hidden tiles (more accumulators / epilogue state live)
+#define CADM_XDL_RES_FRAGS_X 12     // waves with BASE + 1 hidden tiles (more accumulators / epilogue state live)
 #endif
-    // (wide layers keep their whole B operand, 16 * NCH registers, live: no room for resident weights)
     static constexpr bool ASM_MFMA = CADM_XDL_RES && NCH <= 8;     // asm MFMAs (AGPR-resident operands) vs builtins
-    static constexpr int res_frags(int ntw) { return (!CADM_XDL_RES || NCH > 8) ? 0 : ntw == BASE ? CADM_XDL_RES_FRAGS : CADM_XDL_RES_FRAGS_X; }
+    static constexpr int res_frags(int ntw) {      // (wide observations keep two pair slots of rollout state per thread)
+        return (!CADM_XDL_RES || NCH > 8) ? 0 : (ntw == BASE ? CADM_XDL_RES_FRAGS : CADM_XDL_RES_FRAGS_X) - (NPI > 1 ? 2 : 0);
+    }
     static constexpr int MAX_NH_LDS = 4;
     static constexpr int BIAS_BYTES = (MAX_NH_LDS * NT + NTO) * 1024;
     static constexpr bool BIAS_LDS = CTRL + 16 * 64 * 4 + BIAS_BYTES <= 150 * 1024;
@@ -137,42 +141,44 @@ __device__ __forceinline__ void xsplit(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)fmaf((float)hi, -2048.0f, v * 2048.0f);
 }
 
-// Epilogue of a hidden tile: bias, swish, f16 split, store as (half of) a B fragment of the next layer.  Cut in STAGES of
-// mutually independent instructions (stage s of every value before stage s+1 of any): a wave issues in order, so a VALU
-// op waiting for its predecessor's result (v_exp -> v_add -> v_rcp ..) would hold up the MFMAs queued behind it.
+// Epilogue of a hidden tile: swish, f16 split, store as (half of) a B fragment of the next layer (the bias tile is the
+// accumulator's initial value).  Cut in STAGES of mutually independent instructions (stage s of every value before
+// stage s+1 of any): a wave issues in order, so a VALU op waiting for its predecessor's result (v_exp -> v_add -> v_rcp ..)
+// would hold up the MFMAs queued behind it.
 template <class G>
 struct XHiddenEpi {
-    static constexpr int NSTAGE = 7;
-    struct State { floatx4 b, v, s; f16x4 h1, h2; };
+    static constexpr int NSTAGE = 6;
+    struct State { floatx4 v, s; f16x4 h1, h2; };
     unsigned char* xsmem;
     const float* xb;
     int bias_off;
     int layer, out, tstart, lane;
+    __device__ __forceinline__ floatx4 init(int ti) const {       // bias tile (fp32, D layout) of local tile ti
+        const int bt = (layer * G::NT + tstart + ti) * 64 + lane;
+        // (a select between an LDS and a global POINTER would become a flat load with a full vmcnt/lgkmcnt drain)
+        if constexpr (G::BIAS_LDS) return *reinterpret_cast<const floatx4*>(xsmem + bias_off + bt * 16);
+        else return *reinterpret_cast<const floatx4*>(xb + bt * 4);
+    }
     template <int S>
     __device__ __forceinline__ void stage(int ti, const floatx4& hi, const floatx4& lo, const floatx4& ll, State& st) const {
-        if constexpr (S == 0) {            // bias tile of this output tile
-            const int bt = (layer * G::NT + tstart + ti) * 64 + lane;
-            // (a select between an LDS and a global POINTER would become a flat load with a full vmcnt/lgkmcnt drain)
-            if constexpr (G::BIAS_LDS) st.b = *reinterpret_cast<const floatx4*>(xsmem + bias_off + bt * 16);
-            else st.b = *reinterpret_cast<const floatx4*>(xb + bt * 4);
-        } else if constexpr (S == 1) {     // pre-activation (hi + 2^-11 lo + bias), f16-range clamp, exp2 argument
+        if constexpr (S == 0) {            // pre-activation (hi + 2^-11 lo), f16-range clamp, exp2 argument
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float pre = fmaf(lo[r], 4.8828125e-4f, hi[r] + st.b[r]);
+                float pre = fmaf(lo[r], 4.8828125e-4f, hi[r]);
                 if constexpr (G::NPROD == 4) pre = fmaf(ll[r], 2.384185791015625e-7f, pre);
                 st.v[r] = fminf(pre, 60000.0f);
                 st.s[r] = st.v[r] * -1.4426950408889634f;
             }
-        } else if constexpr (S == 2) {
+        } else if constexpr (S == 1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) st.s[r] = __builtin_amdgcn_exp2f(st.s[r]);
-        } else if constexpr (S == 3) {
+        } else if constexpr (S == 2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) st.s[r] = __builtin_amdgcn_rcpf(1.0f + st.s[r]);
-        } else if constexpr (S == 4) {     // swish (dynamics.py:23) and the high f16 part
+        } else if constexpr (S == 3) {     // swish (dynamics.py:23) and the high f16 part
 #pragma unroll
             for (int r = 0; r < 4; ++r) { st.v[r] = st.v[r] * st.s[r]; st.h1[r] = (_Float16)st.v[r]; }
-        } else if constexpr (S == 5) {     // low part: (h - hi) * 2^11, exact in fp32
+        } else if constexpr (S == 4) {     // low part: (h - hi) * 2^11, exact in fp32
 #pragma unroll
             for (int r = 0; r < 4; ++r) st.h2[r] = (_Float16)fmaf((float)st.h1[r], -2048.0f, st.v[r] * 2048.0f);
         } else {
@@ -184,23 +190,50 @@ struct XHiddenEpi {
     }
 };
 
-// One hidden-type layer sweep of this wave: NTW tiles x NCHL chunks, tiles two at a time.
+// Epilogue of a head tile (mu0 mu1 lv0 lv1 of 2 dims per lane): recombine and hand to the state phase through LDS.
+template <class G>
+struct XHeadEpi {
+    static constexpr int NSTAGE = 1;
+    struct State {};
+    unsigned char* xsmem;
+    const float* xb;
+    int bias_off, bias_tile, ht, lane;
+    __device__ __forceinline__ floatx4 init(int) const {
+        const int bt = bias_tile * 64 + lane;
+        if constexpr (G::BIAS_LDS) return *reinterpret_cast<const floatx4*>(xsmem + bias_off + bt * 16);
+        else return *reinterpret_cast<const floatx4*>(xb + bt * 4);
+    }
+    template <int S>
+    __device__ __forceinline__ void stage(int, const floatx4& hi, const floatx4& lo, const floatx4& ll, State&) const {
+        floatx4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = fmaf(lo[r], 4.8828125e-4f, hi[r]);
+            if constexpr (G::NPROD == 4) v[r] = fmaf(ll[r], 2.384185791015625e-7f, v[r]);
+        }
+        *reinterpret_cast<floatx4*>(xsmem + G::OFULL + (ht * 64 + lane) * 16) = v;
+    }
+};
+
+// One layer sweep of this wave: NTW tiles x NCHL chunks, tiles two at a time.
 //   The first NRES fragments (consumption order) are register-resident (res[j][part], AGPRs, loaded once per workgroup);
 //   the other NFS = NF - NRES come through the ring: it holds streamed fragments 0..R-1 of this layer on entry and 0..R-1
 //   of the NEXT streamed layer (nx_nf of them exist) on exit.  wcur = byte offset of this layer's first STREAMED fragment.
+//   The B operand (the 16 rows' activations) is read from LDS chunk by chunk, XD-1 chunks ahead of its use.
 //   The epilogue of a tile group runs stage by stage between the MFMAs of the NEXT group (f16 MFMAs hide independent
-//   VALU work of the same wave); only the last group's epilogue is exposed.
+//   VALU work of the same wave); the last group's epilogue overlaps with the SIMD's other wave.
 template <class G, int NTW, int NCHL, int NRES, class Epi>
 __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2], __amdgpu_buffer_rsrc_t rsrc, unsigned wcur,
                                           unsigned wnext, int nx_nf, const unsigned char* lds_in, int lane, const Epi& epi) {
     constexpr int R = G::R, NF = NTW * NCHL, NFS = NF - NRES, NFSPAD = rup(NFS, R);
     static_assert(NRES >= 0 && NRES <= NF, "bad resident fragment count");
-    f16x8 X1[NCHL], X2[NCHL];
-#pragma unroll
-    for (int c = 0; c < NCHL; ++c) {
-        X1[c] = *reinterpret_cast<const f16x8*>(lds_in + ((0 * NCHL + c) * 64 + lane) * 16);
-        X2[c] = *reinterpret_cast<const f16x8*>(lds_in + ((1 * NCHL + c) * 64 + lane) * 16);
-    }
+    constexpr int XD = NCHL < 3 ? NCHL : 3;
+    f16x8 X1[XD], X2[XD];
+    auto xload = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        X1[c % XD] = *reinterpret_cast<const f16x8*>(lds_in + ((0 * NCHL + c) * 64 + lane) * 16);
+        X2[c % XD] = *reinterpret_cast<const f16x8*>(lds_in + ((1 * NCHL + c) * 64 + lane) * 16);
+    };
     auto prefetch = [&](auto jsc) {      // after streamed time slot js: refill its ring slot
         constexpr int js = decltype(jsc)::value;
         constexpr int jj = js + R;
@@ -214,26 +247,28 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
     constexpr int NPR = G::NPROD;
     floatx4 hi[2][2], lo[2][2], ll[2][2];   // [group parity][tile of the group]: the previous group's pair is being finished
     typename Epi::State pst[2];             // as side work while this group's accumulates (no register moves in between)
-    // stage s of the side epilogue goes to chunk 0 (s = 0: only the bias load, no accumulator read) or to chunks >= 1,
-    // i.e. at least one chunk of MFMAs after the accumulators were last written (the compiler cannot see asm MFMA latency)
-    auto stage_chunk = [](int st) constexpr { return st == 0 || NCHL == 1 ? 0 : 1 + (st - 1) * (NCHL - 1) / (NST - 1); };
+    // stage s of the side epilogue goes to chunks >= 1, i.e. at least one chunk of MFMAs after the accumulators were
+    // last written (the compiler cannot see asm MFMA latency)
+    auto stage_chunk = [](int st) constexpr { return NCHL == 1 ? 0 : NST == 1 ? 1 : 1 + st * (NCHL - 2) / (NST - 1); };
     static_for(std::make_integer_sequence<int, NG>{}, [&](auto gc) {
         constexpr int g = decltype(gc)::value, gp = g & 1, pp = gp ^ 1;
         constexpr int gs = (NTW - 2 * g) < 2 ? (NTW - 2 * g) : 2;
         constexpr int pgs = g > 0 ? 2 : 0;                       // tiles of the previous group (groups before the last are full)
+        static_for(std::make_integer_sequence<int, XD - 1>{}, [&](auto cc) { xload(cc); });
 #pragma unroll
         for (int k = 0; k < gs; ++k) {
-            hi[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f}; lo[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f}; ll[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f};
+            hi[gp][k] = epi.init(2 * g + k); lo[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f}; ll[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int k = 0; k < gs; ++k) xdl_operand_nops(hi[gp][k], lo[gp][k], ll[gp][k]);      // VALU-zeroed accumulators -> MFMA srcC
         static_for(std::make_integer_sequence<int, NCHL>{}, [&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int j0 = 2 * g * NCHL + c * gs;
+            if constexpr (c + XD - 1 < NCHL) xload(std::integral_constant<int, c + XD - 1>{});
             static_for(std::make_integer_sequence<int, NPR * gs>{}, [&](auto mc) {      // hi(k).. lo(k).. lo'(k).. [ll(k)..]
                 constexpr int k = decltype(mc)::value % gs, prod = decltype(mc)::value / gs, j = j0 + k;
                 floatx4& acc = prod == 0 ? hi[gp][k] : prod == 3 ? ll[gp][k] : lo[gp][k];
-                const f16x8& x = prod >= 2 ? X2[c] : X1[c];
+                const f16x8& x = prod >= 2 ? X2[c % XD] : X1[c % XD];
                 constexpr int part = (prod == 1 || prod == 3) ? 1 : 0;
                 if constexpr (j < NRES) xmfma_res(acc, res[j][part], x);
                 else xmfma_ring<G::ASM_MFMA>(acc, ring.w[(j - NRES) % R][part], x);
@@ -242,16 +277,18 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
                 constexpr int j = j0 + decltype(kc)::value;
                 if constexpr (j >= NRES) prefetch(std::integral_constant<int, j - NRES>{});
             });
-            static_for(std::make_integer_sequence<int, NST>{}, [&](auto sc) {
-                constexpr int st = decltype(sc)::value;
-                if constexpr (pgs > 0 && stage_chunk(st) == c) {
+            if constexpr (pgs > 0) {
+                static_for(std::make_integer_sequence<int, NST>{}, [&](auto sc) {
+                    constexpr int st = decltype(sc)::value;
+                    if constexpr (stage_chunk(st) == c) {
 #pragma unroll
-                    for (int k = 0; k < pgs; ++k) epi.template stage<st>(2 * (g - 1) + k, hi[pp][k], lo[pp][k], ll[pp][k], pst[k]);
-                }
-            });
+                        for (int k = 0; k < pgs; ++k) epi.template stage<st>(2 * (g - 1) + k, hi[pp][k], lo[pp][k], ll[pp][k], pst[k]);
+                    }
+                });
+            }
             __builtin_amdgcn_sched_barrier(0);      // pin the software pipeline: no load hoisting across chunks
         });
-        if constexpr (g == NG - 1) {                // the last group's epilogue has no MFMAs left to hide behind
+        if constexpr (g == NG - 1) {                // the last group's epilogue has no MFMAs of this wave left to hide behind
 #pragma unroll
             for (int k = 0; k < gs; ++k) xdl_result_nops(hi[gp][k], lo[gp][k], ll[gp][k]);
             static_for(std::make_integer_sequence<int, NST>{}, [&](auto sc) {
@@ -281,22 +318,23 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     const int e = blockIdx.x / a.wgs_per_member;
     const int grp = blockIdx.x % a.wgs_per_member;
     const int H = a.H;
-    const int arow = tid & 15, fg = tid >> 4;
+    const int arow = tid & 15, fg = (tid >> 4) & 15;
+    const bool feat = wave < 4;                 // the 256 feature threads (rollout state, input assembly)
     const int ntiles = (a.rows_per_member + 15) / 16;
 
     // ---- once per workgroup: stats, zero padding of the operand buffers ----
-    for (int i = tid; i < P; i += 256) {
+    for (int i = tid; i < P; i += G::NTHR) {
         stats[G::ST_OBS_MEAN + i] = a.obs_mean[i];
         stats[G::ST_OBS_DEN + i] = 1.0f / (a.obs_std[i] + 1e-10f);
     }
-    for (int i = tid; i < A; i += 256) {
+    for (int i = tid; i < A; i += G::NTHR) {
         stats[G::ST_ACT_MEAN + i] = a.act_mean[i];
         stats[G::ST_ACT_DEN + i] = 1.0f / (a.act_std[i] + 1e-10f);
     }
-    for (int i = tid; i < (G::OFULL - G::XIN) / 16; i += 256) reinterpret_cast<uintx4*>(xsmem + G::XIN)[i] = uintx4{0u, 0u, 0u, 0u};
+    for (int i = tid; i < (G::OFULL - G::XIN) / 16; i += G::NTHR) reinterpret_cast<uintx4*>(xsmem + G::XIN)[i] = uintx4{0u, 0u, 0u, 0u};
     if (bias_lds) {
         const uintx4* src = reinterpret_cast<const uintx4*>(a.xb + (size_t)(blockIdx.x / a.wgs_per_member) * a.xb_member);
-        for (int i = tid; i < (a.NH * G::NT + NTO) * 64; i += 256) reinterpret_cast<uintx4*>(xsmem + bias_off)[i] = src[i];
+        for (int i = tid; i < (a.NH * G::NT + NTO) * 64; i += G::NTHR) reinterpret_cast<uintx4*>(xsmem + bias_off)[i] = src[i];
     }
 
     // byte offset (part 0) of input feature f of row 0 inside x_in; row arow adds arow * 16
@@ -304,7 +342,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     const int arow16 = arow * 16;
     auto xin_off = [&](int f) { return xin_base(f) + arow16; };
     float* tab = reinterpret_cast<float*>(xsmem + G::TAB);
-    if (arow == 0) {
+    if (arow == 0 && feat) {
 #pragma unroll
         for (int pi = 0; pi < NPI; ++pi) {
             float* te = tab + (pi * 16 + fg) * G::TABW;
@@ -347,9 +385,8 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     const float* xb = a.xb + (size_t)e * a.xb_member;
     const int my_ntw = G::BASE + (wave < G::EXTRA ? 1 : 0);
     const int tstart = wave * G::BASE + (wave < G::EXTRA ? wave : G::EXTRA);
-    int nhead = 0;
-#pragma unroll
-    for (int s = 0; s < G::NTOW; ++s) nhead += ((3 - wave) + 4 * s) < NTO ? 1 : 0;
+    const int ht = G::NW - 1 - wave;                       // this wave's head tile (if < NTO)
+    const int nhead = ht < NTO ? 1 : 0;
     const int l0_nf = my_ntw * NC0, lh_nf = my_ntw * NCH, hd_nf = nhead * NCH;
     const unsigned w_l0 = wbase, w_h1 = w_l0 + l0_nf * CADM_XDL_FRAG_BYTES;
     const unsigned w_hd = w_h1 + (a.NH - 1) * lh_nf * CADM_XDL_FRAG_BYTES;
@@ -358,7 +395,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     // Resident fragments: the first NRES1 of hidden layer 1 and, if registers are left, the whole head (a head is all or
     // nothing: its slots are guarded at run time).  The STREAMED part of a layer is the tail of its stream region.
     constexpr int NRES1 = G::res_frags(NTW) < NTW * NCH ? G::res_frags(NTW) : NTW * NCH;
-    constexpr bool RESO = G::res_frags(NTW) - NRES1 >= G::NTOW * NCH;
+    constexpr bool RESO = G::res_frags(NTW) - NRES1 >= NCH;
     auto lay_res = [&](int l) { return l == 1 ? NRES1 : (RESO && l == a.NH) ? hd_nf : 0; };
     auto lay_off = [&](int l) {          // first streamed fragment of layer l
         return (l == 0 ? w_l0 : l < a.NH ? w_h1 + (l - 1) * lh_nf * CADM_XDL_FRAG_BYTES : w_hd) + lay_res(l) * CADM_XDL_FRAG_BYTES;
@@ -368,7 +405,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         do { l = l == a.NH ? 0 : l + 1; } while (lay_nf(l) == 0);
         return l;
     };
-    uintx4 resH[NRES1 > 0 ? NRES1 : 1][2], resO[RESO ? G::NTOW * NCH : 1][2];
+    uintx4 resH[NRES1 > 0 ? NRES1 : 1][2], resO[RESO ? NCH : 1][2];
     if constexpr (NRES1 > 0) {
         const unsigned h1 = w_h1;          // layer 1's region starts with its resident fragments
 #pragma unroll
@@ -379,7 +416,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     }
     if constexpr (RESO) {
 #pragma unroll
-        for (int q = 0; q < G::NTOW * NCH; ++q) {
+        for (int q = 0; q < NCH; ++q) {
             // (slots of a head tile this wave does not own load in-bounds garbage that is never used)
             const unsigned so = q < hd_nf ? w_hd + q * CADM_XDL_FRAG_BYTES : wbase;
             xres_load(resO[q][0], rsrc, lane * 16, so);
@@ -417,24 +454,27 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
             for (int h = 0; h < 2; ++h) {
                 const int d = 2 * (fg + 16 * pi) + h;
                 const int dc = d < D ? d : 0;
-                po[pi][h] = a.obs_rows ? a.obs_rows[(size_t)lr * D + dc] : a.obs[mi * D + dc];   // :432
+                po[pi][h] = !feat ? 0.0f : a.obs_rows ? a.obs_rows[(size_t)lr * D + dc] : a.obs[mi * D + dc];   // :432
                 pz[pi][h] = 0.0f;
             }
 #pragma unroll
         for (int ai = 0; ai < NAI; ++ai) {
             const int ac = a0 + 16 * ai;
-            areg[ai] = ac < A ? a.actions[abase + ac] : 0.0f;
+            areg[ai] = (feat && ac < A) ? a.actions[abase + ac] : 0.0f;
         }
-        if constexpr (C > 0) {
-            for (int f = P + A + fg; f < K0; f += 16) put_x(xin_off(f), a.ctx_vec[ctx_off + f - P - A]);   // static: context (:433-439)
+        if (feat) {
+            if constexpr (C > 0) {
+                for (int f = P + A + fg; f < K0; f += 16) put_x(xin_off(f), a.ctx_vec[ctx_off + f - P - A]);   // static: context (:433-439)
+            }
+            for (int t = fg; t < H; t += 16) ctrl_s[arow * H + t] = ctrl_term<ENV>(a.actions + abase + t * A, A);
         }
-        for (int t = fg; t < H; t += 16) ctrl_s[arow * H + t] = ctrl_term<ENV>(a.actions + abase + t * A, A);
         float ret = 0.0f;
         __syncthreads();
         TS_DECL
 
         for (int t = 0; t <= H; ++t) {
             // ===== state update from step t-1's head (:348-365,463-466) + reward (:469-471) + input assembly (:442-460) =====
+            if (feat) {
 #pragma unroll
             for (int pi = 0; pi < NPI; ++pi) {
                 const int dp = fg + 16 * pi;
@@ -501,9 +541,11 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                     }
                 }
             }
+            }
             if (t == H) break;
             // Gaussian-head noise of THIS step for this thread's pairs (consumed by the next state phase)
-            if constexpr (NOISE == CADM_NOISE_INJECT) {
+            if (!feat) {
+            } else if constexpr (NOISE == CADM_NOISE_INJECT) {
 #pragma unroll
                 for (int pi = 0; pi < NPI; ++pi) {
                     const int dp = fg + 16 * pi;
@@ -516,6 +558,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
             } else if constexpr (NOISE == CADM_NOISE_PHILOX) {
 #pragma unroll
                 for (int pi = 0; pi < NPI; ++pi) {
+                    if (fg + 16 * pi >= NP) continue;             // (wave-uniform for whole waves of unused pair slots)
                     uint32_t pc[4] = {grow, (uint32_t)t, (uint32_t)(fg + 16 * pi), CADM_STREAM_EPS | ((uint32_t)a.it << 8)};
                     uint32_t pk[2] = {a.seed, a.call};
                     philox_rounds<0, 10>(pc, pk);
@@ -555,68 +598,11 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                 if (1 < a.NH) hidden(1, std::integral_constant<int, NRES1>{});
                 for (int l = 2; l < a.NH; ++l) hidden(l, std::integral_constant<int, 0>{});
                 act_in = act_out;
-                // ================= output heads (mu | logvar tiles) =================
-                {
-                    constexpr int HNF = G::NTOW * NCH, HNFPAD = rup(HNF, R);
-                    f16x8 X1[NCH], X2[NCH];
-                    if (nhead > 0) {
-#pragma unroll
-                        for (int c = 0; c < NCH; ++c) {
-                            X1[c] = *reinterpret_cast<const f16x8*>(xsmem + act_in + ((0 * NCH + c) * 64 + lane) * 16);
-                            X2[c] = *reinterpret_cast<const f16x8*>(xsmem + act_in + ((1 * NCH + c) * 64 + lane) * 16);
-                        }
-                    }
-                    static_for(std::make_integer_sequence<int, G::NTOW>{}, [&](auto sc) {
-                        constexpr int s = decltype(sc)::value;
-                        const int ht = (3 - wave) + 4 * s;
-                        floatx4 hi = floatx4{0.f, 0.f, 0.f, 0.f}, lo = floatx4{0.f, 0.f, 0.f, 0.f}, ll = floatx4{0.f, 0.f, 0.f, 0.f};
-                        static_for(std::make_integer_sequence<int, NCH>{}, [&](auto cc) {
-                            constexpr int c = decltype(cc)::value;
-                            constexpr int jx = s * NCH + c;
-                            if (s < nhead) {
-                                if constexpr (c == 0) xdl_operand_nops(hi, lo, ll);
-                                if constexpr (RESO) {
-                                    xmfma_res(hi, resO[jx][0], X1[c]);
-                                    xmfma_res(lo, resO[jx][1], X1[c]);
-                                    xmfma_res(lo, resO[jx][0], X2[c]);
-                                    if constexpr (G::NPROD == 4) xmfma_res(ll, resO[jx][1], X2[c]);
-                                } else {
-                                    xmfma_ring<G::ASM_MFMA>(hi, ring.w[jx % R][0], X1[c]);
-                                    xmfma_ring<G::ASM_MFMA>(lo, ring.w[jx % R][1], X1[c]);
-                                    xmfma_ring<G::ASM_MFMA>(lo, ring.w[jx % R][0], X2[c]);
-                                    if constexpr (G::NPROD == 4) xmfma_ring<G::ASM_MFMA>(ll, ring.w[jx % R][1], X2[c]);
-                                }
-                            }
-                            constexpr int jj = jx + R;
-                            if constexpr (RESO) {
-                            } else if (jj < HNF) {
-                                if (jj < hd_nf) xring_load<jx % R>(ring, rsrc, w_hd + jj * CADM_XDL_FRAG_BYTES, lane);
-                            } else if constexpr (jj >= HNFPAD) {
-                                if (jj - HNFPAD < l0_nf) xring_load<jx % R>(ring, rsrc, w_l0 + (jj - HNFPAD) * CADM_XDL_FRAG_BYTES, lane);
-                            }
-                        });
-                        if (s < nhead) {
-                            xdl_result_nops(hi, lo, ll);
-                            const int bt = (a.NH * G::NT + ht) * 64 + lane;
-                            floatx4 b;
-                            if constexpr (G::BIAS_LDS) b = *reinterpret_cast<const floatx4*>(xsmem + bias_off + bt * 16);
-                            else b = *reinterpret_cast<const floatx4*>(xb + bt * 4);
-                            floatx4 v;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                v[r] = fmaf(lo[r], 4.8828125e-4f, hi[r] + b[r]);
-                                if constexpr (G::NPROD == 4) v[r] = fmaf(ll[r], 2.384185791015625e-7f, v[r]);
-                            }
-                            *reinterpret_cast<floatx4*>(ofull + (ht * 64 + lane) * 4) = v;
-                        }
-                    });
-                    if constexpr (!RESO) {
-                        static_for(std::make_integer_sequence<int, HNFPAD - HNF>{}, [&](auto jc) {
-                            constexpr int jx = HNF + decltype(jc)::value;
-                            constexpr int jj = jx + R;
-                            if (jj - HNFPAD < l0_nf) xring_load<jx % R>(ring, rsrc, w_l0 + (jj - HNFPAD) * CADM_XDL_FRAG_BYTES, lane);
-                        });
-                    }
+                // ================= output head tile (mu | logvar of 8 dims) =================
+                if (nhead) {
+                    const int nx = next_streamed(a.NH);
+                    xdl_sweep<G, 1, NCH, RESO ? NCH : 0>(ring, resO, rsrc, lay_off(a.NH), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
+                                                         XHeadEpi<G>{xsmem, xb, bias_off, a.NH * G::NT + ht, ht, lane});
                 }
             }
             TS(6)
@@ -628,9 +614,9 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         // ---- a row's return = sum of its threads' reward parts, in fixed slot order ----
         float* ret_s = reinterpret_cast<float*>(xsmem + G::OFULL);
         __syncthreads();
-        ret_s[arow * 16 + fg] = ret;
+        if (feat) ret_s[arow * 16 + fg] = ret;
         __syncthreads();
-        if (fg == 0 && valid) {
+        if (feat && fg == 0 && valid) {
             float r = 0.0f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) r += ret_s[arow * 16 + i];
@@ -641,7 +627,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
 }
 
 template <class G, int NOISE>
-__global__ __launch_bounds__(256) void rollout_xdl_kernel(const RolloutArgs a) {
+__global__ __launch_bounds__(G::NTHR) void rollout_xdl_kernel(const RolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xsmem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // waves [0, EXTRA) own one hidden tile more than the others: two specialisations of the whole body, chosen per wave
@@ -654,7 +640,7 @@ template <class G, int NOISE>
 int xdl_launch_noise(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipStream_t s) {
     RolloutArgs args = a;
     const int tiles = (rows_per_member + 15) / 16;
-    // one workgroup per CU (512 VGPRs per wave); workgroups walk over their member's row tiles
+    // one workgroup of 8 waves per CU (256 registers per wave); workgroups walk over their member's row tiles
     int per_member = ctx->n_cus / ctx->E;
     if (per_member < 1) per_member = 1;
     args.wgs_per_member = tiles < per_member ? tiles : per_member;
@@ -672,7 +658,7 @@ int xdl_launch_noise(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, h
         CADM_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_done.insert(fn);
     }
-    hipLaunchKernelGGL((rollout_xdl_kernel<G, NOISE>), dim3(args.wgs_per_member * ctx->E), dim3(256), lds, s, args);
+    hipLaunchKernelGGL((rollout_xdl_kernel<G, NOISE>), dim3(args.wgs_per_member * ctx->E), dim3(G::NTHR), lds, s, args);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
 }

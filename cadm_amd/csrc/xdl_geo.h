@@ -10,8 +10,8 @@
 //   * An output tile is 16 units; the K dimension of the layers that consume a hidden layer is cut in chunks of
 //     32 = one PAIR of producer tiles, so a lane's D fragments (units 4g..4g+3 of tiles 2c, 2c+1) ARE its B fragment
 //     for chunk c: activations cross layers through LDS without any cross-lane movement.
-//   * Hidden tiles are distributed over the 4 waves contiguously (wave w: BASE + (w < EXTRA) tiles); head tiles
-//     (8 obs dims: mu0 mu1 lv0 lv1 per lane) go to the waves with the fewest hidden tiles first.
+//   * Hidden tiles are distributed over the CADM_XDL_WAVES waves of a workgroup contiguously (wave w: BASE + (w < EXTRA)
+//     tiles); head tiles (8 obs dims: mu0 mu1 lv0 lv1 per lane) go to the waves with the fewest hidden tiles first.
 //   * A "fragment" = one (tile, chunk) of weights = 2 split parts x 64 lanes x 16 B = 2 KB.  Per (member, wave) the
 //     stream stores the fragments in EXACTLY the order that wave consumes them during one rollout step:
 //     [layer 0][hidden 1 .. NH-1][head]; inside a layer tiles go in groups of two, chunk-major inside a group
@@ -19,20 +19,25 @@
 #pragma once
 
 #define CADM_XDL_FRAG_BYTES 2048
+#define CADM_XDL_WAVES 8          // two waves per SIMD: one wave's waits (LDS, L2, epilogue chains) hide behind the other's MFMAs
 
 struct XdlGeo {
     int K0, HID, D, NH;
     int NC0, NT, NCH, NTO, BASE, EXTRA, NTOW;
     __host__ __device__ int ntw(int w) const { return BASE + (w < EXTRA ? 1 : 0); }
     __host__ __device__ int tstart(int w) const { return w * BASE + (w < EXTRA ? w : EXTRA); }
-    __host__ __device__ int head_tile(int w, int s) const { return (3 - w) + 4 * s; }          // slot s of wave w (valid if < NTO)
+    __host__ __device__ int head_tile(int w, int s) const { return (CADM_XDL_WAVES - 1 - w) + CADM_XDL_WAVES * s; }          // slot s of wave w (valid if < NTO)
     __host__ __device__ int nhead(int w) const {
         int n = 0;
         for (int s = 0; s < NTOW; ++s) n += head_tile(w, s) < NTO ? 1 : 0;
         return n;
     }
     __host__ __device__ int wave_frags(int w) const { return ntw(w) * NC0 + (NH - 1) * ntw(w) * NCH + nhead(w) * NCH; }
-    __host__ __device__ int member_frags() const { return wave_frags(0) + wave_frags(1) + wave_frags(2) + wave_frags(3); }
+    __host__ __device__ int member_frags() const {
+        int n = 0;
+        for (int w = 0; w < CADM_XDL_WAVES; ++w) n += wave_frags(w);
+        return n;
+    }
     __host__ __device__ int bias_tiles() const { return NH * NT + NTO; }
 };
 
@@ -43,9 +48,9 @@ inline XdlGeo make_xdl_geo(int K0, int HID, int D, int NH) {
     g.NT = (HID + 15) / 16;
     g.NCH = (g.NT + 1) / 2;
     g.NTO = (D + 7) / 8;
-    g.BASE = g.NT / 4;
-    g.EXTRA = g.NT % 4;
-    g.NTOW = (g.NTO + 3) / 4;
+    g.BASE = g.NT / CADM_XDL_WAVES;
+    g.EXTRA = g.NT % CADM_XDL_WAVES;
+    g.NTOW = (g.NTO + CADM_XDL_WAVES - 1) / CADM_XDL_WAVES;
     return g;
 }
 

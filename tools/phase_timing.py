@@ -26,7 +26,8 @@ def main():
     cfg = synth.CONFIGS[cfgname]
     prob = synth.make_problem(env=cfg["env"], context=cfg["context"], E=cfg["E"], m=1, H=cfg["H"], seed=0)
     eng = make_engine(prob, p=cfg["p"], deterministic=cfg["deterministic"])
-    tbuf = torch.zeros(4 * 24, dtype=torch.int64, device=eng.device)
+    NW = 4 if os.environ.get("CADM_ROLLOUT") == "f32" else 8
+    tbuf = torch.zeros(NW * 24, dtype=torch.int64, device=eng.device)
     check(eng.lib.cadm_debug_set_timing_buffer(eng._ctx, ct.c_void_p(tbuf.data_ptr())))
     n = cfg["n"]
     mean, var = eng._t(prob["init_mean"]), eng._t(prob["init_var"])
@@ -36,12 +37,14 @@ def main():
         eng.rollout_returns(prob["obs"], ctx, acts, seed=1, call=1)
     torch.cuda.synchronize()
     names = NAMES if os.environ.get("CADM_ROLLOUT") == "f32" else XDL_NAMES
-    t = tbuf.cpu().numpy().reshape(4, 24)[:, :len(names)].astype(np.float64) / cfg["H"]
+    t = tbuf.cpu().numpy().reshape(NW, 24)[:, :len(names)].astype(np.float64) / cfg["H"]
     print("cycles per step (s_memtime ticks), workgroup 0, per wave:")
-    print("%-14s %9s %9s %9s %9s" % ("phase", "wave0", "wave1", "wave2", "wave3"))
+    fmt = "%-16s" + " %8s" * NW
+    print(fmt % ("phase", *["wave%d" % w for w in range(NW)]))
+    fmt = "%-16s" + " %8.0f" * NW
     for i, nm in enumerate(names):
-        print("%-14s %9.0f %9.0f %9.0f %9.0f" % (nm, *t[:, i]))
-    print("%-14s %9.0f %9.0f %9.0f %9.0f" % ("TOTAL", *t.sum(1)))
+        print(fmt % (nm, *t[:, i]))
+    print(fmt % ("TOTAL", *t.sum(1)))
 
 
 if __name__ == "__main__":
