@@ -44,11 +44,11 @@ __global__ void pack_xdl_kernel(const XdlPackArgs a) {
         }
         const int grp = lane >> 4, m = lane & 15;
         int tile, c;
-        if (layer < g.NH) {                   // hidden-type outputs: tiles in groups of two, chunk-major inside a group
-            const int gi = fj / (2 * nchl), jj = fj - 2 * gi * nchl;
-            const int gs = (ntw - 2 * gi) < 2 ? (ntw - 2 * gi) : 2;
+        if (layer < g.NH) {                   // hidden-type outputs: tiles in groups of CADM_XDL_GROUP, chunk-major inside a group
+            const int gi = fj / (CADM_XDL_GROUP * nchl), jj = fj - CADM_XDL_GROUP * gi * nchl;
+            const int gs = (ntw - CADM_XDL_GROUP * gi) < CADM_XDL_GROUP ? (ntw - CADM_XDL_GROUP * gi) : CADM_XDL_GROUP;
             c = jj / gs;
-            tile = g.tstart(w) + 2 * gi + jj % gs;
+            tile = g.tstart(w) + CADM_XDL_GROUP * gi + jj % gs;
         } else {                              // head: valid slots in order, chunk-major per slot
             int sv = fj / g.NCH;
             c = fj % g.NCH;

@@ -10,10 +10,14 @@
 #define TS_DECL unsigned long long ts_acc[NPH] = {}; unsigned long long ts_last = __builtin_amdgcn_s_memtime();
 #define TS(i) { const unsigned long long ts_now = __builtin_amdgcn_s_memtime(); ts_acc[i] += ts_now - ts_last; ts_last = ts_now; }
 #define TS_DUMP if (a.tbuf && blockIdx.x == 0 && lane == 0) { for (int i = 0; i < NPH; ++i) a.tbuf[wave * NPH + i] = ts_acc[i]; }
+#define TS_PARAMS , unsigned long long (&ts_acc)[NPH], unsigned long long& ts_last
+#define TS_ARGS , ts_acc, ts_last
 #else
 #define TS_DECL
 #define TS(i)
 #define TS_DUMP
+#define TS_PARAMS
+#define TS_ARGS
 #endif
 
 namespace {
@@ -26,6 +30,7 @@ __device__ __forceinline__ void static_for(std::integer_sequence<int, Js...>, F&
 }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
 constexpr int rup(int a, int b) { return (a + b - 1) / b * b; }
 
 // ---------------------------------------------------------------------------------------------

@@ -15,7 +15,7 @@
 //   * a layer is evaluated transposed, OUT^T = W^T IN^T: weights are the A operand (streamed from L2 in consumption
 //     order through a register ring), the 16 rows are the B / D columns.  A lane's D fragments of tiles (2c, 2c+1) are
 //     its B fragment of chunk c of the next layer: activations cross layers through LDS with lane-linear accesses;
-//   * wave w owns BASE + (w < EXTRA) hidden tiles and computes them two at a time over the whole K (the B operand is
+//   * wave w owns BASE + (w < EXTRA) hidden tiles and computes them one after the other over the whole K (the B operand is
 //     read chunk by chunk from LDS, three chunks ahead); a tile pair's epilogue (swish, f16 split, LDS store) runs in
 //     the shadow of the next pair's MFMAs or, for the last pair, of the SIMD's other wave;
 //   * the rollout state lives in registers of the 256 "feature threads" (waves 0-3) exactly as in the fp32 kernel.
@@ -63,7 +63,9 @@ struct XC {
     // being held in ~26 registers across the MFMA sweeps
     static constexpr int TABW = 28;                                     // floats per (pair slot, fg) entry
     static constexpr int TAB = STATS + rup((2 * P + 2 * A) * 4, 16);
-    static constexpr int CTRL = TAB + NPI * 16 * TABW * 4;              // + 16 * H floats (dynamic)
+    // Gaussian-head noise, produced by waves 4-7 while waves 0-3 run the state update: [step parity][pair slot][fg][row] x 2
+    static constexpr int ZB = TAB + NPI * 16 * TABW * 4;
+    static constexpr int CTRL = ZB + 2 * NPI * 256 * 8;                 // + 16 * H floats (dynamic)
     // Bias tiles (fp32, D layout) live in LDS when they fit next to the rest (a bias read from global memory in a tile's
     // epilogue would sit BEHIND the ring's weight loads in the in-order vmcnt queue and drain the whole ring);
     // otherwise they are fetched at the start of a sweep, ahead of that sweep's ring loads.
@@ -76,10 +78,10 @@ struct XC {
     // (tests/test_isa_hygiene.py checks the ISA for AGPR<->VGPR shuffles of resident fragments, which would also be an
     // undetected MFMA operand hazard).
 #ifndef CADM_XDL_RES_FRAGS
-#define CADM_XDL_RES_FRAGS 14       // waves with BASE hidden tiles
+#define CADM_XDL_RES_FRAGS 13       // waves with BASE hidden tiles
 #endif
 #ifndef CADM_XDL_RES_FRAGS_X
-#define CADM_XDL_RES_FRAGS_X 12     // waves with BASE + 1 hidden tiles (more accumulators / epilogue state live)
+#define CADM_XDL_RES_FRAGS_X 11     // waves with BASE + 1 hidden tiles (more accumulators / epilogue state live)
 #endif
     static constexpr bool ASM_MFMA = CADM_XDL_RES && NCH <= 8;     // asm MFMAs (AGPR-resident operands) vs builtins
     static constexpr int res_frags(int ntw) {      // (wide observations keep two pair slots of rollout state per thread)
@@ -111,7 +113,11 @@ __device__ __forceinline__ floatx4 xmfma(uintx4 a, f16x8 b, floatx4 c) {
 // load (the caller waits with an explicit vmcnt(0)) nor the MFMA's latency (callers keep the accumulator's first VALU
 // read a whole chunk of MFMAs away, or pad with xdl_result_nops).
 __device__ __forceinline__ void xres_load(uintx4& dst, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+    // (readfirstlane: under SGPR pressure hipcc keeps a uniform offset in a VGPR, which the "s" constraint does not move
+    //  back.  s_nop 4: the hazard recognizer does not look into inline asm, and a v_readfirstlane'd SGPR needs 5 wait
+    //  states before a VMEM instruction may read it -- without them the load used the PREVIOUS offset now and then)
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen"
+                 : "=a"(dst) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
 }
 __device__ __forceinline__ void xmfma_res(floatx4& acc, const uintx4& w, const f16x8& x) {
     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
@@ -215,7 +221,7 @@ struct XHeadEpi {
     }
 };
 
-// One layer sweep of this wave: NTW tiles x NCHL chunks, tiles two at a time.
+// One layer sweep of this wave: NTW tiles x NCHL chunks, CADM_XDL_GROUP tiles at a time.
 //   The first NRES fragments (consumption order) are register-resident (res[j][part], AGPRs, loaded once per workgroup);
 //   the other NFS = NF - NRES come through the ring: it holds streamed fragments 0..R-1 of this layer on entry and 0..R-1
 //   of the NEXT streamed layer (nx_nf of them exist) on exit.  wcur = byte offset of this layer's first STREAMED fragment.
@@ -224,7 +230,7 @@ struct XHeadEpi {
 //   VALU work of the same wave); the last group's epilogue overlaps with the SIMD's other wave.
 template <class G, int NTW, int NCHL, int NRES, class Epi>
 __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2], __amdgpu_buffer_rsrc_t rsrc, unsigned wcur,
-                                          unsigned wnext, int nx_nf, const unsigned char* lds_in, int lane, const Epi& epi) {
+                                          unsigned wnext, int nx_nf, const unsigned char* lds_in, int lane, const Epi& epi TS_PARAMS) {
     constexpr int R = G::R, NF = NTW * NCHL, NFS = NF - NRES, NFSPAD = rup(NFS, R);
     static_assert(NRES >= 0 && NRES <= NF, "bad resident fragment count");
     constexpr int XD = NCHL < 3 ? NCHL : 3;
@@ -243,27 +249,28 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
             if (jj - NFSPAD < nx_nf) xring_load<js % R>(ring, rsrc, wnext + (jj - NFSPAD) * CADM_XDL_FRAG_BYTES, lane);
         }
     };
-    constexpr int NG = (NTW + 1) / 2, NST = Epi::NSTAGE;
+    constexpr int GS = CADM_XDL_GROUP, NG = (NTW + GS - 1) / GS, NST = Epi::NSTAGE;
     constexpr int NPR = G::NPROD;
-    floatx4 hi[2][2], lo[2][2], ll[2][2];   // [group parity][tile of the group]: the previous group's pair is being finished
-    typename Epi::State pst[2];             // as side work while this group's accumulates (no register moves in between)
+    floatx4 hi[2][GS], lo[2][GS], ll[2][GS];   // [group parity][tile of the group]: the previous group is being finished
+    typename Epi::State pst[GS];               // as side work while this group accumulates (no register moves in between)
     // stage s of the side epilogue goes to chunks >= 1, i.e. at least one chunk of MFMAs after the accumulators were
     // last written (the compiler cannot see asm MFMA latency)
     auto stage_chunk = [](int st) constexpr { return NCHL == 1 ? 0 : NST == 1 ? 1 : 1 + st * (NCHL - 2) / (NST - 1); };
     static_for(std::make_integer_sequence<int, NG>{}, [&](auto gc) {
         constexpr int g = decltype(gc)::value, gp = g & 1, pp = gp ^ 1;
-        constexpr int gs = (NTW - 2 * g) < 2 ? (NTW - 2 * g) : 2;
-        constexpr int pgs = g > 0 ? 2 : 0;                       // tiles of the previous group (groups before the last are full)
+        constexpr int gs = (NTW - GS * g) < GS ? (NTW - GS * g) : GS;
+        constexpr int pgs = g > 0 ? GS : 0;                      // tiles of the previous group (groups before the last are full)
         static_for(std::make_integer_sequence<int, XD - 1>{}, [&](auto cc) { xload(cc); });
 #pragma unroll
         for (int k = 0; k < gs; ++k) {
-            hi[gp][k] = epi.init(2 * g + k); lo[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f}; ll[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f};
+            hi[gp][k] = epi.init(GS * g + k); lo[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f}; ll[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int k = 0; k < gs; ++k) xdl_operand_nops(hi[gp][k], lo[gp][k], ll[gp][k]);      // VALU-zeroed accumulators -> MFMA srcC
         static_for(std::make_integer_sequence<int, NCHL>{}, [&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            constexpr int j0 = 2 * g * NCHL + c * gs;
+            constexpr int j0 = GS * g * NCHL + c * gs;
+            if constexpr (c == 1 && g == 0) { TS(10) }
             if constexpr (c + XD - 1 < NCHL) xload(std::integral_constant<int, c + XD - 1>{});
             static_for(std::make_integer_sequence<int, NPR * gs>{}, [&](auto mc) {      // hi(k).. lo(k).. lo'(k).. [ll(k)..]
                 constexpr int k = decltype(mc)::value % gs, prod = decltype(mc)::value / gs, j = j0 + k;
@@ -282,21 +289,23 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
                     constexpr int st = decltype(sc)::value;
                     if constexpr (stage_chunk(st) == c) {
 #pragma unroll
-                        for (int k = 0; k < pgs; ++k) epi.template stage<st>(2 * (g - 1) + k, hi[pp][k], lo[pp][k], ll[pp][k], pst[k]);
+                        for (int k = 0; k < pgs; ++k) epi.template stage<st>(GS * (g - 1) + k, hi[pp][k], lo[pp][k], ll[pp][k], pst[k]);
                     }
                 });
             }
             __builtin_amdgcn_sched_barrier(0);      // pin the software pipeline: no load hoisting across chunks
         });
         if constexpr (g == NG - 1) {                // the last group's epilogue has no MFMAs of this wave left to hide behind
+            TS(11)
 #pragma unroll
             for (int k = 0; k < gs; ++k) xdl_result_nops(hi[gp][k], lo[gp][k], ll[gp][k]);
             static_for(std::make_integer_sequence<int, NST>{}, [&](auto sc) {
 #pragma unroll
-                for (int k = 0; k < gs; ++k) epi.template stage<decltype(sc)::value>(2 * g + k, hi[gp][k], lo[gp][k], ll[gp][k], pst[k]);
+                for (int k = 0; k < gs; ++k) epi.template stage<decltype(sc)::value>(GS * g + k, hi[gp][k], lo[gp][k], ll[gp][k], pst[k]);
             });
         }
     });
+    TS(12)
     static_for(std::make_integer_sequence<int, NFSPAD - NFS>{}, [&](auto jc) {
         prefetch(std::integral_constant<int, NFS + decltype(jc)::value>{});
     });
@@ -309,6 +318,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     float* stats = reinterpret_cast<float*>(xsmem + G::STATS);
     float* ctrl_s = reinterpret_cast<float*>(xsmem + G::CTRL);
     float* ofull = reinterpret_cast<float*>(xsmem + G::OFULL);
+    float2* zb = reinterpret_cast<float2*>(xsmem + G::ZB);
     const int bias_off = G::CTRL + rup(16 * a.H * 4, 16);      // LDS byte offset of the bias tiles (BIAS_LDS only)
     const bool bias_lds = G::BIAS_LDS && a.bias_lds;
 
@@ -391,44 +401,58 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     const unsigned w_l0 = wbase, w_h1 = w_l0 + l0_nf * CADM_XDL_FRAG_BYTES;
     const unsigned w_hd = w_h1 + (a.NH - 1) * lh_nf * CADM_XDL_FRAG_BYTES;
 
-    // layer ids: 0 = layer 0, 1 .. NH-1 = hidden, NH = head.  Register-resident layers are absent from the ring's stream.
-    // Resident fragments: the first NRES1 of hidden layer 1 and, if registers are left, the whole head (a head is all or
-    // nothing: its slots are guarded at run time).  The STREAMED part of a layer is the tail of its stream region.
-    constexpr int NRES1 = G::res_frags(NTW) < NTW * NCH ? G::res_frags(NTW) : NTW * NCH;
-    constexpr bool RESO = G::res_frags(NTW) - NRES1 >= NCH;
-    auto lay_res = [&](int l) { return l == 1 ? NRES1 : (RESO && l == a.NH) ? hd_nf : 0; };
+    // layer ids: 0 = layer 0, 1 .. NH-1 = hidden, NH = head.
+    // Register-resident fragments (never re-read from L2): the whole head tile on the waves that have one and registers to
+    // spare, and the first Q_l fragments of hidden layers l = 1..3 -- spread EVENLY, so that every layer streams about the
+    // same number of bytes: the L2 -> CU path (~50 B/clk) is the scarce resource, and a layer that streams nothing
+    // leaves it idle while its neighbours wait for it.  The STREAMED part of a layer is the tail of its stream region.
+    constexpr int NFH = NTW * NCH;                                      // fragments of a hidden layer (this wave)
+    constexpr bool RESO = NTW == G::BASE && G::res_frags(NTW) >= NCH + 3;
+    constexpr int RREM = G::res_frags(NTW) - (RESO ? NCH : 0);
+    constexpr int Q1 = cmin((RREM + 2) / 3, NFH), Q2 = cmin((RREM - Q1 + 1) / 2, NFH), Q3 = cmin(RREM - Q1 - Q2, NFH);
+    constexpr int NRESH = Q1 + Q2 + Q3;
+    auto hq = [&](int l) { return l == 1 ? Q1 : l == 2 ? Q2 : l == 3 ? Q3 : 0; };
+    auto lay_res = [&](int l) { return l == 0 ? 0 : l < a.NH ? hq(l) : RESO ? hd_nf : 0; };
     auto lay_off = [&](int l) {          // first streamed fragment of layer l
         return (l == 0 ? w_l0 : l < a.NH ? w_h1 + (l - 1) * lh_nf * CADM_XDL_FRAG_BYTES : w_hd) + lay_res(l) * CADM_XDL_FRAG_BYTES;
     };
     auto lay_nf = [&](int l) { return (l == 0 ? l0_nf : l < a.NH ? lh_nf : hd_nf) - lay_res(l); };
-    auto next_streamed = [&](int l) {    // next layer (cyclically over steps) with a streamed part; layer 0 always has one
-        do { l = l == a.NH ? 0 : l + 1; } while (lay_nf(l) == 0);
-        return l;
-    };
-    uintx4 resH[NRES1 > 0 ? NRES1 : 1][2], resO[RESO ? NCH : 1][2];
-    if constexpr (NRES1 > 0) {
-        const unsigned h1 = w_h1;          // layer 1's region starts with its resident fragments
-#pragma unroll
-        for (int q = 0; q < NRES1; ++q) {
-            xres_load(resH[q][0], rsrc, lane * 16, h1 + q * CADM_XDL_FRAG_BYTES);
-            xres_load(resH[q][1], rsrc, lane * 16 + 1024, h1 + q * CADM_XDL_FRAG_BYTES);
+    auto next_streamed = [&](int l) {    // next layer (cyclically over steps) with a streamed part
+        for (int k = 0; k <= a.NH; ++k) {
+            l = l == a.NH ? 0 : l + 1;
+            if (lay_nf(l) > 0) break;
         }
-    }
+        return l;                         // (nothing streamed at all: a layer with lay_nf = 0, no loads are issued for it)
+    };
+    uintx4 resH[NRESH > 0 ? NRESH : 1][2], resO[RESO ? NCH : 1][2];
+    static_for(std::make_integer_sequence<int, NRESH>{}, [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        constexpr int l = q < Q1 ? 1 : q < Q1 + Q2 ? 2 : 3, ql = q - (l == 1 ? 0 : l == 2 ? Q1 : Q1 + Q2);
+        // (a layer the model does not have loads in-bounds garbage that is never used)
+        const unsigned so = l < a.NH ? w_h1 + ((l - 1) * lh_nf + ql) * CADM_XDL_FRAG_BYTES : wbase;
+        xres_load(resH[q][0], rsrc, lane * 16, so);
+        xres_load(resH[q][1], rsrc, lane * 16 + 1024, so);
+    });
     if constexpr (RESO) {
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
-            // (slots of a head tile this wave does not own load in-bounds garbage that is never used)
+            // (a wave without a head tile loads in-bounds garbage that is never used)
             const unsigned so = q < hd_nf ? w_hd + q * CADM_XDL_FRAG_BYTES : wbase;
             xres_load(resO[q][0], rsrc, lane * 16, so);
             xres_load(resO[q][1], rsrc, lane * 16 + 1024, so);
         }
     }
-    if constexpr (NRES1 > 0 || RESO) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (NRESH > 0 || RESO) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     XRing<G> ring;
-    static_for(std::make_integer_sequence<int, R>{}, [&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        if (s < l0_nf) xring_load<s>(ring, rsrc, w_l0 + s * CADM_XDL_FRAG_BYTES, lane);
-    });
+    {
+        const int first = next_streamed(a.NH);
+        const unsigned fo = lay_off(first);
+        const int fn = lay_nf(first);
+        static_for(std::make_integer_sequence<int, R>{}, [&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if (s < fn) xring_load<s>(ring, rsrc, fo + s * CADM_XDL_FRAG_BYTES, lane);
+        });
+    }
 
     for (int tile = grp; tile < ntiles; tile += a.wgs_per_member) {
         // ---- this thread's row ----
@@ -447,7 +471,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         else if (a.it & 1) ctx_off = (mi * a.E + ep) * C;                // Q2: [E,m] memory reread as [m,E]
         else ctx_off = (ep * a.m + mi) * C;                              // Q1: encoder j % E
 
-        float po[NPI][2], pz[NPI][2], areg[NAI];
+        float po[NPI][2], areg[NAI];
 #pragma unroll
         for (int pi = 0; pi < NPI; ++pi)
 #pragma unroll
@@ -455,7 +479,6 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                 const int d = 2 * (fg + 16 * pi) + h;
                 const int dc = d < D ? d : 0;
                 po[pi][h] = !feat ? 0.0f : a.obs_rows ? a.obs_rows[(size_t)lr * D + dc] : a.obs[mi * D + dc];   // :432
-                pz[pi][h] = 0.0f;
             }
 #pragma unroll
         for (int ai = 0; ai < NAI; ++ai) {
@@ -488,6 +511,8 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                     if (t > 0) {
                         const int jt = dp >> 2, lt = (dp & 3) * 16 + arow;
                         const floatx4 v = *reinterpret_cast<const floatx4*>(ofull + (jt * 64 + lt) * 4);   // (mu0, mu1, lv0, lv1)
+                        float2 z = make_float2(0.0f, 0.0f);
+                        if constexpr (NOISE != CADM_NOISE_NONE) z = zb[(((t - 1) & 1) * NPI + pi) * 256 + fg * 16 + arow];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             float delta = v[h] * tv(2 + h) + tv(0 + h);                          // denormalize, :349
@@ -495,7 +520,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                                 float lv = tv(6 + h) - softplus_fast(tv(6 + h) - v[2 + h]);          // :356
                                 lv = tv(8 + h) + softplus_fast(lv - tv(8 + h));                      // :357
                                 const float sd = __expf((lv + tv(4 + h)) * 0.5f);                    // :360-363
-                                delta = delta + pz[pi][h] * sd;                                     // :365
+                                delta = delta + (h ? z.y : z.x) * sd;                               // :365
                             }
                             po[pi][h] = postproc<ENV>(2 * dp + h, po[pi][h], delta);                // :466
                         }
@@ -543,26 +568,27 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
             }
             }
             if (t == H) break;
-            // Gaussian-head noise of THIS step for this thread's pairs (consumed by the next state phase)
-            if (!feat) {
-            } else if constexpr (NOISE == CADM_NOISE_INJECT) {
+            // Gaussian-head noise of THIS step (consumed by the next state phase): made by the twin thread in waves 4-7,
+            // which have nothing else to do while waves 0-3 update the state
+            if constexpr (NOISE != CADM_NOISE_NONE) {
+                if (!feat) {
 #pragma unroll
-                for (int pi = 0; pi < NPI; ++pi) {
-                    const int dp = fg + 16 * pi;
-                    if (dp < NP) {
-                        const float* epp = a.eps + ((size_t)t * a.m * a.n_local * a.p + lr) * D + 2 * dp;
-                        pz[pi][0] = epp[0];
-                        pz[pi][1] = (2 * dp + 1 < D) ? epp[1] : 0.0f;
+                    for (int pi = 0; pi < NPI; ++pi) {
+                        const int dp = fg + 16 * pi;
+                        if (dp >= NP) continue;                   // (wave-uniform for whole waves of unused pair slots)
+                        float2 z;
+                        if constexpr (NOISE == CADM_NOISE_INJECT) {
+                            const float* epp = a.eps + ((size_t)t * a.m * a.n_local * a.p + lr) * D + 2 * dp;
+                            z.x = epp[0];
+                            z.y = (2 * dp + 1 < D) ? epp[1] : 0.0f;
+                        } else {
+                            uint32_t pc[4] = {grow, (uint32_t)t, (uint32_t)dp, CADM_STREAM_EPS | ((uint32_t)a.it << 8)};
+                            uint32_t pk[2] = {a.seed, a.call};
+                            philox_rounds<0, 10>(pc, pk);
+                            box_muller(u01(pc[0]), u01(pc[1]), z.x, z.y);
+                        }
+                        zb[((t & 1) * NPI + pi) * 256 + fg * 16 + arow] = z;
                     }
-                }
-            } else if constexpr (NOISE == CADM_NOISE_PHILOX) {
-#pragma unroll
-                for (int pi = 0; pi < NPI; ++pi) {
-                    if (fg + 16 * pi >= NP) continue;             // (wave-uniform for whole waves of unused pair slots)
-                    uint32_t pc[4] = {grow, (uint32_t)t, (uint32_t)(fg + 16 * pi), CADM_STREAM_EPS | ((uint32_t)a.it << 8)};
-                    uint32_t pk[2] = {a.seed, a.call};
-                    philox_rounds<0, 10>(pc, pk);
-                    box_muller(u01(pc[0]), u01(pc[1]), pz[pi][0], pz[pi][1]);
                 }
             }
             TS(0)
@@ -578,31 +604,34 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                 {
                     const int nx = next_streamed(0);
                     xdl_sweep<G, NTW, NC0, 0>(ring, nullptr, rsrc, w_l0, lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
-                                              hidden_epi(0, act_out));
+                                              hidden_epi(0, act_out) TS_ARGS);
                 }
                 TS(2)
                 __syncthreads();
                 TS(3)
                 // hidden layers 1 .. NH-1: the first three are unrolled (distinct resident registers), the rest loop
-                auto hidden = [&](int l, auto res_c) {
-                    constexpr int NRES = decltype(res_c)::value;
+                auto hidden = [&](int l, auto res_c, auto base_c) {
+                    constexpr int NRES = decltype(res_c)::value, RBASE = decltype(base_c)::value;
                     act_in = act_out;
                     act_out = (act_in == G::ACTA) ? G::ACTB : G::ACTA;
                     const int nx = next_streamed(l);
-                    xdl_sweep<G, NTW, NCH, NRES>(ring, resH, rsrc, lay_off(l), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
-                                                 hidden_epi(l, act_out));
+                    xdl_sweep<G, NTW, NCH, NRES>(ring, resH + RBASE, rsrc, lay_off(l), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
+                                                 hidden_epi(l, act_out) TS_ARGS);
                     if (l == 1) { TS(4) } else if (l == 2) { TS(8) } else { TS(9) }
                     __syncthreads();
                     TS(5)
                 };
-                if (1 < a.NH) hidden(1, std::integral_constant<int, NRES1>{});
-                for (int l = 2; l < a.NH; ++l) hidden(l, std::integral_constant<int, 0>{});
+                using IC0 = std::integral_constant<int, 0>;
+                if (1 < a.NH) hidden(1, std::integral_constant<int, Q1>{}, IC0{});
+                if (2 < a.NH) hidden(2, std::integral_constant<int, Q2>{}, std::integral_constant<int, Q1>{});
+                if (3 < a.NH) hidden(3, std::integral_constant<int, Q3>{}, std::integral_constant<int, Q1 + Q2>{});
+                for (int l = 4; l < a.NH; ++l) hidden(l, IC0{}, IC0{});
                 act_in = act_out;
                 // ================= output head tile (mu | logvar of 8 dims) =================
                 if (nhead) {
                     const int nx = next_streamed(a.NH);
                     xdl_sweep<G, 1, NCH, RESO ? NCH : 0>(ring, resO, rsrc, lay_off(a.NH), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
-                                                         XHeadEpi<G>{xsmem, xb, bias_off, a.NH * G::NT + ht, ht, lane});
+                                                         XHeadEpi<G>{xsmem, xb, bias_off, a.NH * G::NT + ht, ht, lane} TS_ARGS);
                 }
             }
             TS(6)

@@ -79,9 +79,19 @@ def test_resident_fragments_never_leave_agprs():
             # The kernel body exists once per wave variant (tiles per wave); each variant loads ITS resident fragments
             # with a burst of "buffer_load_dwordx4 a[..]" and keeps them to the end.  hipcc may park ordinary VGPR values
             # in OTHER AGPRs (harmless spills); a copy into or out of a resident one is the hazard.
-            loads = [i for i, x in enumerate(ins) if x.startswith("buffer_load_dwordx4 a[")]
-            starts = [i for k, i in enumerate(loads) if k == 0 or i - loads[k - 1] > 200]
-            assert starts, "%s: no resident-fragment loads" % sym
+            # variant boundary = target of the dispatch branch (the first far forward branch of the kernel)
+            def addr(x):
+                m3 = re.search(r"// ([0-9A-F]{8,}):", x)
+                return int(m3.group(1), 16) if m3 else None
+            split = len(ins)
+            for i, x in enumerate(ins[:400]):
+                m3 = re.match(r"s_cbranch_\w+ (\d+)", x)
+                if m3 and 1000 < int(m3.group(1)) < 32768:
+                    target = addr(x) + 4 + 4 * int(m3.group(1))
+                    split = next(j for j, y in enumerate(ins) if (addr(y) or 0) >= target)
+                    break
+            starts = [0, split] if split < len(ins) else [0]
+            assert any(x.startswith("buffer_load_dwordx4 a[") for x in ins), "%s: no resident-fragment loads" % sym
             for k, b in enumerate(starts):
                 e = starts[k + 1] if k + 1 < len(starts) else len(ins)
                 resident = set()
@@ -95,6 +105,19 @@ def test_resident_fragments_never_leave_agprs():
                     m2 = re.match(r"v_mfma_f32_16x16x32_f16 v\[\d+:\d+\], a\[(\d+):(\d+)\], v\[", x)
                     assert not (m2 and not set(range(int(m2.group(1)), int(m2.group(2)) + 1)) <= resident), \
                         "%s: MFMA reads an AGPR operand that is not a resident fragment: %s" % (sym, x)
+            # inline-asm loads are invisible to hipcc's hazard recognizer: an SGPR offset written by a VALU instruction
+            # (v_readfirstlane / v_readlane) needs 5 wait states before a VMEM instruction reads it
+            for i, x in enumerate(ins):
+                m2 = re.match(r"buffer_load_dwordx4 a\[\d+:\d+\], v\d+, s\[\d+:\d+\], (s\d+) offen", x)
+                if not m2:
+                    continue
+                waits = 0
+                for y in reversed(ins[max(0, i - 6):i]):
+                    if re.match(r"v_read(first)?lane_b32 %s," % m2.group(1), y):
+                        assert waits >= 5, "%s: %s only %d wait states after %s" % (sym, x.split("//")[0], waits, y.split("//")[0])
+                        break
+                    m3 = re.match(r"s_nop (\d+)", y)
+                    waits += int(m3.group(1)) + 1 if m3 else 1
             res = [x for x in ins if x.startswith("v_mfma_f32_16x16x32_f16") and re.search(r", a\[\d+:\d+\], v\[", x)]
             assert len(res) > 10, "%s: no MFMA reads its A operand from AGPRs -- residency is off" % sym
             checked += 1

@@ -16,7 +16,8 @@ from cadm_amd import synth
 from cadm_amd._lib import check
 from cadm_amd.synth import make_engine
 
-XDL_NAMES = ["state+noise", "bar", "L0 sweep", "bar", "hidden 1 sweep", "hidden bars", "head sweep", "bar", "hidden 2 sweep", "hidden 3+ sweep"]
+XDL_NAMES = ["state+noise", "bar", "L0 rest", "bar", "hidden 1 rest", "hidden bars", "head rest", "bar", "hidden 2 rest", "hidden 3+ rest",
+             "sweeps: to chunk 1", "sweeps: chunks", "sweeps: last epilogue"]
 NAMES = ["assembly", "bar0", "L0 mfma", "L0 epi", "bar1", "hid rebuild", "hid mfma", "hid epi", "hid bar",
          "out noise", "out rebuild", "out mfma", "out part wr", "bar5", "head epi", "bar6"]
 
