@@ -44,11 +44,12 @@ __global__ void pack_xdl_kernel(const XdlPackArgs a) {
         }
         const int grp = lane >> 4, m = lane & 15;
         int tile, c;
-        if (layer < g.NH) {                   // hidden-type outputs: tiles in groups of CADM_XDL_GROUP, chunk-major inside a group
-            const int gi = fj / (CADM_XDL_GROUP * nchl), jj = fj - CADM_XDL_GROUP * gi * nchl;
-            const int gs = (ntw - CADM_XDL_GROUP * gi) < CADM_XDL_GROUP ? (ntw - CADM_XDL_GROUP * gi) : CADM_XDL_GROUP;
+        if (layer < g.NH) {                   // hidden-type outputs: tiles in groups of xdl_group(w), chunk-major inside a group
+            const int gsz = xdl_group(w);
+            const int gi = fj / (gsz * nchl), jj = fj - gsz * gi * nchl;
+            const int gs = (ntw - gsz * gi) < gsz ? (ntw - gsz * gi) : gsz;
             c = jj / gs;
-            tile = g.tstart(w) + CADM_XDL_GROUP * gi + jj % gs;
+            tile = g.tstart(w) + gsz * gi + jj % gs;
         } else {                              // head: valid slots in order, chunk-major per slot
             int sv = fj / g.NCH;
             c = fj % g.NCH;

@@ -221,14 +221,15 @@ struct XHeadEpi {
     }
 };
 
-// One layer sweep of this wave: NTW tiles x NCHL chunks, CADM_XDL_GROUP tiles at a time.
+// One layer sweep of this wave: NTW tiles x NCHL chunks, GS tiles at a time.  SIDE: a group's epilogue runs stage by stage
+// between the next group's MFMAs (only the last one is exposed); !SIDE: every group's epilogue right behind its MFMAs.
 //   The first NRES fragments (consumption order) are register-resident (res[j][part], AGPRs, loaded once per workgroup);
 //   the other NFS = NF - NRES come through the ring: it holds streamed fragments 0..R-1 of this layer on entry and 0..R-1
 //   of the NEXT streamed layer (nx_nf of them exist) on exit.  wcur = byte offset of this layer's first STREAMED fragment.
 //   The B operand (the 16 rows' activations) is read from LDS chunk by chunk, XD-1 chunks ahead of its use.
 //   The epilogue of a tile group runs stage by stage between the MFMAs of the NEXT group (f16 MFMAs hide independent
 //   VALU work of the same wave); the last group's epilogue overlaps with the SIMD's other wave.
-template <class G, int NTW, int NCHL, int NRES, class Epi>
+template <class G, int NTW, int NCHL, int NRES, int GS, bool SIDE, class Epi>
 __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2], __amdgpu_buffer_rsrc_t rsrc, unsigned wcur,
                                           unsigned wnext, int nx_nf, const unsigned char* lds_in, int lane, const Epi& epi TS_PARAMS) {
     constexpr int R = G::R, NF = NTW * NCHL, NFS = NF - NRES, NFSPAD = rup(NFS, R);
@@ -249,7 +250,7 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
             if (jj - NFSPAD < nx_nf) xring_load<js % R>(ring, rsrc, wnext + (jj - NFSPAD) * CADM_XDL_FRAG_BYTES, lane);
         }
     };
-    constexpr int GS = CADM_XDL_GROUP, NG = (NTW + GS - 1) / GS, NST = Epi::NSTAGE;
+    constexpr int NG = (NTW + GS - 1) / GS, NST = Epi::NSTAGE;
     constexpr int NPR = G::NPROD;
     floatx4 hi[2][GS], lo[2][GS], ll[2][GS];   // [group parity][tile of the group]: the previous group is being finished
     typename Epi::State pst[GS];               // as side work while this group accumulates (no register moves in between)
@@ -259,7 +260,7 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
     static_for(std::make_integer_sequence<int, NG>{}, [&](auto gc) {
         constexpr int g = decltype(gc)::value, gp = g & 1, pp = gp ^ 1;
         constexpr int gs = (NTW - GS * g) < GS ? (NTW - GS * g) : GS;
-        constexpr int pgs = g > 0 ? GS : 0;                      // tiles of the previous group (groups before the last are full)
+        constexpr int pgs = (SIDE && g > 0) ? GS : 0;            // tiles of the previous group (groups before the last are full)
         static_for(std::make_integer_sequence<int, XD - 1>{}, [&](auto cc) { xload(cc); });
 #pragma unroll
         for (int k = 0; k < gs; ++k) {
@@ -295,7 +296,7 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
             }
             __builtin_amdgcn_sched_barrier(0);      // pin the software pipeline: no load hoisting across chunks
         });
-        if constexpr (g == NG - 1) {                // the last group's epilogue has no MFMAs of this wave left to hide behind
+        if constexpr (g == NG - 1 || !SIDE) {       // the last group's epilogue has no MFMAs of this wave left to hide behind
             TS(11)
 #pragma unroll
             for (int k = 0; k < gs; ++k) xdl_result_nops(hi[gp][k], lo[gp][k], ll[gp][k]);
@@ -311,7 +312,7 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
     });
 }
 
-template <class G, int NOISE, int NTW>
+template <class G, int NOISE, int NTW, bool SEQ>
 __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsmem) {
     constexpr int D = G::D, A = G::A, P = G::P, C = G::C, K0 = G::K0, NC0 = G::NC0, NCH = G::NCH, NTO = G::NTO;
     constexpr int NP = G::NP, NPI = G::NPI, NAI = G::NAI, ENV = G::ENV, R = G::R;
@@ -406,6 +407,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     // spare, and the first Q_l fragments of hidden layers l = 1..3 -- spread EVENLY, so that every layer streams about the
     // same number of bytes: the L2 -> CU path (~50 B/clk) is the scarce resource, and a layer that streams nothing
     // leaves it idle while its neighbours wait for it.  The STREAMED part of a layer is the tail of its stream region.
+    constexpr int GSZ = SEQ ? 1 : CADM_XDL_GROUP;                       // tiles per group (xdl_geo.h: xdl_group(wave))
     constexpr int NFH = NTW * NCH;                                      // fragments of a hidden layer (this wave)
     constexpr bool RESO = NTW == G::BASE && G::res_frags(NTW) >= NCH + 3;
     constexpr int RREM = G::res_frags(NTW) - (RESO ? NCH : 0);
@@ -603,7 +605,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                 // layer 0
                 {
                     const int nx = next_streamed(0);
-                    xdl_sweep<G, NTW, NC0, 0>(ring, nullptr, rsrc, w_l0, lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
+                    xdl_sweep<G, NTW, NC0, 0, GSZ, !SEQ>(ring, nullptr, rsrc, w_l0, lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
                                               hidden_epi(0, act_out) TS_ARGS);
                 }
                 TS(2)
@@ -615,7 +617,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                     act_in = act_out;
                     act_out = (act_in == G::ACTA) ? G::ACTB : G::ACTA;
                     const int nx = next_streamed(l);
-                    xdl_sweep<G, NTW, NCH, NRES>(ring, resH + RBASE, rsrc, lay_off(l), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
+                    xdl_sweep<G, NTW, NCH, NRES, GSZ, !SEQ>(ring, resH + RBASE, rsrc, lay_off(l), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
                                                  hidden_epi(l, act_out) TS_ARGS);
                     if (l == 1) { TS(4) } else if (l == 2) { TS(8) } else { TS(9) }
                     __syncthreads();
@@ -630,7 +632,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                 // ================= output head tile (mu | logvar of 8 dims) =================
                 if (nhead) {
                     const int nx = next_streamed(a.NH);
-                    xdl_sweep<G, 1, NCH, RESO ? NCH : 0>(ring, resO, rsrc, lay_off(a.NH), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
+                    xdl_sweep<G, 1, NCH, RESO ? NCH : 0, 1, false>(ring, resO, rsrc, lay_off(a.NH), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
                                                          XHeadEpi<G>{xsmem, xb, bias_off, a.NH * G::NT + ht, ht, lane} TS_ARGS);
                 }
             }
@@ -661,8 +663,18 @@ __global__ __launch_bounds__(G::NTHR) void rollout_xdl_kernel(const RolloutArgs 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // waves [0, EXTRA) own one hidden tile more than the others: two specialisations of the whole body, chosen per wave
     // (a scalar branch; every wave executes the same number of barriers)
-    if (G::EXTRA > 0 && wave < G::EXTRA) xdl_run<G, NOISE, G::BASE + 1>(a, xsmem_raw);
-    else xdl_run<G, NOISE, G::BASE>(a, xsmem_raw);
+    // and waves 4-7 go tile by tile (xdl_geo.h: xdl_group)
+    constexpr int HALF = G::NW / 2;
+    const bool seq = CADM_XDL_SEQ && wave >= HALF;
+    if (wave < G::EXTRA) {
+        if constexpr (G::EXTRA > 0) {
+            if (!seq) xdl_run<G, NOISE, G::BASE + 1, false>(a, xsmem_raw);
+            else if constexpr (CADM_XDL_SEQ && G::EXTRA > HALF) xdl_run<G, NOISE, G::BASE + 1, true>(a, xsmem_raw);
+        }
+    } else {
+        if (seq) { if constexpr (CADM_XDL_SEQ) xdl_run<G, NOISE, G::BASE, true>(a, xsmem_raw); }
+        else if constexpr (!CADM_XDL_SEQ || G::EXTRA < HALF) xdl_run<G, NOISE, G::BASE, false>(a, xsmem_raw);
+    }
 }
 
 template <class G, int NOISE>

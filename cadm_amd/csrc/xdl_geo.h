@@ -14,15 +14,20 @@
 //     tiles); head tiles (8 obs dims: mu0 mu1 lv0 lv1 per lane) go to the waves with the fewest hidden tiles first.
 //   * A "fragment" = one (tile, chunk) of weights = 2 split parts x 64 lanes x 16 B = 2 KB.  Per (member, wave) the
 //     stream stores the fragments in EXACTLY the order that wave consumes them during one rollout step:
-//     [layer 0][hidden 1 .. NH-1][head]; inside a layer tiles go in groups of CADM_XDL_GROUP, chunk-major inside a group
+//     [layer 0][hidden 1 .. NH-1][head]; inside a layer tiles go in groups of xdl_group(wave), chunk-major inside a group
 //     (xdl_frag_index), so the kernel addresses the stream linearly.
 #pragma once
 
 #define CADM_XDL_FRAG_BYTES 2048
-// tiles a wave accumulates at a time: 2 halves the LDS reads of the B operand (each group re-reads all of K); the last
-// group's epilogue is hidden by the SIMD's other wave either way (1 vs 2 measured within 2 % at BASELINE cfg2)
+// Tiles a wave accumulates at a time.  Waves 0-3 (the first wave of each SIMD) take their tiles two at a time and run
+// the epilogues at the end; waves 4-7 go tile by tile, each tile's epilogue right behind its MFMAs.  The two waves of a
+// SIMD are thereby out of phase: one wave's epilogue (VALU) meets the other's MFMAs instead of its epilogue
+// (a 16-cycle f16 MFMA hides only ~1 VALU op of its own wave, profiles/r2_issue_microbench.md).
 #ifndef CADM_XDL_GROUP
 #define CADM_XDL_GROUP 2
+#endif
+#ifndef CADM_XDL_SEQ
+#define CADM_XDL_SEQ 0                // measured: 211 vs 203 us per launch at cfg2 -- off
 #endif
 #define CADM_XDL_WAVES 8          // two waves per SIMD: one wave's waits (LDS, L2, epilogue chains) hide behind the other's MFMAs
 
@@ -59,10 +64,12 @@ inline XdlGeo make_xdl_geo(int K0, int HID, int D, int NH) {
     return g;
 }
 
-// position of fragment (local tile ti, chunk c) in a layer's consumption order, for a wave with ntw tiles:
-// tiles go in groups of CADM_XDL_GROUP, chunk-major inside a group
-__host__ __device__ constexpr int xdl_frag_index(int ntw, int nchl, int ti, int c) {
-    const int g = ti / CADM_XDL_GROUP;
-    const int gs = (ntw - CADM_XDL_GROUP * g) < CADM_XDL_GROUP ? (ntw - CADM_XDL_GROUP * g) : CADM_XDL_GROUP;
-    return CADM_XDL_GROUP * g * nchl + c * gs + (ti - CADM_XDL_GROUP * g);
+__host__ __device__ constexpr int xdl_group(int w) { return (CADM_XDL_SEQ && w >= CADM_XDL_WAVES / 2) ? 1 : CADM_XDL_GROUP; }
+
+// position of fragment (local tile ti, chunk c) in a layer's consumption order, for a wave with ntw tiles taken in
+// groups of gsz: chunk-major inside a group
+__host__ __device__ constexpr int xdl_frag_index(int ntw, int nchl, int ti, int c, int gsz) {
+    const int g = ti / gsz;
+    const int gs = (ntw - gsz * g) < gsz ? (ntw - gsz * g) : gsz;
+    return gsz * g * nchl + c * gs + (ti - gsz * g);
 }

@@ -79,19 +79,17 @@ def test_resident_fragments_never_leave_agprs():
             # The kernel body exists once per wave variant (tiles per wave); each variant loads ITS resident fragments
             # with a burst of "buffer_load_dwordx4 a[..]" and keeps them to the end.  hipcc may park ordinary VGPR values
             # in OTHER AGPRs (harmless spills); a copy into or out of a resident one is the hazard.
-            # variant boundary = target of the dispatch branch (the first far forward branch of the kernel)
-            def addr(x):
-                m3 = re.search(r"// ([0-9A-F]{8,}):", x)
-                return int(m3.group(1), 16) if m3 else None
-            split = len(ins)
-            for i, x in enumerate(ins[:400]):
-                m3 = re.match(r"s_cbranch_\w+ (\d+)", x)
-                if m3 and 1000 < int(m3.group(1)) < 32768:
-                    target = addr(x) + 4 + 4 * int(m3.group(1))
-                    split = next(j for j, y in enumerate(ins) if (addr(y) or 0) >= target)
-                    break
-            starts = [0, split] if split < len(ins) else [0]
-            assert any(x.startswith("buffer_load_dwordx4 a[") for x in ins), "%s: no resident-fragment loads" % sym
+            # variant k = [its prologue][burst of resident loads][tile loop][unconditional branch to the common exit]:
+            # a boundary is the first s_branch / s_endpgm behind the last MFMA that precedes the next burst
+            loads = [i for i, x in enumerate(ins) if x.startswith("buffer_load_dwordx4 a[")]
+            assert loads, "%s: no resident-fragment loads" % sym
+            bursts = [i for k, i in enumerate(loads) if k == 0 or i - loads[k - 1] > 200]
+            mfma_at = [i for i, x in enumerate(ins) if x.startswith("v_mfma_")]
+            starts = [0]
+            for nb in bursts[1:]:
+                last = max(i for i in mfma_at if i < nb)
+                end = next(i for i in range(last, nb) if ins[i].startswith(("s_branch", "s_endpgm")))
+                starts.append(end + 1)
             for k, b in enumerate(starts):
                 e = starts[k + 1] if k + 1 < len(starts) else len(ins)
                 resident = set()
