@@ -703,7 +703,7 @@ template <int ENV, int HID, int... CS>
 int dispatch_ctx_list(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) {
     int rc = CADM_EINVAL;
     bool hit = false;
-    ((ctx->C == CS ? (hit = true, rc = ctx->use_xdl ? xdl_launch<XC<ENV, CS, HID>>(ctx, a, rpm, s) : launch<RC<ENV, CS, HID, 1>>(ctx, a, rpm, s), 0) : 0), ...);
+    ((ctx->C == CS ? (hit = true, rc = ctx->use_xdl ? xdl_launch<ENV, CS, HID>(ctx, a, rpm, s) : launch<RC<ENV, CS, HID, 1>>(ctx, a, rpm, s), 0) : 0), ...);
     if (!hit) cadm_set_error("rollout: context_out_dim %d not compiled in (built with CTXS = " CADM_STR(CADM_CTX_LIST) ")", ctx->C);
     return rc;
 }

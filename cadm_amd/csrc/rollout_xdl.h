@@ -33,9 +33,11 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define CADM_XDL_RING 4
 #endif
 
-template <int ENV_, int C_, int HID_>
+// MT = row tiles (of 16 rows) a workgroup advances together.  2 for large batches: every weight fragment then feeds two sets
+// of MFMAs (half the weight stream, half the barriers and sweep start-ups per row), all 512 threads hold rollout state.
+template <int ENV_, int C_, int HID_, int MT_ = 1>
 struct XC {
-    static constexpr int ENV = ENV_, C = C_, HID = HID_;
+    static constexpr int ENV = ENV_, C = C_, HID = HID_, MT = MT_;
     static constexpr int D = env_D(ENV), A = env_A(ENV), P = env_P(ENV);
     static constexpr int K0 = P + A + C;
     static constexpr int NC0 = (K0 + 31) / 32;            // chunks of layer 0
@@ -53,11 +55,12 @@ struct XC {
     static constexpr int NP = (D + 1) / 2, NPI = (NP + 15) / 16, NAI = (A + 15) / 16;
     static_assert(BASE >= 1, "hidden width too small for the 8-wave tile split (>= 128)");
     // LDS carve (bytes)
-    static constexpr int XIN = 0;                                  // [2 parts][NC0][64 lanes] x 16 B
-    static constexpr int ACTA = XIN + 2 * NC0 * 1024;              // [2][NCH][64] x 16 B
-    static constexpr int ACTB = ACTA + 2 * NCH * 1024;
-    static constexpr int OFULL = ACTB + 2 * NCH * 1024;            // [NTO][64] x float4
-    static constexpr int STATS = OFULL + NTO * 1024;               // floats
+    static constexpr int XIN = 0;                                  // [MT][2 parts][NC0][64 lanes] x 16 B
+    static constexpr int XIN_T = 2 * NC0 * 1024, ACT_T = 2 * NCH * 1024, OFULL_T = NTO * 1024;      // bytes per row tile
+    static constexpr int ACTA = XIN + MT * XIN_T;                  // [MT][2][NCH][64] x 16 B
+    static constexpr int ACTB = ACTA + MT * ACT_T;
+    static constexpr int OFULL = ACTB + MT * ACT_T;                // [MT][NTO][64] x float4
+    static constexpr int STATS = OFULL + MT * OFULL_T;             // floats
     static constexpr int ST_OBS_MEAN = 0, ST_OBS_DEN = P, ST_ACT_MEAN = 2 * P, ST_ACT_DEN = 2 * P + A;
     // per feature-slot constants (head statistics, derived-feature slots): read from LDS in every state phase instead of
     // being held in ~26 registers across the MFMA sweeps
@@ -65,7 +68,8 @@ struct XC {
     static constexpr int TAB = STATS + rup((2 * P + 2 * A) * 4, 16);
     // Gaussian-head noise, produced by waves 4-7 while waves 0-3 run the state update: [step parity][pair slot][fg][row] x 2
     static constexpr int ZB = TAB + NPI * 16 * TABW * 4;
-    static constexpr int CTRL = ZB + 2 * NPI * 256 * 8;                 // + 16 * H floats (dynamic)
+    static constexpr int ZB_T = 2 * NPI * 256 * 8;                      // bytes per row tile
+    static constexpr int CTRL = ZB + MT * ZB_T;                         // + MT * 16 * H floats (dynamic)
     // Bias tiles (fp32, D layout) live in LDS when they fit next to the rest (a bias read from global memory in a tile's
     // epilogue would sit BEHIND the ring's weight loads in the in-order vmcnt queue and drain the whole ring);
     // otherwise they are fetched at the start of a sweep, ahead of that sweep's ring loads.
@@ -80,16 +84,22 @@ struct XC {
 #ifndef CADM_XDL_RES_FRAGS
 #define CADM_XDL_RES_FRAGS 13       // waves with BASE hidden tiles
 #endif
+#ifndef CADM_XDL_RES_MT2_LESS
+#define CADM_XDL_RES_MT2_LESS 3     // two row tiles: twice the accumulators, operand registers and rollout state
+#endif
 #ifndef CADM_XDL_RES_FRAGS_X
 #define CADM_XDL_RES_FRAGS_X 11     // waves with BASE + 1 hidden tiles (more accumulators / epilogue state live)
 #endif
     static constexpr bool ASM_MFMA = CADM_XDL_RES && NCH <= 8;     // asm MFMAs (AGPR-resident operands) vs builtins
     static constexpr int res_frags(int ntw) {      // (wide observations keep two pair slots of rollout state per thread)
-        return (!CADM_XDL_RES || NCH > 8) ? 0 : (ntw == BASE ? CADM_XDL_RES_FRAGS : CADM_XDL_RES_FRAGS_X) - (NPI > 1 ? 2 : 0);
+        return (!CADM_XDL_RES || NCH > 8) ? 0
+               : MT > 1 ? (ntw >= 2 ? CADM_XDL_RES_FRAGS_X : CADM_XDL_RES_FRAGS) - (NPI > 1 ? 2 : 0) - CADM_XDL_RES_MT2_LESS
+                        : (ntw == BASE ? CADM_XDL_RES_FRAGS : CADM_XDL_RES_FRAGS_X) - (NPI > 1 ? 2 : 0);
     }
     static constexpr int MAX_NH_LDS = 4;
     static constexpr int BIAS_BYTES = (MAX_NH_LDS * NT + NTO) * 1024;
-    static constexpr bool BIAS_LDS = CTRL + 16 * 64 * 4 + BIAS_BYTES <= 150 * 1024;
+    static constexpr bool BIAS_LDS = CTRL + MT * 16 * 64 * 4 + BIAS_BYTES <= 154 * 1024;
+    static constexpr int XDEPTH = MT > 1 ? 2 : 3;          // B-operand chunks in registers (lookahead XDEPTH - 1)
 };
 
 template <class G>
@@ -166,7 +176,7 @@ struct XHiddenEpi {
         else return *reinterpret_cast<const floatx4*>(xb + bt * 4);
     }
     template <int S>
-    __device__ __forceinline__ void stage(int ti, const floatx4& hi, const floatx4& lo, const floatx4& ll, State& st) const {
+    __device__ __forceinline__ void stage(int ti, int hh, const floatx4& hi, const floatx4& lo, const floatx4& ll, State& st) const {
         if constexpr (S == 0) {            // pre-activation (hi + 2^-11 lo), f16-range clamp, exp2 argument
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -189,7 +199,7 @@ struct XHiddenEpi {
             for (int r = 0; r < 4; ++r) st.h2[r] = (_Float16)fmaf((float)st.h1[r], -2048.0f, st.v[r] * 2048.0f);
         } else {
             const int Tg = tstart + ti;
-            unsigned char* dst = xsmem + out + ((Tg >> 1) * 64 + lane) * 16 + (Tg & 1) * 8;
+            unsigned char* dst = xsmem + out + hh * G::ACT_T + ((Tg >> 1) * 64 + lane) * 16 + (Tg & 1) * 8;
             *reinterpret_cast<f16x4*>(dst) = st.h1;
             *reinterpret_cast<f16x4*>(dst + G::NCH * 1024) = st.h2;
         }
@@ -210,14 +220,14 @@ struct XHeadEpi {
         else return *reinterpret_cast<const floatx4*>(xb + bt * 4);
     }
     template <int S>
-    __device__ __forceinline__ void stage(int, const floatx4& hi, const floatx4& lo, const floatx4& ll, State&) const {
+    __device__ __forceinline__ void stage(int, int hh, const floatx4& hi, const floatx4& lo, const floatx4& ll, State&) const {
         floatx4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             v[r] = fmaf(lo[r], 4.8828125e-4f, hi[r]);
             if constexpr (G::NPROD == 4) v[r] = fmaf(ll[r], 2.384185791015625e-7f, v[r]);
         }
-        *reinterpret_cast<floatx4*>(xsmem + G::OFULL + (ht * 64 + lane) * 16) = v;
+        *reinterpret_cast<floatx4*>(xsmem + G::OFULL + hh * G::OFULL_T + (ht * 64 + lane) * 16) = v;
     }
 };
 
@@ -234,12 +244,16 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
                                           unsigned wnext, int nx_nf, const unsigned char* lds_in, int lane, const Epi& epi TS_PARAMS) {
     constexpr int R = G::R, NF = NTW * NCHL, NFS = NF - NRES, NFSPAD = rup(NFS, R);
     static_assert(NRES >= 0 && NRES <= NF, "bad resident fragment count");
-    constexpr int XD = NCHL < 3 ? NCHL : 3;
-    f16x8 X1[XD], X2[XD];
+    constexpr int MT = G::MT, XD = NCHL < G::XDEPTH ? NCHL : G::XDEPTH;
+    constexpr int IN_T = 2 * NCHL * 1024;                  // bytes of one row tile's operand block
+    f16x8 X1[XD][MT], X2[XD][MT];
     auto xload = [&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        X1[c % XD] = *reinterpret_cast<const f16x8*>(lds_in + ((0 * NCHL + c) * 64 + lane) * 16);
-        X2[c % XD] = *reinterpret_cast<const f16x8*>(lds_in + ((1 * NCHL + c) * 64 + lane) * 16);
+#pragma unroll
+        for (int h = 0; h < MT; ++h) {
+            X1[c % XD][h] = *reinterpret_cast<const f16x8*>(lds_in + h * IN_T + ((0 * NCHL + c) * 64 + lane) * 16);
+            X2[c % XD][h] = *reinterpret_cast<const f16x8*>(lds_in + h * IN_T + ((1 * NCHL + c) * 64 + lane) * 16);
+        }
     };
     auto prefetch = [&](auto jsc) {      // after streamed time slot js: refill its ring slot
         constexpr int js = decltype(jsc)::value;
@@ -252,8 +266,8 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
     };
     constexpr int NG = (NTW + GS - 1) / GS, NST = Epi::NSTAGE;
     constexpr int NPR = G::NPROD;
-    floatx4 hi[2][GS], lo[2][GS], ll[2][GS];   // [group parity][tile of the group]: the previous group is being finished
-    typename Epi::State pst[GS];               // as side work while this group accumulates (no register moves in between)
+    floatx4 hi[2][GS][MT], lo[2][GS][MT], ll[2][GS][MT];   // [group parity][tile of the group][row tile]: the previous group is
+    typename Epi::State pst[GS][MT];                       // finished as side work while this group accumulates (no register moves)
     // stage s of the side epilogue goes to chunks >= 1, i.e. at least one chunk of MFMAs after the accumulators were
     // last written (the compiler cannot see asm MFMA latency)
     auto stage_chunk = [](int st) constexpr { return NCHL == 1 ? 0 : NST == 1 ? 1 : 1 + st * (NCHL - 2) / (NST - 1); };
@@ -263,20 +277,25 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
         constexpr int pgs = (SIDE && g > 0) ? GS : 0;            // tiles of the previous group (groups before the last are full)
         static_for(std::make_integer_sequence<int, XD - 1>{}, [&](auto cc) { xload(cc); });
 #pragma unroll
-        for (int k = 0; k < gs; ++k) {
-            hi[gp][k] = epi.init(GS * g + k); lo[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f}; ll[gp][k] = floatx4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int k = 0; k < gs; ++k)
 #pragma unroll
-        for (int k = 0; k < gs; ++k) xdl_operand_nops(hi[gp][k], lo[gp][k], ll[gp][k]);      // VALU-zeroed accumulators -> MFMA srcC
+            for (int h = 0; h < MT; ++h) {
+                hi[gp][k][h] = epi.init(GS * g + k); lo[gp][k][h] = floatx4{0.f, 0.f, 0.f, 0.f}; ll[gp][k][h] = floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int k = 0; k < gs; ++k)
+#pragma unroll
+            for (int h = 0; h < MT; ++h) xdl_operand_nops(hi[gp][k][h], lo[gp][k][h], ll[gp][k][h]);      // VALU-zeroed accumulators -> MFMA srcC
         static_for(std::make_integer_sequence<int, NCHL>{}, [&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int j0 = GS * g * NCHL + c * gs;
             if constexpr (c == 1 && g == 0) { TS(10) }
             if constexpr (c + XD - 1 < NCHL) xload(std::integral_constant<int, c + XD - 1>{});
-            static_for(std::make_integer_sequence<int, NPR * gs>{}, [&](auto mc) {      // hi(k).. lo(k).. lo'(k).. [ll(k)..]
-                constexpr int k = decltype(mc)::value % gs, prod = decltype(mc)::value / gs, j = j0 + k;
-                floatx4& acc = prod == 0 ? hi[gp][k] : prod == 3 ? ll[gp][k] : lo[gp][k];
-                const f16x8& x = prod >= 2 ? X2[c % XD] : X1[c % XD];
+            static_for(std::make_integer_sequence<int, NPR * gs * MT>{}, [&](auto mc) {      // hi(k,h).. lo(k,h).. lo'(k,h).. [ll(k,h)..]
+                constexpr int h = decltype(mc)::value % MT, k = (decltype(mc)::value / MT) % gs, prod = decltype(mc)::value / (MT * gs);
+                constexpr int j = j0 + k;
+                floatx4& acc = prod == 0 ? hi[gp][k][h] : prod == 3 ? ll[gp][k][h] : lo[gp][k][h];
+                const f16x8& x = prod >= 2 ? X2[c % XD][h] : X1[c % XD][h];
                 constexpr int part = (prod == 1 || prod == 3) ? 1 : 0;
                 if constexpr (j < NRES) xmfma_res(acc, res[j][part], x);
                 else xmfma_ring<G::ASM_MFMA>(acc, ring.w[(j - NRES) % R][part], x);
@@ -290,7 +309,10 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
                     constexpr int st = decltype(sc)::value;
                     if constexpr (stage_chunk(st) == c) {
 #pragma unroll
-                        for (int k = 0; k < pgs; ++k) epi.template stage<st>(GS * (g - 1) + k, hi[pp][k], lo[pp][k], ll[pp][k], pst[k]);
+                        for (int k = 0; k < pgs; ++k)
+#pragma unroll
+                            for (int h = 0; h < MT; ++h)
+                                epi.template stage<st>(GS * (g - 1) + k, h, hi[pp][k][h], lo[pp][k][h], ll[pp][k][h], pst[k][h]);
                     }
                 });
             }
@@ -299,10 +321,15 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
         if constexpr (g == NG - 1 || !SIDE) {       // the last group's epilogue has no MFMAs of this wave left to hide behind
             TS(11)
 #pragma unroll
-            for (int k = 0; k < gs; ++k) xdl_result_nops(hi[gp][k], lo[gp][k], ll[gp][k]);
+            for (int k = 0; k < gs; ++k)
+#pragma unroll
+                for (int h = 0; h < MT; ++h) xdl_result_nops(hi[gp][k][h], lo[gp][k][h], ll[gp][k][h]);
             static_for(std::make_integer_sequence<int, NST>{}, [&](auto sc) {
 #pragma unroll
-                for (int k = 0; k < gs; ++k) epi.template stage<decltype(sc)::value>(GS * g + k, hi[gp][k], lo[gp][k], ll[gp][k], pst[k]);
+                for (int k = 0; k < gs; ++k)
+#pragma unroll
+                    for (int h = 0; h < MT; ++h)
+                        epi.template stage<decltype(sc)::value>(GS * g + k, h, hi[gp][k][h], lo[gp][k][h], ll[gp][k][h], pst[k][h]);
             });
         }
     });
@@ -316,13 +343,7 @@ template <class G, int NOISE, int NTW, bool SEQ>
 __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsmem) {
     constexpr int D = G::D, A = G::A, P = G::P, C = G::C, K0 = G::K0, NC0 = G::NC0, NCH = G::NCH, NTO = G::NTO;
     constexpr int NP = G::NP, NPI = G::NPI, NAI = G::NAI, ENV = G::ENV, R = G::R;
-    float* stats = reinterpret_cast<float*>(xsmem + G::STATS);
-    float* ctrl_s = reinterpret_cast<float*>(xsmem + G::CTRL);
-    float* ofull = reinterpret_cast<float*>(xsmem + G::OFULL);
-    float2* zb = reinterpret_cast<float2*>(xsmem + G::ZB);
-    const int bias_off = G::CTRL + rup(16 * a.H * 4, 16);      // LDS byte offset of the bias tiles (BIAS_LDS only)
-    const bool bias_lds = G::BIAS_LDS && a.bias_lds;
-
+    constexpr int MT = G::MT;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -330,8 +351,18 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     const int grp = blockIdx.x % a.wgs_per_member;
     const int H = a.H;
     const int arow = tid & 15, fg = (tid >> 4) & 15;
-    const bool feat = wave < 4;                 // the 256 feature threads (rollout state, input assembly)
+    // feature threads (rollout state, input assembly): MT = 1: waves 0-3, their twins in waves 4-7 make the noise;
+    // MT = 2: everybody -- waves 0-3 hold row tile 0, waves 4-7 row tile 1, and make their own noise
+    const bool feat = MT > 1 || wave < 4;
+    const int rt = MT > 1 ? (wave >> 2) : 0;                   // row tile of this thread's state
     const int ntiles = (a.rows_per_member + 15) / 16;
+    float* stats = reinterpret_cast<float*>(xsmem + G::STATS);
+    float* ctrl_s = reinterpret_cast<float*>(xsmem + G::CTRL) + rt * 16 * H;
+    float* ofull = reinterpret_cast<float*>(xsmem + G::OFULL + rt * G::OFULL_T);
+    float2* zb = reinterpret_cast<float2*>(xsmem + G::ZB + rt * G::ZB_T);
+    const int xin_rt = G::XIN + rt * G::XIN_T;                 // this thread's row tile inside x_in
+    const int bias_off = G::CTRL + rup(MT * 16 * a.H * 4, 16);      // LDS byte offset of the bias tiles (BIAS_LDS only)
+    const bool bias_lds = G::BIAS_LDS && a.bias_lds;
 
     // ---- once per workgroup: stats, zero padding of the operand buffers ----
     for (int i = tid; i < P; i += G::NTHR) {
@@ -353,7 +384,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     const int arow16 = arow * 16;
     auto xin_off = [&](int f) { return xin_base(f) + arow16; };
     float* tab = reinterpret_cast<float*>(xsmem + G::TAB);
-    if (arow == 0 && feat) {
+    if (arow == 0 && wave < 4) {
 #pragma unroll
         for (int pi = 0; pi < NPI; ++pi) {
             float* te = tab + (pi * 16 + fg) * G::TABW;
@@ -386,8 +417,8 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         v = fminf(fmaxf(v, -65000.0f), 65000.0f);                       // f16 range (only diverged rows ever get here)
         _Float16 h1, h2;
         xsplit(v, h1, h2);
-        *reinterpret_cast<_Float16*>(xsmem + G::XIN + off) = h1;
-        *reinterpret_cast<_Float16*>(xsmem + G::XIN + NC0 * 1024 + off) = h2;
+        *reinterpret_cast<_Float16*>(xsmem + xin_rt + off) = h1;
+        *reinterpret_cast<_Float16*>(xsmem + xin_rt + NC0 * 1024 + off) = h2;
     };
 
     // ---- weight stream of this (member, wave) ----
@@ -456,9 +487,9 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         });
     }
 
-    for (int tile = grp; tile < ntiles; tile += a.wgs_per_member) {
+    for (int tile = grp; tile < (ntiles + MT - 1) / MT; tile += a.wgs_per_member) {      // groups of MT row tiles
         // ---- this thread's row ----
-        int re = tile * 16 + arow;
+        int re = (tile * MT + rt) * 16 + arow;
         const bool valid = re < a.rows_per_member;
         if (!valid) re = a.rows_per_member - 1;
         const int cidx = re / a.PE, jl = re % a.PE;
@@ -573,7 +604,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
             // Gaussian-head noise of THIS step (consumed by the next state phase): made by the twin thread in waves 4-7,
             // which have nothing else to do while waves 0-3 update the state
             if constexpr (NOISE != CADM_NOISE_NONE) {
-                if (!feat) {
+                if (MT > 1 || !feat) {
 #pragma unroll
                     for (int pi = 0; pi < NPI; ++pi) {
                         const int dp = fg + 16 * pi;
@@ -643,7 +674,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         TS_DUMP
 
         // ---- a row's return = sum of its threads' reward parts, in fixed slot order ----
-        float* ret_s = reinterpret_cast<float*>(xsmem + G::OFULL);
+        float* ret_s = ofull;                      // (this row tile's head buffer, free between tiles)
         __syncthreads();
         if (feat) ret_s[arow * 16 + fg] = ret;
         __syncthreads();
@@ -680,13 +711,13 @@ __global__ __launch_bounds__(G::NTHR) void rollout_xdl_kernel(const RolloutArgs 
 template <class G, int NOISE>
 int xdl_launch_noise(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipStream_t s) {
     RolloutArgs args = a;
-    const int tiles = (rows_per_member + 15) / 16;
+    const int tiles = ((rows_per_member + 15) / 16 + G::MT - 1) / G::MT;       // groups of MT row tiles
     // one workgroup of 8 waves per CU (256 registers per wave); workgroups walk over their member's row tiles
     int per_member = ctx->n_cus / ctx->E;
     if (per_member < 1) per_member = 1;
     args.wgs_per_member = tiles < per_member ? tiles : per_member;
     args.rows_per_member = rows_per_member;
-    size_t lds = (size_t)G::CTRL + (size_t)rup(16 * a.H * 4, 16);
+    size_t lds = (size_t)G::CTRL + (size_t)rup(G::MT * 16 * a.H * 4, 16);
     const size_t bias_b = (size_t)(a.NH * G::NT + G::NTO) * 1024;
     args.bias_lds = G::BIAS_LDS;
     if (G::BIAS_LDS) lds += bias_b;
@@ -705,10 +736,22 @@ int xdl_launch_noise(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, h
 }
 
 template <class G>
-int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipStream_t s) {
+int xdl_launch_mt(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipStream_t s) {
     if (a.deterministic) return xdl_launch_noise<G, CADM_NOISE_NONE>(ctx, a, rows_per_member, s);
     if (a.eps) return xdl_launch_noise<G, CADM_NOISE_INJECT>(ctx, a, rows_per_member, s);
     return xdl_launch_noise<G, CADM_NOISE_PHILOX>(ctx, a, rows_per_member, s);
+}
+
+// Two row tiles per workgroup once every workgroup has at least two tiles to walk over.
+template <int ENV, int C, int HID>
+int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipStream_t s) {
+    const int tiles = (rows_per_member + 15) / 16;
+    int per_member = ctx->n_cus / ctx->E;
+    if (per_member < 1) per_member = 1;
+    bool two = tiles >= 2 * per_member;
+    if (const char* ev = getenv("CADM_XDL_MT")) two = ev[0] == '2';        // developer override (A/B measurements)
+    return two ? xdl_launch_mt<XC<ENV, C, HID, 2>>(ctx, a, rows_per_member, s)
+               : xdl_launch_mt<XC<ENV, C, HID, 1>>(ctx, a, rows_per_member, s);
 }
 
 }  // namespace

@@ -67,7 +67,7 @@ def test_resident_fragments_never_leave_agprs():
     for img in images:
         for sym, ins in _kernels(img).items():
             # XC<ENV, C, HID>: geometries with HID <= 256 use the asm MFMA path with AGPR-resident fragments
-            m = re.search(r"2XCILi(\d+)ELi(\d+)ELi(\d+)EEE", sym)
+            m = re.search(r"2XCILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEE", sym)        # XC<ENV, C, HID, MT>
             assert m, sym
             hid = int(m.group(3))
             n_mfma = sum(1 for x in ins if x.startswith("v_mfma_f32_16x16x32_f16"))
@@ -81,10 +81,15 @@ def test_resident_fragments_never_leave_agprs():
             # in OTHER AGPRs (harmless spills); a copy into or out of a resident one is the hazard.
             # variant k = [its prologue][burst of resident loads][tile loop][unconditional branch to the common exit]:
             # a boundary is the first s_branch / s_endpgm behind the last MFMA that precedes the next burst
-            loads = [i for i, x in enumerate(ins) if x.startswith("buffer_load_dwordx4 a[")]
+            # (the asm statement of a resident load is "s_nop 4; buffer_load_dwordx4 a[..]": that pair identifies them --
+            #  hipcc may also point ordinary ring loads at spare AGPRs, which it tracks itself)
+            loads = [i for i, x in enumerate(ins) if i > 0 and x.startswith("buffer_load_dwordx4 a[") and ins[i - 1].startswith("s_nop 4")]
             assert loads, "%s: no resident-fragment loads" % sym
-            bursts = [i for k, i in enumerate(loads) if k == 0 or i - loads[k - 1] > 200]
             mfma_at = [i for i, x in enumerate(ins) if x.startswith("v_mfma_")]
+            bursts = []      # a new burst = a resident load with MFMAs between it and the previous burst's loads
+            for k, i in enumerate(loads):
+                if k == 0 or any(loads[k - 1] < m < i for m in mfma_at):
+                    bursts.append(i)
             starts = [0]
             for nb in bursts[1:]:
                 last = max(i for i in mfma_at if i < nb)
@@ -93,9 +98,9 @@ def test_resident_fragments_never_leave_agprs():
             for k, b in enumerate(starts):
                 e = starts[k + 1] if k + 1 < len(starts) else len(ins)
                 resident = set()
-                for x in ins[b:e]:
-                    m2 = re.match(r"buffer_load_dwordx4 a\[(\d+):(\d+)\]", x)
-                    if m2:
+                for i in loads:
+                    if b <= i < e:
+                        m2 = re.match(r"buffer_load_dwordx4 a\[(\d+):(\d+)\]", ins[i])
                         resident.update(range(int(m2.group(1)), int(m2.group(2)) + 1))
                 for x in ins[b:e]:
                     m2 = re.match(r"v_accvgpr_write_b32 a(\d+),", x) or re.match(r"v_accvgpr_read_b32 v\d+, a(\d+)", x)
@@ -105,7 +110,8 @@ def test_resident_fragments_never_leave_agprs():
                         "%s: MFMA reads an AGPR operand that is not a resident fragment: %s" % (sym, x)
             # inline-asm loads are invisible to hipcc's hazard recognizer: an SGPR offset written by a VALU instruction
             # (v_readfirstlane / v_readlane) needs 5 wait states before a VMEM instruction reads it
-            for i, x in enumerate(ins):
+            for i in loads:
+                x = ins[i]
                 m2 = re.match(r"buffer_load_dwordx4 a\[\d+:\d+\], v\d+, s\[\d+:\d+\], (s\d+) offen", x)
                 if not m2:
                     continue
