@@ -19,6 +19,7 @@ struct RolloutArgs {
     int m, n_local, n_global, cand_offset, E, p, PE, H, NH, it, quirks, deterministic, norm_actions;
     uint32_t seed, call;
     int wgs_per_member, rows_per_member;
+    int tile0, tile_count;            // xdl kernel: row tiles [tile0, tile0 + tile_count) of every member in this launch
     int bias_lds;                     // xdl kernel: bias tiles staged in LDS
     unsigned long long* tbuf;   // CADM_PHASE_TIMING builds only
 };

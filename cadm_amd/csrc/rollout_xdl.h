@@ -355,7 +355,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     // MT = 2: everybody -- waves 0-3 hold row tile 0, waves 4-7 row tile 1, and make their own noise
     const bool feat = MT > 1 || wave < 4;
     const int rt = MT > 1 ? (wave >> 2) : 0;                   // row tile of this thread's state
-    const int ntiles = (a.rows_per_member + 15) / 16;
+    const int ntiles = a.tile_count;                            // row tiles of this launch: [tile0, tile0 + tile_count) of the member
     float* stats = reinterpret_cast<float*>(xsmem + G::STATS);
     float* ctrl_s = reinterpret_cast<float*>(xsmem + G::CTRL) + rt * 16 * H;
     float* ofull = reinterpret_cast<float*>(xsmem + G::OFULL + rt * G::OFULL_T);
@@ -489,7 +489,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
 
     for (int tile = grp; tile < (ntiles + MT - 1) / MT; tile += a.wgs_per_member) {      // groups of MT row tiles
         // ---- this thread's row ----
-        int re = (tile * MT + rt) * 16 + arow;
+        int re = (a.tile0 + tile * MT + rt) * 16 + arow;
         const bool valid = re < a.rows_per_member;
         if (!valid) re = a.rows_per_member - 1;
         const int cidx = re / a.PE, jl = re % a.PE;
@@ -711,8 +711,9 @@ __global__ __launch_bounds__(G::NTHR) void rollout_xdl_kernel(const RolloutArgs 
 template <class G, int NOISE>
 int xdl_launch_noise(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipStream_t s) {
     RolloutArgs args = a;
-    const int tiles = ((rows_per_member + 15) / 16 + G::MT - 1) / G::MT;       // groups of MT row tiles
-    // one workgroup of 8 waves per CU (256 registers per wave); workgroups walk over their member's row tiles
+    // this launch covers row tiles [a.tile0, a.tile0 + a.tile_count) of every member, in groups of MT;
+    // one workgroup of 8 waves per CU (256 registers per wave); workgroups walk over their member's groups
+    const int tiles = (a.tile_count + G::MT - 1) / G::MT;
     int per_member = ctx->n_cus / ctx->E;
     if (per_member < 1) per_member = 1;
     args.wgs_per_member = tiles < per_member ? tiles : per_member;
@@ -742,16 +743,30 @@ int xdl_launch_mt(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipS
     return xdl_launch_noise<G, CADM_NOISE_PHILOX>(ctx, a, rows_per_member, s);
 }
 
-// Two row tiles per workgroup once every workgroup has at least two tiles to walk over.
+// Two row tiles per workgroup once every workgroup has at least two tiles to walk over.  The member's tiles are then cut
+// in two launches so that no workgroup idles through a whole two-tile round: the first takes as many FULL rounds of tile
+// pairs as there are (every workgroup the same number), the second the remainder -- as single tiles (one-tile flavour) if
+// they fit one round, else as one more round of pairs.  Rows are independent, so the cut does not change any result.
 template <int ENV, int C, int HID>
-int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipStream_t s) {
+int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a0, int rows_per_member, hipStream_t s) {
+    RolloutArgs a = a0;
     const int tiles = (rows_per_member + 15) / 16;
     int per_member = ctx->n_cus / ctx->E;
     if (per_member < 1) per_member = 1;
-    bool two = tiles >= 2 * per_member;
-    if (const char* ev = getenv("CADM_XDL_MT")) two = ev[0] == '2';        // developer override (A/B measurements)
-    return two ? xdl_launch_mt<XC<ENV, C, HID, 2>>(ctx, a, rows_per_member, s)
-               : xdl_launch_mt<XC<ENV, C, HID, 1>>(ctx, a, rows_per_member, s);
+    a.tile0 = 0;
+    a.tile_count = tiles;
+    int flavour = tiles >= 2 * per_member ? 2 : 1;
+    if (const char* ev = getenv("CADM_XDL_MT")) flavour = ev[0] == '2' ? -2 : -1;        // developer override: one launch, forced flavour
+    if (flavour == 1 || flavour == -1) return xdl_launch_mt<XC<ENV, C, HID, 1>>(ctx, a, rows_per_member, s);
+    if (flavour == -2) return xdl_launch_mt<XC<ENV, C, HID, 2>>(ctx, a, rows_per_member, s);
+    const int full = (tiles / (2 * per_member)) * 2 * per_member;         // tiles in full rounds of pairs
+    a.tile_count = full;
+    int rc = xdl_launch_mt<XC<ENV, C, HID, 2>>(ctx, a, rows_per_member, s);
+    if (rc || full == tiles) return rc;
+    a.tile0 = full;
+    a.tile_count = tiles - full;
+    return a.tile_count <= per_member ? xdl_launch_mt<XC<ENV, C, HID, 1>>(ctx, a, rows_per_member, s)
+                                      : xdl_launch_mt<XC<ENV, C, HID, 2>>(ctx, a, rows_per_member, s);
 }
 
 }  // namespace
