@@ -1,5 +1,6 @@
 """Determinism / stability soak: repeated plans must be bit-identical, twin engines trained on the same batches must stay
-bit-identical (ragged batch sizes included).  python tools/soak.py [seconds]"""
+bit-identical (ragged batch sizes included).  python tools/soak.py [seconds] [candidates]
+(candidates >= 1000 exercises the two-row-tile rollout flavour and its split launches)"""
 import sys, os, time
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, torch
@@ -10,7 +11,8 @@ prob = synth.make_problem(env="halfcheetah", context=True, E=5, m=1, H=30, train
 engA, engB = make_engine(prob, p=20), make_engine(prob, p=20)
 WD = (0.000025, 0.00005, 0.000075, 0.000075, 0.0001); CWD = (0.000025, 0.00005, 0.000075)
 for e in (engA, engB): e.train_configure(1e-3, WD, CWD, 1.0, 0.5, max_batch=256)
-args = (prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], 200)
+NC = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+args = (prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], NC)
 ref_plan = engA.cem_plan(*args, seed=7, call=1).clone()
 it = 0; nplan = 0; ntrain = 0
 rng = np.random.default_rng(0)
@@ -33,4 +35,4 @@ while time.time() < t_end:
     assert torch.isfinite(la).all()
     engA.repack(); ref_plan = engA.cem_plan(*args, seed=7, call=1).clone()      # weights changed: new reference plan
 torch.cuda.synchronize()
-print("soak OK: %d iterations, %d plans, %d train steps per engine, deterministic throughout" % (it, nplan, ntrain))
+print("soak OK (%d candidates): %d iterations, %d plans, %d train steps per engine, deterministic throughout" % (NC, it, nplan, ntrain))
