@@ -266,6 +266,9 @@ def main():
                      "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/r2_pmc_traffic_%s.json (a separate "
                                      "rocprofv3 --pmc pass of this command, NOT measured in this run)" % args.config,
                      "kernel": "rollout_xdl_kernel", "avg_launch_ms": s["kernel_avg_launch_ms"], "launches": s["launches"],
+                     "launch_note": "one 'launch' = one rollout of all rows over the horizon, bracketed by hipEvents inside libcadm_hip.so "
+                                    "(a single kernel at cfg2; at >= 2 row tiles per workgroup slot the launcher issues a tile-pair kernel "
+                                    "plus a single-tile kernel for the remainder)",
                      "flops_per_row_step": s["flops_per_row_step"], "row_steps_per_launch": s["row_steps_per_launch"]},
     }
     prob_head, n_head, p_head = head.prob, head.n, head.p

@@ -4,21 +4,24 @@
 // ensemble MLP, Gaussian head, state update and reward accumulation (reference core/utils.py:431-472).
 //
 // Why not v_mfma_f32_16x16x4_f32: on gfx950 the fp32-input MFMA runs at the fp32 VECTOR rate (1/16 of the f16 rate) and
-// a wave cannot issue any VALU work in its shadow (tools/issue_bench: +12 cycles per MFMA<->VALU switch, +4 per VALU op),
-// while v_mfma_f32_16x16x32_f16 hides ~5 single-issue instructions per 32 cycles.  Every fp32 operand is split in two
-// f16 numbers (xdl_geo.h): 3 f16 MFMAs per 16x16x32 block with fp32 accumulation reproduce the fp32 product to 2^-22.
+// a wave cannot issue any VALU work in its shadow (tools/issue_bench: +15 cycles for the first VALU op after an MFMA, +4 for
+// each further one).  Every fp32 operand is split in two f16 numbers (xdl_geo.h): 3 v_mfma_f32_16x16x32_f16 per 16x16x32
+// block with fp32 accumulation reproduce the fp32 product to 2^-22 in 3/16 of the matrix-pipe time.
 //
 // Mapping:
-//   * workgroup = 8 waves (two per SIMD, 256 registers each) = 16 rows of ONE ensemble member; a workgroup walks over
-//     row tiles grp, grp + wgs_per_member, ..  of its member (one tile at BASELINE cfg2).  Two waves per SIMD: while one
-//     waits (LDS operand loads, the weight stream, an epilogue's exp/rcp chain) the other one's MFMAs run;
-//   * a layer is evaluated transposed, OUT^T = W^T IN^T: weights are the A operand (streamed from L2 in consumption
-//     order through a register ring), the 16 rows are the B / D columns.  A lane's D fragments of tiles (2c, 2c+1) are
-//     its B fragment of chunk c of the next layer: activations cross layers through LDS with lane-linear accesses;
-//   * wave w owns BASE + (w < EXTRA) hidden tiles and computes them one after the other over the whole K (the B operand is
-//     read chunk by chunk from LDS, three chunks ahead); a tile pair's epilogue (swish, f16 split, LDS store) runs in
-//     the shadow of the next pair's MFMAs or, for the last pair, of the SIMD's other wave;
-//   * the rollout state lives in registers of the 256 "feature threads" (waves 0-3) exactly as in the fp32 kernel.
+//   * workgroup = 8 waves (two per SIMD, 256 registers each) = MT x 16 rows of ONE ensemble member (MT = 1, or 2 for
+//     large batches); a workgroup walks over groups of MT row tiles grp, grp + wgs_per_member, ..  of its member (one
+//     tile at BASELINE cfg2).  Two waves per SIMD: while one waits (LDS operand loads, the weight stream, an epilogue's
+//     exp/rcp chain) the other one's MFMAs run;
+//   * a layer is evaluated transposed, OUT^T = W^T IN^T: weights are the A operand (a third register-resident, the rest
+//     streamed from L2 in consumption order through a register ring), the 16 rows of a tile are the B / D columns.  A
+//     lane's D fragments of tiles (2c, 2c+1) are its B fragment of chunk c of the next layer: activations cross layers
+//     through LDS with lane-linear accesses;
+//   * wave w owns BASE + (w < EXTRA) hidden tiles and computes them CADM_XDL_GROUP at a time over the whole K (the B
+//     operand is read chunk by chunk from LDS, ahead of its use); the last group's epilogue (swish, f16 split, LDS store)
+//     overlaps with the SIMD's other wave, earlier groups' with the next group's MFMAs;
+//   * MT = 1: the rollout state lives in registers of the 256 "feature threads" (waves 0-3), their twins in waves 4-7
+//     produce the Gaussian-head noise; MT = 2: all 512 threads hold state (waves 4-7: the second row tile).
 #include "rollout_args.h"
 #include "rollout_env.h"
 #include "xdl_geo.h"
