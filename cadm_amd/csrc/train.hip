@@ -536,13 +536,15 @@ struct DwArgs {
 #define DW_NSLAB 1                   // slabs per K panel in flight (registers): one keeps the kernel at 120 VGPRs = 4 workgroups per CU
 
 // One 48 x 64 tile of one job per workgroup, reduction over the batch: the whole step's ~925 tiles then fit the chip's
-// 1024 workgroup slots (4 per CU) in ONE round (32 x 64 tiles needed 1330 = two rounds).  The global loads of a K
-// panel are issued up front (registers) and the panel is then walked slab by slab -- stash slab s into its own LDS
-// region as its loads land, barrier, 32-deep MFMA sweep.  4 waves side by side, each 48 x 16.  Occupancy beats panel
-// depth here: 2-slab panels (156 VGPRs, 3 per CU) and register double-buffering (178 VGPRs) both measured slower.
+// 1024 workgroup slots (4 per CU) in ONE round (32 x 64 tiles needed 1330 = two rounds).  K is walked in 32-deep slabs:
+// stash the slab's loads into LDS as they land, barrier, MFMA sweep; 4 waves side by side, each 48 x 16.  Occupancy beats
+// panel depth here: 2-slab panels (156 VGPRs, 3 per CU) and register double-buffering (178 VGPRs) both measured slower.
 __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
-    __shared__ __attribute__((aligned(16))) float As[DW_NSLAB * TK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[DW_NSLAB * TK * LDB];
+    __shared__ __attribute__((aligned(16))) float dw_smem[DW_NSLAB * TK * (LDA + LDB)];
+    float* const As = dw_smem;
+    float* const Bs = dw_smem + DW_NSLAB * TK * LDA;
+    constexpr int LDC = TN + 4;                          // the finished tile, staged for the vectorised Adam epilogue
+    static_assert(TM * LDC <= DW_NSLAB * TK * (LDA + LDB), "the C tile must fit the slab buffers");
     const int tile = blockIdx.x, e = blockIdx.y;
     int ji = 0;
 #pragma unroll 1
@@ -586,61 +588,89 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     const int kmax = K - 1;
     const bool do_colsum = jb.bW && mb == 0 && tid < TN;
 
-    for (int kp = 0; kp < (jb.X ? K : 0); kp += DW_NSLAB * TK) {     // X == null: L2-only job, gradient = wdc * W
-        if (kp > 0) __syncthreads();               // previous panel fully consumed before its LDS is overwritten
+    // The loads of slab s+1 are issued right after slab s has been stashed into LDS -- into the SAME registers, which are
+    // dead by then -- so their latency runs under slab s's MFMAs at no register cost.
+    static_assert(DW_NSLAB == 1, "the slab pipeline below keeps one slab of loads in flight");
+    const int KP = jb.X ? K : 0;                                       // X == null: L2-only job, gradient = wdc * W
+    auto issue = [&](int k0) {
 #pragma unroll
-        for (int s = 0; s < DW_NSLAB; ++s) {
-            const int k0 = kp + s * TK;
-#pragma unroll
-            for (int it = 0; it < NLA; ++it) {
-                const int k = k0 + ka[it];
-                ra[s][it] = pa[it][(long)(k < kmax ? k : kmax) * jb.ldx];
-            }
-#pragma unroll
-            for (int it = 0; it < NLB; ++it) {
-                const int k = k0 + kb[it];
-                rb[s][it] = pb[it][(long)(k < kmax ? k : kmax) * N];
-            }
+        for (int it = 0; it < NLA; ++it) {
+            const int k = k0 + ka[it];
+            ra[0][it] = pa[it][(long)(k < kmax ? k : kmax) * jb.ldx];
         }
 #pragma unroll
-        for (int s = 0; s < DW_NSLAB; ++s) {
-            const int k0 = kp + s * TK;
-            if (k0 >= K) break;
-            float* as = As + s * TK * LDA;
-            float* bs = Bs + s * TK * LDB;
+        for (int it = 0; it < NLB; ++it) {
+            const int k = k0 + kb[it];
+            rb[0][it] = pb[it][(long)(k < kmax ? k : kmax) * N];
+        }
+    };
+    if (KP > 0) issue(0);
+    for (int k0 = 0; k0 < KP; k0 += TK) {
+        if (k0 > 0) __syncthreads();               // previous slab fully consumed before its LDS is overwritten
 #pragma unroll
-            for (int it = 0; it < NLA; ++it) as[la[it]] = (va[it] && k0 + ka[it] <= kmax) ? ra[s][it] : 0.0f;
+        for (int it = 0; it < NLA; ++it) As[la[it]] = (va[it] && k0 + ka[it] <= kmax) ? ra[0][it] : 0.0f;
 #pragma unroll
-            for (int it = 0; it < NLB; ++it) bs[lb[it]] = (vb[it] && k0 + kb[it] <= kmax) ? rb[s][it] : 0.0f;
-            __syncthreads();
-            if (do_colsum) {
+        for (int it = 0; it < NLB; ++it) Bs[lb[it]] = (vb[it] && k0 + kb[it] <= kmax) ? rb[0][it] : 0.0f;
+        __syncthreads();
+        if (k0 + TK < KP) issue(k0 + TK);
+        if (do_colsum) {
 #pragma unroll
-                for (int kk = 0; kk < TK; ++kk) colsum += bs[kk * LDB + tid];
-            }
+            for (int kk = 0; kk < TK; ++kk) colsum += Bs[kk * LDB + tid];
+        }
 #pragma unroll
-            for (int ks = 0; ks < TK / 4; ++ks) {
-                const int kr = ks * 4 + (lane >> 4);
-                const float b = bs[kr * LDB + wn * 16 + (lane & 15)];
+        for (int ks = 0; ks < TK / 4; ++ks) {
+            const int kr = ks * 4 + (lane >> 4);
+            const float b = Bs[kr * LDB + wn * 16 + (lane & 15)];
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(as[kr * LDA + i * 16 + (lane & 15)], b, acc[i], 0, 0, 0);
-            }
+            for (int i = 0; i < MI; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[kr * LDA + i * 16 + (lane & 15)], b, acc[i], 0, 0, 0);
         }
     }
 
-    // ---- epilogue: D layout col = lane & 15 -> n, row = (lane >> 4) * 4 + r -> m ----
+    // ---- epilogue: D layout col = lane & 15 -> n, row = (lane >> 4) * 4 + r -> m.  Adam touches W, m and v once each
+    // (read + write): that traffic, not the GEMM, is most of this kernel, so the tile goes through LDS and every thread
+    // updates 4 consecutive columns with 16-byte accesses (a D-layout thread would touch 12 scattered dwords x 6) ----
+    if ((N & 3) == 0) {
+        __syncthreads();                                 // every wave is done reading the slab buffers
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = mb + i * 16 + (lane >> 4) * 4 + r;
-            const int n = nb + wn * 16 + (lane & 15);
+            for (int r = 0; r < 4; ++r) dw_smem[(i * 16 + (lane >> 4) * 4 + r) * LDC + wn * 16 + (lane & 15)] = acc[i][r];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < TM * TN / 4 / 256; ++it) {
+            const int idx = tid + it * 256;
+            const int ml = idx / (TN / 4), n4 = (idx % (TN / 4)) * 4;
+            const int m = mb + ml, n = nb + n4;
             if (m >= M || n >= N) continue;
             const long o = ((long)e * M + m) * N + n;
-            float w = jb.W[o], mo = jb.Mw[o], vo = jb.Vw[o];
-            adam_update(w, mo, vo, acc[i][r] + jb.wdc * w, a.lr_t, a.b1, a.b2, a.eps);
-            jb.W[o] = w; jb.Mw[o] = mo; jb.Vw[o] = vo;
+            const floatx4 g = *reinterpret_cast<const floatx4*>(dw_smem + ml * LDC + n4);
+            floatx4 w = *reinterpret_cast<const floatx4*>(jb.W + o), mo = *reinterpret_cast<const floatx4*>(jb.Mw + o),
+                    vo = *reinterpret_cast<const floatx4*>(jb.Vw + o);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float wc = w[c], mc = mo[c], vc = vo[c];
+                adam_update(wc, mc, vc, g[c] + jb.wdc * wc, a.lr_t, a.b1, a.b2, a.eps);
+                w[c] = wc; mo[c] = mc; vo[c] = vc;
+            }
+            *reinterpret_cast<floatx4*>(jb.W + o) = w;
+            *reinterpret_cast<floatx4*>(jb.Mw + o) = mo;
+            *reinterpret_cast<floatx4*>(jb.Vw + o) = vo;
         }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb + i * 16 + (lane >> 4) * 4 + r;
+                const int n = nb + wn * 16 + (lane & 15);
+                if (m >= M || n >= N) continue;
+                const long o = ((long)e * M + m) * N + n;
+                float w = jb.W[o], mo = jb.Mw[o], vo = jb.Vw[o];
+                adam_update(w, mo, vo, acc[i][r] + jb.wdc * w, a.lr_t, a.b1, a.b2, a.eps);
+                jb.W[o] = w; jb.Mw[o] = mo; jb.Vw[o] = vo;
+            }
+    }
     if (do_colsum && nb + tid < N) {
         const long o = (long)e * N + nb + tid;
         float w = jb.bW[o], mo = jb.bM[o], vo = jb.bV[o];

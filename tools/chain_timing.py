@@ -17,7 +17,8 @@ from cadm_amd.synth import make_engine
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-    prob = synth.make_problem(env="halfcheetah", context=True, E=5, with_back=True, seed=0)
+    hid = int(os.environ.get("CHAIN_HID", "200"))
+    prob = synth.make_problem(env="halfcheetah", context=True, E=5, with_back=True, seed=0, hidden_sizes=(hid,) * 4)
     eng = make_engine(prob, p=20)
     batch = {k: eng._t(v) for k, v in synth.make_train_batch(prob, B=B, seed=1).items()}
     tbuf = torch.zeros(4096, dtype=torch.int64, device=eng.device)
