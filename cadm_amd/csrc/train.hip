@@ -524,7 +524,7 @@ struct DwJob {                       // W[e] (M x N) <- Adam(W, X[e]^T dZ[e] + w
 #define DW_MAXJOBS 20
 struct DwArgs {
     DwJob job[DW_MAXJOBS];
-    int njobs, B;
+    int njobs, B, tiles, E;          // tiles: work items per member
     float lr_t, b1, b2, eps;
 };
 
@@ -545,7 +545,13 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     float* const Bs = dw_smem + DW_NSLAB * TK * LDA;
     constexpr int LDC = TN + 4;                          // the finished tile, staged for the vectorised Adam epilogue
     static_assert(TM * LDC <= DW_NSLAB * TK * (LDA + LDB), "the C tile must fit the slab buffers");
-    const int tile = blockIdx.x, e = blockIdx.y;
+    // Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8), each with its own L2.  Consecutive work items
+    // (member-major, then job, then tile) re-read the same X / dZ panels, so XCD x gets the x-th CONTIGUOUS eighth of them:
+    // a panel is then fetched into one L2 instead of up to eight (the kernel is fabric-bound: W, m, v alone are 44 MB).
+    const int per_xcd = (a.tiles * a.E + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= a.tiles * a.E) return;
+    const int e = item / a.tiles, tile = item - e * a.tiles;
     int ji = 0;
 #pragma unroll 1
     while (ji + 1 < a.njobs && tile >= a.job[ji + 1].tile0) ++ji;
@@ -1313,7 +1319,8 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     };
     if (det && (rc = l2_only_job(ctx->ff[NH + 1], wd_dyn(NH + 1), t->a_ff[2 * (NH + 1)]))) return rc;
     if (has_back && (rc = l2_only_job(ctx->back[NH + 1], wd_dyn(NH + 1), t->a_bk[2 * (NH + 1)]))) return rc;
-    hipLaunchKernelGGL(dw_adam_kernel, dim3(tiles, E), dim3(256), 0, s, da);
+    da.tiles = tiles; da.E = E;
+    hipLaunchKernelGGL(dw_adam_kernel, dim3(8 * ((tiles * E + 7) / 8)), dim3(256), 0, s, da);
     CADM_CHECK_HIP(hipGetLastError());
     ctx->packed = false;   // planner streams are stale until cadm_repack
     return CADM_OK;
