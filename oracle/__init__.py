@@ -14,7 +14,9 @@ cites the reference call site (file:line under /root/reference) it follows.
 What IS pinned to reference code executed in the build container: the planner
 graph's data movement, member assignment, CEM update, variable creation order
 and draw order (tests/golden/make_graph_golden.py runs cadm/dynamics/core/utils.py
-unchanged on a numpy-eager tensorflow stand-in -> graph_golden.npz) and the
+unchanged on a numpy-eager tensorflow stand-in -> graph_golden.npz), the training
+loss composition and the model's variable list (tests/golden/make_loss_golden.py
+runs the reference model's constructor on the same stand-in -> loss_golden.npz) and the
 future-window builder (tests/golden/make_f2_golden.py runs the reference's own
 process_samples -> f2_windows.npz).
 

@@ -79,3 +79,48 @@ def make_inputs(case):
                 cp_act=f32(rng.uniform(-1, 1, (m, A * Hh))), init_mean=f32(np.zeros((m, H, A))), init_var=f32(np.full((m, H, A), 0.25)),
                 bs_obs=f32(rng.standard_normal((E, B, D))), bs_act=f32(rng.uniform(-1, 1, (E, B, A))),
                 bs_cp_obs=f32(0.1 * rng.standard_normal((E, B, D * Hh))), bs_cp_act=f32(rng.uniform(-1, 1, (E, B, A * Hh))))
+
+
+# ---- the training-loss golden (tests/golden/make_loss_golden.py): the reference model's constructor on a bootstrap batch ----
+LOSS_CASES = {
+    "hc_cadm_prob": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=5, m=1, n=52, H=2, hidden=(128,) * 4, cp_hidden=(24, 16, 8), C=10,
+                         Hh=3, F=2, B=6, seed=303, deterministic=False, back_coeff=0.5, weight_decay_coeff=1.0,
+                         weight_decays=(0.000025, 0.00005, 0.000075, 0.000075, 0.0001),
+                         context_weight_decays=(0.000025, 0.00005, 0.000075, 0.000075)),
+    "hc_cadm_det": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=5, m=1, n=52, H=2, hidden=(128,) * 4, cp_hidden=(16, 8), C=10,
+                        Hh=2, F=2, B=5, seed=404, deterministic=True, back_coeff=0.5, weight_decay_coeff=0.5,
+                        weight_decays=(0.000025, 0.00005, 0.000075, 0.000075, 0.0001),
+                        context_weight_decays=(0.000025, 0.00005, 0.000075)),
+}
+
+
+def make_loss_inputs(case):
+    c = LOSS_CASES[case]
+    rng = np.random.default_rng(c["seed"] + 1)
+    D, A, P, Hh, m, H, E, B = c["D"], c["A"], c["P"], c["Hh"], c["m"], c["H"], c["E"], c["B"]
+    f32 = lambda x: np.asarray(x, np.float32)
+    ms = lambda k: (f32(rng.standard_normal(k)), f32(rng.uniform(0.5, 2.0, k)))
+    st = {}
+    st["obs_mean"], st["obs_std"] = ms(P)
+    st["act_mean"], st["act_std"] = ms(A)
+    st["delta_mean"], st["delta_std"] = ms(D)
+    st["cp_obs_mean"], st["cp_obs_std"] = f32(np.zeros(D * Hh)), f32(np.ones(D * Hh))
+    st["cp_act_mean"], st["cp_act_std"] = ms(A * Hh)
+    st["back_delta_mean"], st["back_delta_std"] = ms(D)
+    return dict(stats=st, obs=f32(rng.standard_normal((m, D))), obs_next=f32(rng.standard_normal((m, D))),
+                act=f32(rng.uniform(-1, 1, (m, A))), cp_obs=f32(0.1 * rng.standard_normal((m, D * Hh))),
+                cp_act=f32(rng.uniform(-1, 1, (m, A * Hh))), init_mean=f32(np.zeros((m, H, A))), init_var=f32(np.full((m, H, A), 0.25)),
+                bs_obs=f32(rng.standard_normal((E, B, D))), bs_obs_next=f32(rng.standard_normal((E, B, D))),
+                bs_act=f32(rng.uniform(-1, 1, (E, B, A))), bs_delta=f32(rng.standard_normal((E, B, D))),
+                bs_back_delta=f32(rng.standard_normal((E, B, D))), bs_cp_obs=f32(0.1 * rng.standard_normal((E, B, D * Hh))),
+                bs_cp_act=f32(rng.uniform(-1, 1, (E, B, A * Hh))))
+
+
+def placeholder_feed(inp):
+    """The constructor's placeholders in creation order (mlp_cadm_ensemble_cem_dynamics.py:108-137)."""
+    st = inp["stats"]
+    return [inp["obs"], inp["obs_next"], inp["act"], inp["cp_obs"], inp["cp_act"],
+            inp["bs_obs"], inp["bs_obs_next"], inp["bs_act"], inp["bs_delta"], inp["bs_back_delta"], inp["bs_cp_obs"], inp["bs_cp_act"],
+            st["obs_mean"], st["obs_std"], st["act_mean"], st["act_std"], st["delta_mean"], st["delta_std"],
+            st["cp_obs_mean"], st["cp_obs_std"], st["cp_act_mean"], st["cp_act_std"], st["back_delta_mean"], st["back_delta_std"],
+            inp["init_mean"], inp["init_var"]]

@@ -87,16 +87,28 @@ def build_tf(weights, draws):
     # variables: the creation order IS tf.trainable_variables() order (what save / load rely on)
     scope = []
 
+    created = {}           # full name -> array: a second request for the same name returns the SAME variable (AUTO_REUSE)
+
     class _Scope:
-        def __init__(self, name): self.name = name
+        def __init__(self, name, reuse=None, **kw): self.name = name
         def __enter__(self): scope.append(self.name)
         def __exit__(self, *a): scope.pop()
 
     def get_variable(name, shape=None, initializer=None, **kw):
-        return weights.dense("/".join(scope + [name]), tuple(int(s) for s in shape))
+        full = "/".join(scope + [name])
+        if full not in created:
+            created[full] = weights.dense(full, tuple(int(s) for s in shape))
+        return created[full]
 
-    def Variable(value, dtype=None, name=None, **kw):
-        return weights.plain("/".join(scope + [name]), value)
+    def Variable(value, dtype=None, name=None, **kw):      # tf.Variable never reuses: a second call gets a uniquified name
+        full, k = "/".join(scope + [name]), 0
+        while full in created:
+            k += 1
+            full = "/".join(scope + ["%s_%d" % (name, k)])
+        created[full] = weights.plain(full, value)
+        return created[full]
+
+    tf._scope, tf._created = scope, created
 
     tf.Variable = Variable
     tf.compat = types.SimpleNamespace(v1=types.SimpleNamespace(get_variable=get_variable, variable_scope=_Scope))

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Golden values for the TRAINING LOSS COMPOSITION and the model's VARIABLE LIST, produced by the reference's own
+constructor.
+
+`MLPEnsembleCEMDynamicsModel.__init__` (/root/reference/cadm/dynamics/mlp_cadm_ensemble_cem_dynamics.py:26-342) is
+imported unchanged and run on the numpy-eager `tensorflow` stand-in of make_graph_golden.py (extended here with
+placeholders fed in creation order, variable reuse, a do-nothing optimizer).  Because the stand-in is eager, the
+constructor COMPUTES what it would normally only wire up: the context / forward / backward networks on a bootstrap batch
+and, with the reference's own lines :269-313, mse_loss, back_mse_loss, the three l2 terms, mu_loss, var_loss, reg_loss,
+recon_loss and loss.  It also shows which variables the constructor creates, in tf.trainable_variables() order -- among
+them TWO pairs of max/min_logvar for the forward model: the layer is built twice (policy graph, training graph) under
+AUTO_REUSE, which shares get_variable weights but not tf.Variable ones.
+
+What this is not: TensorFlow (see make_graph_golden.py).  Run in the build container only:
+    python tests/golden/make_loss_golden.py        -> tests/golden/loss_golden.npz
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import graph_inputs as gi  # noqa: E402
+import make_graph_golden as mg  # noqa: E402
+
+REF = "/root/reference"
+
+
+def run_case(case):
+    c = gi.LOSS_CASES[case]
+    inp = gi.make_loss_inputs(case)
+    weights, draws = gi.Weights(c["seed"]), gi.Draws(c["seed"])
+    for k in [k for k in sys.modules if k == "tensorflow" or k.startswith("cadm")]:
+        del sys.modules[k]
+    sys.modules["tensorflow"] = tf = mg.build_tf(weights, draws)
+    tf.nn.tanh, tf.nn.softmax = np.tanh, (lambda x: x)            # default arguments of the layer classes, unused on this path
+    if not any(isinstance(f, mg._PlaceholderFinder) for f in sys.meta_path):
+        sys.meta_path.append(mg._PlaceholderFinder())
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    # ---- what the constructor needs beyond the graph builder ----
+    feed = list(gi.placeholder_feed(inp))            # arrays in the order the constructor creates its placeholders
+
+    def placeholder(dtype, shape=None, name=None):
+        arr = feed.pop(0)
+        assert len(shape) == arr.ndim and all(s is None or int(s) == d for s, d in zip(shape, arr.shape)), (shape, arr.shape)
+        return arr
+
+    v1 = tf.compat.v1
+    v1.placeholder = placeholder
+    v1.AUTO_REUSE = object()
+    v1.GraphKeys = types.SimpleNamespace(TRAINABLE_VARIABLES="trainable_variables")
+    v1.get_default_graph = lambda: types.SimpleNamespace(get_name_scope=lambda: "/".join(tf._scope))
+    v1.get_collection = lambda key, scope=None: []
+    v1.trainable_variables = lambda: [v for _, v in weights.vars]
+    v1.get_default_session = lambda: None
+
+    class _Opt:
+        def __init__(self, lr): self.lr = lr
+        def minimize(self, loss): return None
+
+    v1.train = types.SimpleNamespace(AdamOptimizer=_Opt)
+    tf.constant = lambda v, **k: np.float32(v)
+    M = importlib.import_module("cadm.dynamics.mlp_cadm_ensemble_cem_dynamics")        # the reference model, unchanged
+    Env = importlib.import_module("cadm.envs.half_cheetah_env").HalfCheetahEnv
+    env = types.SimpleNamespace(observation_space=types.SimpleNamespace(shape=(c["D"],)), proc_observation_space_dims=c["P"],
+                                action_space=types.SimpleNamespace(shape=(c["A"],)),
+                                obs_preproc=lambda o: Env.obs_preproc(None, o), obs_postproc=lambda o, d: Env.obs_postproc(None, o, d),
+                                tf_reward_fn=lambda: Env.tf_reward_fn(None))
+    model = M.MLPEnsembleCEMDynamicsModel(
+        "dyn_model", env, hidden_sizes=c["hidden"], hidden_nonlinearity="swish", n_forwards=c["H"], n_candidates=c["n"],
+        ensemble_size=c["E"], n_particles=c["p"], use_cem=True, deterministic=c["deterministic"], weight_decays=c["weight_decays"],
+        weight_decay_coeff=c["weight_decay_coeff"], cp_hidden_sizes=c["cp_hidden"], context_weight_decays=c["context_weight_decays"],
+        context_out_dim=c["C"], context_hidden_nonlinearity="relu", history_length=c["Hh"], future_length=c["F"], state_diff=True,
+        back_coeff=c["back_coeff"])
+    assert not feed, "placeholders left unfed: %d" % len(feed)
+    res = {case + "/var_names": np.array([n for n, _ in weights.vars]),
+           case + "/var_shapes": np.array([",".join(map(str, v.shape)) for _, v in weights.vars])}
+    for k in ("mse_loss", "back_mse_loss", "l2_reg_loss", "context_l2_reg_loss", "back_l2_reg_loss", "l2_loss", "mu_loss", "var_loss",
+              "reg_loss", "recon_loss", "loss"):
+        if hasattr(model, k):
+            res[case + "/" + k] = np.asarray(getattr(model, k), np.float32)
+    res[case + "/delta_pred"] = np.asarray(model.delta_pred, np.float32)
+    return res
+
+
+def main():
+    out = {}
+    for case in gi.LOSS_CASES:
+        out.update(run_case(case))
+    np.savez_compressed(os.path.join(HERE, "loss_golden.npz"), **out)
+    for k, v in out.items():
+        if v.ndim == 0:
+            print(k, float(v))
+    first = next(iter(gi.LOSS_CASES))
+    print("variables:", list(out[first + "/var_names"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,80 @@
+"""The TRAINING LOSS COMPOSITION and the model's VARIABLE LIST pinned to the reference's own constructor:
+tests/golden/loss_golden.npz was written by /root/reference/cadm/dynamics/mlp_cadm_ensemble_cem_dynamics.py's
+`MLPEnsembleCEMDynamicsModel.__init__`, imported unchanged and executed on the numpy-eager `tensorflow` stand-in
+(tests/golden/make_loss_golden.py says what that does and does not prove).  Inputs are regenerated from
+tests/golden/graph_inputs.py; the oracle's `train_losses` and the HIP training step (forward only) must reproduce the
+reference's mse_loss / back_mse_loss / recon_loss / loss."""
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import graph_inputs as gi  # noqa: E402
+
+GOLD = np.load(os.path.join(HERE, "golden", "loss_golden.npz"))
+NETS = ("context_model", "ff_model", "backward_model")
+
+
+def rebuild(case):
+    """(config, nets, inputs) with the weights exactly as the generator handed them to the reference constructor."""
+    c = gi.LOSS_CASES[case]
+    W = gi.Weights(c["seed"])
+    nets = {k: OrderedDict() for k in NETS}
+    for name, shp in zip(GOLD[case + "/var_names"], GOLD[case + "/var_shapes"]):
+        _, net, _, pname = str(name).split("/")                 # <model>/<net>/<layer scope>/<variable>
+        shape = tuple(int(s) for s in str(shp).split(","))
+        if pname.endswith(("_weight", "_bias")):
+            nets[net][pname] = W.dense(str(name), shape)
+        else:
+            nets[net][pname] = W.plain(str(name), np.ones(shape) / 2.0 if pname == "max_logvar" else -np.ones(shape) * 10)
+    return c, nets, gi.make_loss_inputs(case)
+
+
+def test_constructor_variable_order_is_the_checkpoint_order():
+    """`save` writes tf.trainable_variables() (dynamics.py:266,571-577): context_model, ff_model, backward_model, each dynamics
+    net as hidden_i_{weight,bias}, output_mu_*, output_logvar_*, max_logvar, min_logvar -- ONE logvar pair per net, also for
+    the deterministic backward model."""
+    from cadm_amd.engine import ctx_param_names, dyn_param_names
+    names = ["/".join((str(x).split("/")[1], str(x).split("/")[3])) for x in GOLD["hc_cadm_prob/var_names"]]
+    want = (["context_model/" + x for x in ctx_param_names(3)] + ["ff_model/" + x for x in dyn_param_names(4)]
+            + ["backward_model/" + x for x in dyn_param_names(4)])
+    assert names == want
+
+
+@pytest.mark.parametrize("case", sorted(gi.LOSS_CASES))
+def test_oracle_losses_match_the_reference_constructor(case):
+    import torch
+    from oracle import train as otrain
+    c, nets, inp = rebuild(case)
+    t = lambda d: otrain.to_torch(d, torch.float32)
+    batch = {k: torch.tensor(inp["bs_" + k]) for k in ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")}
+    cfg = dict(deterministic=c["deterministic"], back_coeff=c["back_coeff"], weight_decay_coeff=c["weight_decay_coeff"],
+               weight_decays=c["weight_decays"], context_weight_decays=c["context_weight_decays"], n_hidden=len(c["hidden"]),
+               n_cp_hidden=len(c["cp_hidden"]))
+    out = otrain.train_losses(c["env"], t(nets["ff_model"]), t(nets["backward_model"]), t(nets["context_model"]), t(inp["stats"]),
+                              batch, cfg)
+    for ok, gk in (("mse", "mse_loss"), ("back_mse", "back_mse_loss"), ("recon", "recon_loss"), ("loss", "loss")):
+        np.testing.assert_allclose(float(out[ok]), float(GOLD[case + "/" + gk]), rtol=2e-5, err_msg=gk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(gi.LOSS_CASES))
+def test_hip_training_forward_matches_the_reference_constructor(gpu, case):
+    from cadm_amd import synth
+    c, nets, inp = rebuild(case)
+    prob = synth.make_problem(env=c["env"], context=True, E=c["E"], m=1, hidden_sizes=c["hidden"], cp_hidden_sizes=c["cp_hidden"],
+                              C=c["C"], Hh=c["Hh"], H=c["H"], with_back=True, seed=0)
+    prob["cp"], prob["ff"], prob["back"] = nets["context_model"], nets["ff_model"], nets["backward_model"]
+    prob["stats"] = {k: np.asarray(v, np.float64) for k, v in inp["stats"].items()}
+    eng = synth.make_engine(prob, p=c["p"], deterministic=c["deterministic"])
+    eng.train_configure(1e-3, c["weight_decays"], c["context_weight_decays"], c["weight_decay_coeff"], c["back_coeff"],
+                        max_batch=c["B"])
+    batch = {k: eng._t(inp["bs_" + k]) for k in ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")}
+    got = eng.train_step(batch, train=False).cpu().numpy()                     # [mse, back_mse, recon]
+    want = [float(GOLD[case + "/" + k]) for k in ("mse_loss", "back_mse_loss", "recon_loss")]
+    np.testing.assert_allclose(got, want, rtol=5e-5)
+    eng.close()
