@@ -124,3 +124,15 @@ def placeholder_feed(inp):
             st["obs_mean"], st["obs_std"], st["act_mean"], st["act_std"], st["delta_mean"], st["delta_std"],
             st["cp_obs_mean"], st["cp_obs_std"], st["cp_act_mean"], st["cp_act_std"], st["back_delta_mean"], st["back_delta_std"],
             inp["init_mean"], inp["init_var"]]
+
+
+def make_fit_inputs(case, N=7):
+    """Windowed samples as `fit` receives them (dynamics.py:382-390): [N, F, .] future windows, [N, Hh * .] histories, mask."""
+    c = LOSS_CASES[case]
+    rng = np.random.default_rng(c["seed"] + 2)
+    D, A, Hh, F = c["D"], c["A"], c["Hh"], c["F"]
+    fb = (rng.uniform(size=(N, F)) > 0.3).astype(np.float64)
+    fb[:, 0] = 1.0
+    return dict(obs=rng.standard_normal((N, F, D)), act=rng.uniform(-1, 1, (N, F, A)), delta=rng.standard_normal((N, F, D)),
+                cp_obs=0.1 * rng.standard_normal((N, D * Hh)), cp_act=rng.uniform(-1, 1, (N, A * Hh)), future_bool=fb,
+                obs_next=rng.standard_normal((N, F, D)), back_delta=rng.standard_normal((N, F, D)))

@@ -7,9 +7,9 @@ imported unchanged and run on the numpy-eager `tensorflow` stand-in of make_grap
 placeholders fed in creation order, variable reuse, a do-nothing optimizer).  Because the stand-in is eager, the
 constructor COMPUTES what it would normally only wire up: the context / forward / backward networks on a bootstrap batch
 and, with the reference's own lines :269-313, mse_loss, back_mse_loss, the three l2 terms, mu_loss, var_loss, reg_loss,
-recon_loss and loss.  It also shows which variables the constructor creates, in tf.trainable_variables() order -- among
-them TWO pairs of max/min_logvar for the forward model: the layer is built twice (policy graph, training graph) under
-AUTO_REUSE, which shares get_variable weights but not tf.Variable ones.
+recon_loss and loss.  It also shows which variables the constructor creates, in tf.trainable_variables() order, and the
+constructed object's own `_preprocess_inputs`, `compute_normalization` and `get_normalization_stats` (pure numpy) are run
+on windowed samples as `fit` would.
 
 What this is not: TensorFlow (see make_graph_golden.py).  Run in the build container only:
     python tests/golden/make_loss_golden.py        -> tests/golden/loss_golden.npz
@@ -84,6 +84,17 @@ def run_case(case):
         if hasattr(model, k):
             res[case + "/" + k] = np.asarray(getattr(model, k), np.float32)
     res[case + "/delta_pred"] = np.asarray(model.delta_pred, np.float32)
+    # fit()'s host-side data path, the reference's own methods on that model object (pure numpy, dynamics.py:590-696)
+    d = gi.make_fit_inputs(case)
+    rows = model._preprocess_inputs(d["obs"], d["act"], d["delta"], d["cp_obs"], d["cp_act"], d["future_bool"], d["obs_next"],
+                                    d["back_delta"])
+    for k, v in zip(("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act"), rows):
+        res[case + "/rows_" + k] = np.asarray(v, np.float64)
+    _obs, _act, _delta, _obs_next, _back_delta, _cp_obs, _cp_act = rows
+    model.compute_normalization(_obs, _act, _delta, _cp_obs, _cp_act, _back_delta)
+    for k, v in zip(("obs_mean", "obs_std", "act_mean", "act_std", "delta_mean", "delta_std", "cp_obs_mean", "cp_obs_std",
+                     "cp_act_mean", "cp_act_std", "back_delta_mean", "back_delta_std"), model.get_normalization_stats()):
+        res[case + "/norm_" + k] = np.asarray(v, np.float64)
     return res
 
 

@@ -61,6 +61,26 @@ def test_oracle_losses_match_the_reference_constructor(case):
         np.testing.assert_allclose(float(out[ok]), float(GOLD[case + "/" + gk]), rtol=2e-5, err_msg=gk)
 
 
+@pytest.mark.parametrize("case", sorted(gi.LOSS_CASES))
+def test_fit_rows_and_normalisation_match_the_reference_methods(case):
+    """`_preprocess_inputs`, `compute_normalization`, `get_normalization_stats` (dynamics.py:590-696) as executed by the reference
+    model object itself, against the oracle's restatement (which tests/test_oracle_train.py ties the product class to)."""
+    from oracle import envs as oenvs
+    from oracle import train as otrain
+    c = gi.LOSS_CASES[case]
+    d = gi.make_fit_inputs(case)
+    rows = otrain.preprocess_inputs(d["obs"], d["act"], d["delta"], d["cp_obs"], d["cp_act"], d["future_bool"], d["obs_next"],
+                                    d["back_delta"], c["D"], c["A"], c["Hh"], c["F"])
+    names = ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
+    for k, v in zip(names, rows):
+        np.testing.assert_array_equal(v, GOLD[case + "/rows_" + k], err_msg=k)
+    r = dict(zip(names, rows))
+    norm = otrain.compute_normalization(oenvs.make_env(c["env"]), r["obs"], r["act"], r["delta"], r["cp_obs"], r["cp_act"], r["back_delta"])
+    st = otrain.normalization_stats(norm, c["D"], c["A"], c["Hh"], discrete=False, state_diff=True)
+    for k, v in st.items():
+        np.testing.assert_allclose(v, GOLD[case + "/norm_" + k], rtol=0, atol=1e-12, err_msg=k)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", sorted(gi.LOSS_CASES))
 def test_hip_training_forward_matches_the_reference_constructor(gpu, case):
