@@ -9,6 +9,12 @@ CASES = {   # name: dict(env, E, p, m, n, H, hidden, cp_hidden, C, Hh, seed)
                        C=10, Hh=3, B=2, seed=101),
     "hc_cadm_m3": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=5, m=3, n=52, H=4, hidden=(128,) * 4, cp_hidden=(16, 8),
                        C=10, Hh=2, B=2, seed=202),
+    # random shooting (core/utils.py:490-561): the planner branch taken when no CEM initial distribution is fed
+    # the vanilla PE-TS twin (create_plus_ensemble_cem_mlp, core/utils.py:5-248): no context encoder
+    "hc_vanilla_m2": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=10, m=2, n=54, H=3, hidden=(128,) * 4, cp_hidden=(), C=0, Hh=2,
+                          B=2, seed=606, vanilla=True),
+    "hc_cadm_rs": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=10, m=2, n=40, H=3, hidden=(128,) * 4, cp_hidden=(16, 8),
+                       C=10, Hh=2, B=2, seed=505, rs=True),
 }
 
 
@@ -37,6 +43,11 @@ class Draws:
         z = self.rng.standard_normal(tuple(int(s) for s in shape)).astype(np.float32)
         self.log.append(("normal", z))
         return z
+
+    def uniform(self, shape, lo, hi):
+        u = self.rng.uniform(lo, hi, tuple(int(s) for s in shape)).astype(np.float32)
+        self.log.append(("uniform", u))
+        return u
 
 
 class Weights:

@@ -80,8 +80,9 @@ def build_tf(weights, draws):
     def normal(shape, **kw):
         return draws.normal(shape)
 
-    def uniform(*a, **k):
-        raise RuntimeError("random shooting is not part of this golden")
+    def uniform(shape, minval=0, maxval=None, dtype=np.float32, **kw):
+        assert dtype == np.float32, "discrete random shooting is not part of this golden"
+        return draws.uniform(shape, minval, maxval)
 
     tf.random = types.SimpleNamespace(truncated_normal=truncated_normal, normal=normal, uniform=uniform)
     # variables: the creation order IS tf.trainable_variables() order (what save / load rely on)
@@ -168,6 +169,23 @@ def run_case(case):
     st = inp["stats"]
     D, A, E = c["D"], c["A"], c["E"]
     wd = (0.000025, 0.00005, 0.000075, 0.000075, 0.0001)
+    if c.get("vanilla"):                                                    # mlp_ensemble_cem_dynamics.py:92-130
+        with tf.compat.v1.variable_scope("ff_model"):
+            out = U.create_plus_ensemble_cem_mlp(
+                output_dim=D, hidden_sizes=c["hidden"], hidden_nonlinearity=swish, output_nonlinearity=tf.identity, input_obs_dim=D,
+                input_act_dim=A, input_obs_var=inp["obs"], input_act_var=None, n_forwards=c["H"], ensemble_size=E, weight_decays=wd,
+                reward_fn=reward, n_candidates=c["n"], norm_obs_mean_var=st["obs_mean"], norm_obs_std_var=st["obs_std"],
+                norm_act_mean_var=st["act_mean"], norm_act_std_var=st["act_std"], norm_delta_mean_var=st["delta_mean"],
+                norm_delta_std_var=st["delta_std"], n_particles=c["p"], bs_input_obs_var=inp["bs_obs"], bs_input_act_var=inp["bs_act"],
+                cem_init_mean_var=inp["init_mean"], cem_init_var_var=inp["init_var"], obs_preproc_fn=pre, obs_postproc_fn=post,
+                deterministic=False)
+        (_, _, output_var, optimal_action, mu, logvar, max_lv, min_lv, l2_regs) = out
+        return {case + "/plan": np.asarray(optimal_action, np.float32), case + "/train_mu": np.asarray(mu, np.float32),
+                case + "/train_logvar": np.asarray(logvar, np.float32), case + "/train_output": np.asarray(output_var, np.float32),
+                case + "/var_names": np.array([n for n, _ in weights.vars]),
+                case + "/var_shapes": np.array([",".join(map(str, v.shape)) for _, v in weights.vars]),
+                case + "/draw_kinds": np.array([k for k, _ in draws.log]),
+                case + "/draw_shapes": np.array([",".join(map(str, z.shape)) for _, z in draws.log])}
     with tf.compat.v1.variable_scope("context_model"):                      # dynamics.py:140-156
         bs_cp, _, cp_forward = U.create_ensemble_pure_context_predictor(
             context_hidden_sizes=c["cp_hidden"], context_hidden_nonlinearity=tf.nn.relu, output_nonlinearity=tf.identity,
@@ -184,8 +202,9 @@ def run_case(case):
             norm_act_std_var=st["act_std"], norm_delta_mean_var=st["delta_mean"], norm_delta_std_var=st["delta_std"],
             norm_cp_obs_mean_var=st["cp_obs_mean"], norm_cp_obs_std_var=st["cp_obs_std"], norm_cp_act_mean_var=st["cp_act_mean"],
             norm_cp_act_std_var=st["cp_act_std"], n_particles=c["p"], bs_input_obs_var=inp["bs_obs"], bs_input_act_var=inp["bs_act"],
-            bs_input_cp_var=bs_cp, cp_output_dim=c["C"], history_length=c["Hh"], cem_init_mean_var=inp["init_mean"],
-            cem_init_var_var=inp["init_var"], obs_preproc_fn=pre, obs_postproc_fn=post, deterministic=False,
+            bs_input_cp_var=bs_cp, cp_output_dim=c["C"], history_length=c["Hh"],
+            cem_init_mean_var=None if c.get("rs") else inp["init_mean"], cem_init_var_var=None if c.get("rs") else inp["init_var"],
+            obs_preproc_fn=pre, obs_postproc_fn=post, deterministic=False,
             build_policy_graph=True, cp_forward=cp_forward)
     (_, _, output_var, optimal_action, mu, logvar, max_lv, min_lv, l2_regs, inference_cp, _) = out
     res = {case + "/plan": np.asarray(optimal_action, np.float32), case + "/context": np.asarray(inference_cp, np.float32),

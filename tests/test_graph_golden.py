@@ -30,16 +30,22 @@ def rebuild(case):
         shape = tuple(int(s) for s in str(shp).split(","))
         if pname.endswith(("_weight", "_bias")):
             nets[net][pname] = W.dense(str(name), shape)
-        else:       # tf.Variable(np.ones([1, D]) / 2.) / tf.Variable(-np.ones([1, D]) * 10)  (core/utils.py:338-339)
-            nets[net][pname] = W.plain(str(name), np.ones(shape) / 2.0 if pname == "max_logvar" else -np.ones(shape) * 10)
+        else:       # tf.Variable(np.ones([1, D]) / 2.) / tf.Variable(-np.ones([1, D]) * 10)  (core/utils.py:338-339; :70-71 vanilla)
+            key = {"max_log_var": "max_logvar", "min_log_var": "min_logvar"}.get(pname, pname)      # the vanilla builder's spelling
+            nets[net][key] = W.plain(str(name), np.ones(shape) / 2.0 if key == "max_logvar" else -np.ones(shape) * 10)
     draws = gi.Draws(c["seed"])
     seq = []
     for kind, shp in zip(GOLD[case + "/draw_kinds"], GOLD[case + "/draw_shapes"]):
         shape = tuple(int(s) for s in str(shp).split(","))
-        seq.append((str(kind), draws.truncated(shape) if kind == "truncated_normal" else draws.normal(shape)))
+        seq.append((str(kind), draws.truncated(shape) if kind == "truncated_normal" else draws.uniform(shape, -1, 1) if kind == "uniform"
+                    else draws.normal(shape)))
     E, p, m, n, H, D = c["E"], c["p"], c["m"], c["n"], c["H"], c["D"]
-    assert [k for k, _ in seq] == ["normal"] + (["truncated_normal"] + ["normal"] * H) * 5     # the graph's draw order
     train_eps = seq[0][1]
+    if c.get("rs"):       # random shooting: one uniform action tensor, then the head noise of every step
+        assert [k for k, _ in seq] == ["normal", "uniform"] + ["normal"] * H
+        eps = np.stack([e.reshape(p, m, n, D).transpose(1, 2, 0, 3) for _, e in seq[2:]])        # [H, m, n, p, D]
+        return c, nets, gi.make_inputs(case), seq[1][1], eps, train_eps
+    assert [k for k, _ in seq] == ["normal"] + (["truncated_normal"] + ["normal"] * H) * 5     # the graph's draw order
     z, eps = [], []
     for it in range(5):
         blk = seq[1 + it * (H + 1):1 + (it + 1) * (H + 1)]
@@ -62,21 +68,30 @@ def test_variable_creation_order_is_the_checkpoint_order():
 def test_oracle_reproduces_the_reference_graph(case):
     c, nets, inp, z, eps, train_eps = rebuild(case)
     env, st = oenvs.make_env(c["env"]), inp["stats"]
-    cp, ff = nets["context_model"], nets["ff_model"]
-    ctx = onets.context_forward(cp, inp["cp_obs"], inp["cp_act"], st)
-    np.testing.assert_allclose(ctx, GOLD[case + "/context"], rtol=1e-5, atol=1e-6)
-    # training-graph forward on the [E, B, .] batch (core/utils.py:372-381): heads before the noise
-    bs_cp = onets.context_forward_bs(cp, inp["bs_cp_obs"], inp["bs_cp_act"], st)
-    np.testing.assert_allclose(bs_cp, GOLD[case + "/bs_cp"], rtol=1e-5, atol=1e-6)
-    x = np.concatenate([onets.normalize(env.obs_preproc(inp["bs_obs"]), st["obs_mean"], st["obs_std"]),
-                        onets.normalize(inp["bs_act"], st["act_mean"], st["act_std"]), bs_cp], axis=-1)
+    cp, ff = nets["context_model"] or None, nets["ff_model"]
+    feats = [onets.normalize(env.obs_preproc(inp["bs_obs"]), st["obs_mean"], st["obs_std"]),
+             onets.normalize(inp["bs_act"], st["act_mean"], st["act_std"])]
+    if cp is not None:
+        ctx = onets.context_forward(cp, inp["cp_obs"], inp["cp_act"], st)
+        np.testing.assert_allclose(ctx, GOLD[case + "/context"], rtol=1e-5, atol=1e-6)
+        # training-graph forward on the [E, B, .] batch (core/utils.py:372-381): heads before the noise
+        bs_cp = onets.context_forward_bs(cp, inp["bs_cp_obs"], inp["bs_cp_act"], st)
+        np.testing.assert_allclose(bs_cp, GOLD[case + "/bs_cp"], rtol=1e-5, atol=1e-6)
+        feats.append(bs_cp)
+    x = np.concatenate(feats, axis=-1)
     out, mu, lv = onets.dynamics_forward(ff, x, st["delta_mean"], st["delta_std"], train_eps, False)
     np.testing.assert_allclose(mu, GOLD[case + "/train_mu"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(lv, GOLD[case + "/train_logvar"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(out, GOLD[case + "/train_output"], rtol=1e-5, atol=1e-5)
+    if c.get("rs"):      # the random-shooting planner (core/utils.py:490-561): z = the uniform action tensor [m, n, H, A]
+        for form in ("literal", "indexed"):
+            first, _ = oplanner.rs_plan(env, ff, cp, st, inp["obs"], inp["cp_obs"], inp["cp_act"], z, eps, c["E"], c["p"], formulation=form)
+            np.testing.assert_array_equal(first, GOLD[case + "/plan"], err_msg=form)
+        return
     # the unrolled CEM planner, both formulations of the oracle (literal tile/transpose/reshape chain and index-mapped)
     for form in ("literal", "indexed"):
-        plan = oplanner.cem_plan(env, ff, cp, st, inp["obs"], inp["cp_obs"], inp["cp_act"], inp["init_mean"], inp["init_var"], z, eps,
+        plan = oplanner.cem_plan(env, ff, cp, st, inp["obs"], inp["cp_obs"] if cp is not None else None,
+                                 inp["cp_act"] if cp is not None else None, inp["init_mean"], inp["init_var"], z, eps,
                                  c["E"], c["p"], formulation=form)
         err = np.abs(plan - GOLD[case + "/plan"]).max()
         assert err <= 1e-5, "%s formulation: plan differs from the reference graph's by %.2e" % (form, err)
@@ -90,11 +105,21 @@ def test_hip_planner_reproduces_the_reference_graph(gpu, case):
     c, nets, inp, z, eps, _ = rebuild(case)
     eng = HipEngine(c["env"], c["E"], c["p"], c["D"], c["A"], c["P"], c["C"], c["hidden"], c["H"], history_length=c["Hh"],
                     cp_hidden_sizes=c["cp_hidden"])
-    eng.set_net("context_model", nets["context_model"])
+    vanilla = c["C"] == 0
+    if not vanilla:
+        eng.set_net("context_model", nets["context_model"])
     eng.set_net("ff_model", nets["ff_model"])
     eng.set_stats(inp["stats"])
-    ctx = eng.context_forward(inp["cp_obs"], inp["cp_act"]).cpu().numpy()
-    np.testing.assert_allclose(ctx, GOLD[case + "/context"], rtol=2e-5, atol=2e-6)
+    if vanilla:
+        inp = dict(inp, cp_obs=None, cp_act=None)
+    else:
+        ctx = eng.context_forward(inp["cp_obs"], inp["cp_act"]).cpu().numpy()
+        np.testing.assert_allclose(ctx, GOLD[case + "/context"], rtol=2e-5, atol=2e-6)
+    if c.get("rs"):
+        first, _ = hplanner.rs_plan(eng, inp["obs"], inp["cp_obs"], inp["cp_act"], c["n"], actions=z, eps=eng._t(eps))
+        np.testing.assert_array_equal(first.cpu().numpy(), np.clip(GOLD[case + "/plan"], -1.0, 1.0))     # the chosen candidate's action
+        eng.close()
+        return
     plan = hplanner.cem_plan(eng, inp["obs"], inp["cp_obs"], inp["cp_act"], inp["init_mean"], inp["init_var"], c["n"],
                              z=eng._t(z), eps=eng._t(eps)).cpu().numpy()
     ref = np.clip(GOLD[case + "/plan"], -1.0, 1.0)            # get_action's clip (dynamics.py:365-366)
