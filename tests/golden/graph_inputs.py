@@ -98,6 +98,10 @@ LOSS_CASES = {
                          Hh=3, F=2, B=6, seed=303, deterministic=False, back_coeff=0.5, weight_decay_coeff=1.0,
                          weight_decays=(0.000025, 0.00005, 0.000075, 0.000075, 0.0001),
                          context_weight_decays=(0.000025, 0.00005, 0.000075, 0.000075)),
+    # the vanilla PE-TS class (cadm/dynamics/mlp_ensemble_cem_dynamics.py): no context, no backward model
+    "hc_vanilla_prob": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=5, m=1, n=52, H=2, hidden=(128,) * 4, cp_hidden=(), C=0,
+                            Hh=1, F=1, B=6, seed=707, deterministic=False, back_coeff=0.0, weight_decay_coeff=1.0, vanilla=True,
+                            weight_decays=(0.000025, 0.00005, 0.000075, 0.000075, 0.0001), context_weight_decays=()),
     "hc_cadm_det": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=5, m=1, n=52, H=2, hidden=(128,) * 4, cp_hidden=(16, 8), C=10,
                         Hh=2, F=2, B=5, seed=404, deterministic=True, back_coeff=0.5, weight_decay_coeff=0.5,
                         weight_decays=(0.000025, 0.00005, 0.000075, 0.000075, 0.0001),
@@ -127,9 +131,14 @@ def make_loss_inputs(case):
                 bs_cp_act=f32(rng.uniform(-1, 1, (E, B, A * Hh))))
 
 
-def placeholder_feed(inp):
-    """The constructor's placeholders in creation order (mlp_cadm_ensemble_cem_dynamics.py:108-137)."""
+def placeholder_feed(inp, vanilla=False):
+    """The constructor's placeholders in creation order (mlp_cadm_ensemble_cem_dynamics.py:108-137; vanilla
+    mlp_ensemble_cem_dynamics.py:91-107)."""
     st = inp["stats"]
+    if vanilla:
+        return [inp["obs"], inp["act"], inp["bs_delta"][0], inp["bs_obs"], inp["bs_act"], inp["bs_delta"],
+                st["obs_mean"], st["obs_std"], st["act_mean"], st["act_std"], st["delta_mean"], st["delta_std"],
+                inp["init_mean"], inp["init_var"]]
     return [inp["obs"], inp["obs_next"], inp["act"], inp["cp_obs"], inp["cp_act"],
             inp["bs_obs"], inp["bs_obs_next"], inp["bs_act"], inp["bs_delta"], inp["bs_back_delta"], inp["bs_cp_obs"], inp["bs_cp_act"],
             st["obs_mean"], st["obs_std"], st["act_mean"], st["act_std"], st["delta_mean"], st["delta_std"],

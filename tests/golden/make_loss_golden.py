@@ -42,7 +42,7 @@ def run_case(case):
     if REF not in sys.path:
         sys.path.insert(0, REF)
     # ---- what the constructor needs beyond the graph builder ----
-    feed = list(gi.placeholder_feed(inp))            # arrays in the order the constructor creates its placeholders
+    feed = list(gi.placeholder_feed(inp, vanilla=bool(c.get("vanilla"))))     # arrays in the order the constructor creates its placeholders
 
     def placeholder(dtype, shape=None, name=None):
         arr = feed.pop(0)
@@ -70,6 +70,23 @@ def run_case(case):
                                 action_space=types.SimpleNamespace(shape=(c["A"],)),
                                 obs_preproc=lambda o: Env.obs_preproc(None, o), obs_postproc=lambda o, d: Env.obs_postproc(None, o, d),
                                 tf_reward_fn=lambda: Env.tf_reward_fn(None))
+    if c.get("vanilla"):
+        MV = importlib.import_module("cadm.dynamics.mlp_ensemble_cem_dynamics")               # the vanilla reference model, unchanged
+        model = MV.MLPEnsembleCEMDynamicsModel(
+            "dyn_model", env, hidden_sizes=c["hidden"], hidden_nonlinearity="swish", n_forwards=c["H"], n_candidates=c["n"],
+            ensemble_size=c["E"], n_particles=c["p"], use_cem=True, deterministic=c["deterministic"], weight_decays=c["weight_decays"],
+            weight_decay_coeff=c["weight_decay_coeff"])
+        assert not feed, "placeholders left unfed: %d" % len(feed)
+        res = {case + "/var_names": np.array([n for n, _ in weights.vars]),
+               case + "/var_shapes": np.array([",".join(map(str, v.shape)) for _, v in weights.vars])}
+        for k in ("mse_loss", "l2_reg_loss", "mu_loss", "var_loss", "reg_loss", "recon_loss", "loss"):
+            res[case + "/" + k] = np.asarray(getattr(model, k), np.float32)
+        d = gi.make_fit_inputs(case)
+        rows = [d[k].reshape(-1, d[k].shape[-1]) for k in ("obs", "act", "delta")]         # vanilla fit takes flat [N, .] samples
+        model.compute_normalization(*rows)
+        for k, v in zip(("obs_mean", "obs_std", "act_mean", "act_std", "delta_mean", "delta_std"), model.get_normalization_stats()):
+            res[case + "/norm_" + k] = np.asarray(v, np.float64)
+        return res
     model = M.MLPEnsembleCEMDynamicsModel(
         "dyn_model", env, hidden_sizes=c["hidden"], hidden_nonlinearity="swish", n_forwards=c["H"], n_candidates=c["n"],
         ensemble_size=c["E"], n_particles=c["p"], use_cem=True, deterministic=c["deterministic"], weight_decays=c["weight_decays"],

@@ -25,12 +25,14 @@ def rebuild(case):
     W = gi.Weights(c["seed"])
     nets = {k: OrderedDict() for k in NETS}
     for name, shp in zip(GOLD[case + "/var_names"], GOLD[case + "/var_shapes"]):
-        _, net, _, pname = str(name).split("/")                 # <model>/<net>/<layer scope>/<variable>
+        parts = str(name).split("/")                             # <model>/<net>/<layer scope>/<variable>; vanilla: no <net> level
+        net, pname = (parts[1], parts[3]) if len(parts) == 4 else ("ff_model", parts[-1])
         shape = tuple(int(s) for s in str(shp).split(","))
         if pname.endswith(("_weight", "_bias")):
             nets[net][pname] = W.dense(str(name), shape)
         else:
-            nets[net][pname] = W.plain(str(name), np.ones(shape) / 2.0 if pname == "max_logvar" else -np.ones(shape) * 10)
+            key = {"max_log_var": "max_logvar", "min_log_var": "min_logvar"}.get(pname, pname)      # the vanilla builder's spelling
+            nets[net][key] = W.plain(str(name), np.ones(shape) / 2.0 if key == "max_logvar" else -np.ones(shape) * 10)
     return c, nets, gi.make_loss_inputs(case)
 
 
@@ -50,14 +52,15 @@ def test_oracle_losses_match_the_reference_constructor(case):
     import torch
     from oracle import train as otrain
     c, nets, inp = rebuild(case)
-    t = lambda d: otrain.to_torch(d, torch.float32)
+    t = lambda d: otrain.to_torch(d, torch.float32) if d else None
     batch = {k: torch.tensor(inp["bs_" + k]) for k in ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")}
     cfg = dict(deterministic=c["deterministic"], back_coeff=c["back_coeff"], weight_decay_coeff=c["weight_decay_coeff"],
                weight_decays=c["weight_decays"], context_weight_decays=c["context_weight_decays"], n_hidden=len(c["hidden"]),
                n_cp_hidden=len(c["cp_hidden"]))
     out = otrain.train_losses(c["env"], t(nets["ff_model"]), t(nets["backward_model"]), t(nets["context_model"]), t(inp["stats"]),
                               batch, cfg)
-    for ok, gk in (("mse", "mse_loss"), ("back_mse", "back_mse_loss"), ("recon", "recon_loss"), ("loss", "loss")):
+    pairs = [("mse", "mse_loss"), ("recon", "recon_loss"), ("loss", "loss")] + ([] if c.get("vanilla") else [("back_mse", "back_mse_loss")])
+    for ok, gk in pairs:
         np.testing.assert_allclose(float(out[ok]), float(GOLD[case + "/" + gk]), rtol=2e-5, err_msg=gk)
 
 
@@ -69,6 +72,13 @@ def test_fit_rows_and_normalisation_match_the_reference_methods(case):
     from oracle import train as otrain
     c = gi.LOSS_CASES[case]
     d = gi.make_fit_inputs(case)
+    if c.get("vanilla"):      # mlp_ensemble_cem_dynamics.py:344-372: three statistics over flat samples
+        obs, act, delta = (d[k].reshape(-1, d[k].shape[-1]) for k in ("obs", "act", "delta"))
+        env = oenvs.make_env(c["env"])
+        for k, v in (("obs", env.obs_preproc(obs)), ("act", act), ("delta", delta)):
+            np.testing.assert_allclose(v.mean(0), GOLD[case + "/norm_%s_mean" % k], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(v.std(0), GOLD[case + "/norm_%s_std" % k], rtol=0, atol=1e-12)
+        return
     rows = otrain.preprocess_inputs(d["obs"], d["act"], d["delta"], d["cp_obs"], d["cp_act"], d["future_bool"], d["obs_next"],
                                     d["back_delta"], c["D"], c["A"], c["Hh"], c["F"])
     names = ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
@@ -86,15 +96,20 @@ def test_fit_rows_and_normalisation_match_the_reference_methods(case):
 def test_hip_training_forward_matches_the_reference_constructor(gpu, case):
     from cadm_amd import synth
     c, nets, inp = rebuild(case)
-    prob = synth.make_problem(env=c["env"], context=True, E=c["E"], m=1, hidden_sizes=c["hidden"], cp_hidden_sizes=c["cp_hidden"],
-                              C=c["C"], Hh=c["Hh"], H=c["H"], with_back=True, seed=0)
-    prob["cp"], prob["ff"], prob["back"] = nets["context_model"], nets["ff_model"], nets["backward_model"]
-    prob["stats"] = {k: np.asarray(v, np.float64) for k, v in inp["stats"].items()}
+    vanilla = bool(c.get("vanilla"))
+    prob = synth.make_problem(env=c["env"], context=not vanilla, E=c["E"], m=1, hidden_sizes=c["hidden"],
+                              cp_hidden_sizes=c["cp_hidden"] or (8,), C=c["C"], Hh=c["Hh"], H=c["H"], with_back=not vanilla, seed=0)
+    prob["ff"] = nets["ff_model"]
+    if not vanilla:
+        prob["cp"], prob["back"] = nets["context_model"], nets["backward_model"]
+    prob["stats"] = dict(prob["stats"], **{k: np.asarray(v, np.float64) for k, v in inp["stats"].items()
+                                           if not vanilla or k.split("_")[0] in ("obs", "act", "delta")})
     eng = synth.make_engine(prob, p=c["p"], deterministic=c["deterministic"])
     eng.train_configure(1e-3, c["weight_decays"], c["context_weight_decays"], c["weight_decay_coeff"], c["back_coeff"],
                         max_batch=c["B"])
-    batch = {k: eng._t(inp["bs_" + k]) for k in ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")}
+    keys = ("obs", "act", "delta") if vanilla else ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
+    batch = {k: eng._t(inp["bs_" + k]) for k in keys}
     got = eng.train_step(batch, train=False).cpu().numpy()                     # [mse, back_mse, recon]
-    want = [float(GOLD[case + "/" + k]) for k in ("mse_loss", "back_mse_loss", "recon_loss")]
+    want = [float(GOLD[case + "/mse_loss"]), 0.0 if vanilla else float(GOLD[case + "/back_mse_loss"]), float(GOLD[case + "/recon_loss"])]
     np.testing.assert_allclose(got, want, rtol=5e-5)
     eng.close()
