@@ -13,6 +13,16 @@ CASES = {   # name: dict(env, E, p, m, n, H, hidden, cp_hidden, C, Hh, seed)
     # the vanilla PE-TS twin (create_plus_ensemble_cem_mlp, core/utils.py:5-248): no context encoder
     "hc_vanilla_m2": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=10, m=2, n=54, H=3, hidden=(128,) * 4, cp_hidden=(), C=0, Hh=2,
                           B=2, seed=606, vanilla=True),
+    # the other env kinds' closures (obs_preproc / obs_postproc / tf_reward_fn of cadm/envs/*.py) inside the same graph
+    "ant_cadm": dict(env="ant", D=28, A=8, P=27, E=5, p=5, m=2, n=52, H=3, hidden=(128,) * 4, cp_hidden=(16, 8), C=10, Hh=2, B=2, seed=811),
+    "humanoid_cadm": dict(env="slim_humanoid", D=45, A=17, P=45, E=5, p=5, m=1, n=52, H=2, hidden=(128,) * 4, cp_hidden=(16, 8), C=10,
+                          Hh=2, B=2, seed=812),
+    "cripple_cadm": dict(env="cripple_halfcheetah", D=18, A=6, P=18, E=5, p=5, m=2, n=52, H=3, hidden=(128,) * 4, cp_hidden=(16, 8),
+                         C=10, Hh=2, B=2, seed=813),
+    "pendulum_cadm": dict(env="pendulum", D=3, A=1, P=3, E=5, p=5, m=2, n=52, H=4, hidden=(128,) * 4, cp_hidden=(16, 8), C=10, Hh=2,
+                          B=2, seed=814),
+    "cartpole_rs": dict(env="cartpole", D=4, A=2, P=4, E=5, p=5, m=2, n=40, H=4, hidden=(128,) * 4, cp_hidden=(16, 8), C=10, Hh=2,
+                        B=2, seed=815, rs=True, discrete=True),
     "hc_cadm_rs": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=10, m=2, n=40, H=3, hidden=(128,) * 4, cp_hidden=(16, 8),
                        C=10, Hh=2, B=2, seed=505, rs=True),
 }
@@ -43,6 +53,11 @@ class Draws:
         z = self.rng.standard_normal(tuple(int(s) for s in shape)).astype(np.float32)
         self.log.append(("normal", z))
         return z
+
+    def randint(self, shape, n):
+        k = self.rng.integers(0, int(n), tuple(int(s) for s in shape)).astype(np.int32)
+        self.log.append(("randint", k))
+        return k
 
     def uniform(self, shape, lo, hi):
         u = self.rng.uniform(lo, hi, tuple(int(s) for s in shape)).astype(np.float32)

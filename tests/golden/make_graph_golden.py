@@ -2,8 +2,8 @@
 """Golden vectors for the PLANNER GRAPH WIRING, executed by the reference's own graph-building code.
 
 What this is: /root/reference/cadm/dynamics/core/utils.py (`create_ensemble_pure_context_predictor`,
-`create_plus_cadm_ensemble_cem_mlp`, `create_dense_layer`, `normalize`) and the env closures of
-/root/reference/cadm/envs/half_cheetah_env.py are imported UNCHANGED and run.  The reference builds a TensorFlow 1.15
+`create_plus_cadm_ensemble_cem_mlp`, `create_plus_ensemble_cem_mlp`, `create_dense_layer`, `normalize`) and the env closures of
+/root/reference/cadm/envs/*.py (every env kind) are imported UNCHANGED and run.  The reference builds a TensorFlow 1.15
 graph; TensorFlow is not installed here, so `tensorflow` is replaced by the numpy-EAGER stand-in below: every `tf.*` call
 the graph builder makes is mapped to the numpy function with the same published semantics (float32), "placeholders" are
 concrete arrays, and the unrolled CEM graph therefore computes its result while it is being "built".
@@ -58,6 +58,9 @@ def build_tf(weights, draws):
     tf.argmax = lambda x, axis, output_type=np.int64: np.argmax(x, axis=axis).astype(output_type)
     tf.one_hot = lambda idx, depth: np.eye(depth, dtype=F32)[idx]
     tf.matmul = lambda a, b: np.matmul(a, b)
+    tf.cast = lambda x, dtype=None, **kw: _a(x).astype(dtype)
+    tf.logical_and, tf.less, tf.greater = np.logical_and, np.less, np.greater
+    tf.clip_by_value = lambda x, lo, hi: np.clip(x, F32(lo), F32(hi))
 
     def softplus(x):       # tf.nn.softplus, TF 1.15 Eigen functor: threshold = log(eps) + 2
         x = _a(x)
@@ -72,7 +75,7 @@ def build_tf(weights, draws):
 
     tf.nn = types.SimpleNamespace(softplus=softplus, top_k=top_k, relu=lambda x: np.maximum(x, F32(0)),
                                   l2_loss=lambda w: np.sum(np.square(w), dtype=np.float32) / F32(2), softmax=None)
-    tf.math = types.SimpleNamespace(log=np.log)
+    tf.math = types.SimpleNamespace(log=np.log, atan2=np.arctan2)
 
     def truncated_normal(shape, mean=0.0, stddev=1.0, **kw):      # mean + stddev * Z, Z ~ N(0,1) re-drawn beyond 2 sigma
         return (mean + stddev * draws.truncated(shape)).astype(np.float32)
@@ -81,7 +84,8 @@ def build_tf(weights, draws):
         return draws.normal(shape)
 
     def uniform(shape, minval=0, maxval=None, dtype=np.float32, **kw):
-        assert dtype == np.float32, "discrete random shooting is not part of this golden"
+        if dtype == np.int32:                            # discrete random shooting: action indices in [0, maxval)
+            return draws.randint(shape, maxval)
         return draws.uniform(shape, minval, maxval)
 
     tf.random = types.SimpleNamespace(truncated_normal=truncated_normal, normal=normal, uniform=uniform)
@@ -149,6 +153,13 @@ class _PlaceholderFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         pass
 
 
+ENVS = {"halfcheetah": ("cadm.envs.half_cheetah_env", "HalfCheetahEnv"),
+        "cripple_halfcheetah": ("cadm.envs.half_cheetah_cripple_env", "CrippleHalfCheetahEnv"),
+        "ant": ("cadm.envs.ant_env", "AntEnv"), "slim_humanoid": ("cadm.envs.slim_humanoid_env", "SlimHumanoidEnv"),
+        "cartpole": ("cadm.envs.classic_control", "RandomCartPole_Force_Length"),
+        "pendulum": ("cadm.envs.classic_control", "RandomPendulumAll")}
+
+
 def run_case(case):
     c = gi.CASES[case]
     inp = gi.make_inputs(case)
@@ -161,10 +172,12 @@ def run_case(case):
     if REF not in sys.path:
         sys.path.insert(0, REF)
     U = importlib.import_module("cadm.dynamics.core.utils")                 # the reference's graph builder, unchanged
-    Env = importlib.import_module("cadm.envs.half_cheetah_env").HalfCheetahEnv
-    pre = lambda o: Env.obs_preproc(None, o)
-    post = lambda o, d: Env.obs_postproc(None, o, d)
-    reward = Env.tf_reward_fn(None)
+    mod, cls = ENVS[c["env"]]
+    Env = getattr(importlib.import_module(mod), cls)                         # the env class's closures, unchanged
+    me = types.SimpleNamespace(max_torque=2.0)                               # `self` of the closures (pendulum: classic_control.py:185)
+    pre = lambda o: Env.obs_preproc(me, o)
+    post = lambda o, d: Env.obs_postproc(me, o, d)
+    reward = Env.tf_reward_fn(me)
     swish = lambda x: x * tf.sigmoid(x)                                     # mlp_cadm_ensemble_cem_dynamics.py:23
     st = inp["stats"]
     D, A, E = c["D"], c["A"], c["E"]
@@ -204,7 +217,7 @@ def run_case(case):
             norm_cp_act_std_var=st["cp_act_std"], n_particles=c["p"], bs_input_obs_var=inp["bs_obs"], bs_input_act_var=inp["bs_act"],
             bs_input_cp_var=bs_cp, cp_output_dim=c["C"], history_length=c["Hh"],
             cem_init_mean_var=None if c.get("rs") else inp["init_mean"], cem_init_var_var=None if c.get("rs") else inp["init_var"],
-            obs_preproc_fn=pre, obs_postproc_fn=post, deterministic=False,
+            obs_preproc_fn=pre, obs_postproc_fn=post, deterministic=False, discrete=bool(c.get("discrete")),
             build_policy_graph=True, cp_forward=cp_forward)
     (_, _, output_var, optimal_action, mu, logvar, max_lv, min_lv, l2_regs, inference_cp, _) = out
     res = {case + "/plan": np.asarray(optimal_action, np.float32), case + "/context": np.asarray(inference_cp, np.float32),

@@ -38,11 +38,11 @@ def rebuild(case):
     for kind, shp in zip(GOLD[case + "/draw_kinds"], GOLD[case + "/draw_shapes"]):
         shape = tuple(int(s) for s in str(shp).split(","))
         seq.append((str(kind), draws.truncated(shape) if kind == "truncated_normal" else draws.uniform(shape, -1, 1) if kind == "uniform"
-                    else draws.normal(shape)))
+                    else draws.randint(shape, c["A"]) if kind == "randint" else draws.normal(shape)))
     E, p, m, n, H, D = c["E"], c["p"], c["m"], c["n"], c["H"], c["D"]
     train_eps = seq[0][1]
     if c.get("rs"):       # random shooting: one uniform action tensor, then the head noise of every step
-        assert [k for k, _ in seq] == ["normal", "uniform"] + ["normal"] * H
+        assert [k for k, _ in seq] == ["normal", "randint" if c.get("discrete") else "uniform"] + ["normal"] * H
         eps = np.stack([e.reshape(p, m, n, D).transpose(1, 2, 0, 3) for _, e in seq[2:]])        # [H, m, n, p, D]
         return c, nets, gi.make_inputs(case), seq[1][1], eps, train_eps
     assert [k for k, _ in seq] == ["normal"] + (["truncated_normal"] + ["normal"] * H) * 5     # the graph's draw order
@@ -85,7 +85,12 @@ def test_oracle_reproduces_the_reference_graph(case):
     np.testing.assert_allclose(out, GOLD[case + "/train_output"], rtol=1e-5, atol=1e-5)
     if c.get("rs"):      # the random-shooting planner (core/utils.py:490-561): z = the uniform action tensor [m, n, H, A]
         for form in ("literal", "indexed"):
-            first, _ = oplanner.rs_plan(env, ff, cp, st, inp["obs"], inp["cp_obs"], inp["cp_act"], z, eps, c["E"], c["p"], formulation=form)
+            if c.get("discrete"):     # z = action indices [m, n, H]; the net sees their one-hot rows un-normalised (core/utils.py:499-500)
+                first, _ = oplanner.rs_plan(env, ff, cp, st, inp["obs"], inp["cp_obs"], inp["cp_act"], np.eye(c["A"], dtype=np.float32)[z],
+                                            eps, c["E"], c["p"], formulation=form, raw_actions=z)
+            else:
+                first, _ = oplanner.rs_plan(env, ff, cp, st, inp["obs"], inp["cp_obs"], inp["cp_act"], z, eps, c["E"], c["p"],
+                                            formulation=form)
             np.testing.assert_array_equal(first, GOLD[case + "/plan"], err_msg=form)
         return
     # the unrolled CEM planner, both formulations of the oracle (literal tile/transpose/reshape chain and index-mapped)
@@ -104,7 +109,7 @@ def test_hip_planner_reproduces_the_reference_graph(gpu, case):
     from cadm_amd.engine import HipEngine
     c, nets, inp, z, eps, _ = rebuild(case)
     eng = HipEngine(c["env"], c["E"], c["p"], c["D"], c["A"], c["P"], c["C"], c["hidden"], c["H"], history_length=c["Hh"],
-                    cp_hidden_sizes=c["cp_hidden"])
+                    cp_hidden_sizes=c["cp_hidden"], discrete=bool(c.get("discrete")))
     vanilla = c["C"] == 0
     if not vanilla:
         eng.set_net("context_model", nets["context_model"])
@@ -116,8 +121,13 @@ def test_hip_planner_reproduces_the_reference_graph(gpu, case):
         ctx = eng.context_forward(inp["cp_obs"], inp["cp_act"]).cpu().numpy()
         np.testing.assert_allclose(ctx, GOLD[case + "/context"], rtol=2e-5, atol=2e-6)
     if c.get("rs"):
-        first, _ = hplanner.rs_plan(eng, inp["obs"], inp["cp_obs"], inp["cp_act"], c["n"], actions=z, eps=eng._t(eps))
-        np.testing.assert_array_equal(first.cpu().numpy(), np.clip(GOLD[case + "/plan"], -1.0, 1.0))     # the chosen candidate's action
+        if c.get("discrete"):
+            first, _ = hplanner.rs_plan(eng, inp["obs"], inp["cp_obs"], inp["cp_act"], c["n"], actions=np.eye(c["A"], dtype=np.float32)[z],
+                                        raw=z, eps=eng._t(eps))
+            np.testing.assert_array_equal(first.cpu().numpy(), GOLD[case + "/plan"])                      # the chosen action index
+        else:
+            first, _ = hplanner.rs_plan(eng, inp["obs"], inp["cp_obs"], inp["cp_act"], c["n"], actions=z, eps=eng._t(eps))
+            np.testing.assert_array_equal(first.cpu().numpy(), np.clip(GOLD[case + "/plan"], -1.0, 1.0))  # the chosen candidate's action
         eng.close()
         return
     plan = hplanner.cem_plan(eng, inp["obs"], inp["cp_obs"], inp["cp_act"], inp["init_mean"], inp["init_var"], c["n"],
