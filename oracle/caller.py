@@ -1,7 +1,8 @@
 """Oracle restatement of the samplers' per-env bookkeeping around get_action (test infrastructure only).
 
 Follows /root/reference/cadm/samplers/sampler.py: warm start :52-57,118-120; history window :95-97,165-178;
-done handling :193-202."""
+done handling :193-202.  Pinned to the reference's own Sampler.obtain_samples run (tests/golden/make_sampler_golden.py ->
+sampler_golden.npz, tests/test_sampler_golden.py)."""
 import numpy as np
 
 
