@@ -259,6 +259,58 @@ def early_stop_trace(v_recon, persistency):
     return last, trace
 
 
+def _fit_setup(env, data, stream, E, valid_split_ratio, max_logging, discrete, state_diff):
+    """Everything `fit` does before its epoch loop (dynamics.py:399-467): targets, normalisation over the first-step columns,
+    window split, `_preprocess_inputs`, bootstrap indices.  -> (stats, train rows, valid rows or None, bootstrap_idx, n_train)"""
+    D, A = env.obs_dim, env.act_dim
+    obs, act, obs_next = data["obs"], data["act"], data["obs_next"]
+    cp_obs, cp_act, future_bool = data["cp_obs"], data["cp_act"], data["future_bool"]
+    F = future_bool.shape[1]
+    Hh = cp_obs.shape[1] // D if D else 0
+    o1, on1 = obs.reshape(-1, D), obs_next.reshape(-1, D)
+    delta = env.targ_proc(o1, on1).reshape(-1, F * D)                    # :401,405
+    back_delta = env.targ_proc(on1, o1).reshape(-1, F * D)               # :402,407
+    norm = compute_normalization(env, obs[:, :D], act[:, :A], delta[:, :D], cp_obs, cp_act, back_delta[:, :D])   # :428-440
+    stats_np = normalization_stats(norm, D, A, Hh, discrete, state_diff)
+    N = obs.shape[0]
+    n_valid = min(int(N * valid_split_ratio), max_logging)              # :443
+    perm = np.asarray(stream.permutation(N))                            # :444
+    tr, va = perm[n_valid:], perm[:n_valid]
+    cols = lambda idx: preprocess_inputs(obs[idx], act[idx], delta[idx], cp_obs[idx], cp_act[idx], future_bool[idx],
+                                         obs_next[idx], back_delta[idx], D, A, Hh, F)
+    names = ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
+    train = dict(zip(names, cols(tr)))
+    valid = dict(zip(names, cols(va))) if n_valid > 0 else None
+    n_train = train["obs"].shape[0]
+    if E > 1:
+        bidx = np.asarray(stream.bootstrap(E, n_train))                 # :465
+    else:
+        bidx = np.tile(np.arange(n_train), (E, 1))                      # :467
+    return stats_np, train, valid, bidx, n_train
+
+
+def fit_feed_sequence(env, data, stream, E, epochs, batch_size, valid_split_ratio=0.2, max_logging=5000, discrete=False,
+                      state_diff=True):
+    """What `fit` FEEDS the graph, without training: (stats, [per epoch: ([train batches], valid batch or None)]); a batch is a dict
+    of [E, B, .] arrays.  Same draws from `stream` as `fit_reference` (tests/test_loss_golden.py compares it with the feeds of
+    the reference's own fit())."""
+    stats, train, valid, bidx, n_train = _fit_setup(env, data, stream, E, valid_split_ratio, max_logging, discrete, state_diff)
+    out = []
+    for _ in range(epochs):
+        order = np.asarray(stream.epoch_order(E, n_train))              # shuffle_rows, :472-474
+        bidx = bidx[np.arange(E)[:, None], order]                       # :483
+        batches = []
+        for b in range(int(np.ceil(n_train / batch_size))):
+            idx = bidx[:, b * batch_size:(b + 1) * batch_size]          # :487
+            batches.append({k: v[idx] for k, v in train.items()})
+        vb = None
+        if valid is not None and valid["obs"].shape[0] > 0:
+            vidx = np.tile(np.arange(valid["obs"].shape[0]), (E, 1))    # :469-470
+            vb = {k: v[vidx] for k, v in valid.items()}
+        out.append((batches, vb))
+    return stats, out
+
+
 # ----------------------------------------------------------------------------
 # fit(): the whole host loop, on an injected index stream
 # ----------------------------------------------------------------------------
@@ -277,34 +329,10 @@ def fit_reference(env, env_name, nets, data, stream, cfg, epochs, batch_size, va
     cfg: the `train_losses` cfg + state_diff, discrete.
     Returns dict(train=[per-step (mse, back_mse, recon)], valid=[per-epoch], params={net: {name: numpy}}, stats=dict,
     epochs_run)."""
-    D, A = env.obs_dim, env.act_dim
-    obs, act, obs_next = data["obs"], data["act"], data["obs_next"]
-    cp_obs, cp_act, future_bool = data["cp_obs"], data["cp_act"], data["future_bool"]
-    F = future_bool.shape[1]
-    Hh = cp_obs.shape[1] // D if D else 0
-    o1, on1 = obs.reshape(-1, D), obs_next.reshape(-1, D)
-    delta = env.targ_proc(o1, on1).reshape(-1, F * D)                    # :401,405
-    back_delta = env.targ_proc(on1, o1).reshape(-1, F * D)               # :402,407
-    norm = compute_normalization(env, obs[:, :D], act[:, :A], delta[:, :D], cp_obs, cp_act, back_delta[:, :D])   # :428-440
-    stats_np = normalization_stats(norm, D, A, Hh, cfg.get("discrete", False), cfg.get("state_diff", True))
-    st = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in stats_np.items()}
-
-    N = obs.shape[0]
-    n_valid = min(int(N * valid_split_ratio), max_logging)              # :443
-    perm = np.asarray(stream.permutation(N))                            # :444
-    tr, va = perm[n_valid:], perm[:n_valid]
-    cols = lambda idx: preprocess_inputs(obs[idx], act[idx], delta[idx], cp_obs[idx], cp_act[idx], future_bool[idx],
-                                         obs_next[idx], back_delta[idx], D, A, Hh, F)
-    names = ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
-    train = dict(zip(names, cols(tr)))
-    valid = dict(zip(names, cols(va))) if n_valid > 0 else None
-    n_train = train["obs"].shape[0]
     E = next(iter(nets["ff"].values())).shape[0]
-    if E > 1:
-        bidx = np.asarray(stream.bootstrap(E, n_train))                 # :465
-    else:
-        bidx = np.tile(np.arange(n_train), (E, 1))                      # :467
-
+    stats_np, train, valid, bidx, n_train = _fit_setup(env, data, stream, E, valid_split_ratio, max_logging,
+                                                       cfg.get("discrete", False), cfg.get("state_diff", True))
+    st = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in stats_np.items()}
     params = {k: (None if v is None else to_torch(v, dtype, requires_grad=True)) for k, v in nets.items()}
     adam = TF1Adam(lr=lr)
     tb = lambda d, idx: {k: torch.tensor(np.asarray(v[idx]), dtype=dtype) for k, v in d.items()}

@@ -29,6 +29,83 @@ import make_graph_golden as mg  # noqa: E402
 REF = "/root/reference"
 
 
+class _PH(np.ndarray):
+    """A fed placeholder: hashable by identity (`fit` uses placeholders as feed_dict keys); anything computed FROM it is a plain
+    array / numpy scalar again (a 0-d subclass instance would make the constructor's `recon_loss += ...` an in-place update of
+    `mse_loss`, which tensors are not)."""
+    __hash__ = object.__hash__
+
+    def __eq__(self, other):
+        return self is other if isinstance(other, _PH) else np.ndarray.__eq__(self, other)
+
+    def __array_wrap__(self, out_arr, context=None, return_scalar=False):
+        out = np.asarray(out_arr)
+        return out[()] if out.ndim == 0 else out
+
+    def __getitem__(self, idx):
+        return np.asarray(self)[idx]
+
+
+def run_fit(model, tf, c, case):
+    """The reference's own `fit` (dynamics.py:382-569) on the constructed model, with a session that records what it is fed
+    and answers with SCRIPTED losses (no TensorFlow, no training): pins the host loop -- targets, dataset columns,
+    normalisation, window split, `_preprocess_inputs`, bootstrap indices, per-epoch `shuffle_rows`, batch slicing, the
+    validation batch and the rolling-average early stop -- and the order in which it consumes `np.random`."""
+    d = gi.make_fit_inputs(case, N=23)
+    N, F, D, A = d["obs"].shape[0], c["F"], c["D"], c["A"]
+    draws = []
+    real = {k: getattr(np.random, k) for k in ("permutation", "randint", "uniform")}
+
+    def logged(kind):
+        def f(*a, **k):
+            out = real[kind](*a, **k)
+            draws.append((kind, np.array(out)))
+            return out
+        return f
+
+    v_script = [10.0, 8.0, 7.0, 6.5, 6.4, 6.45, 6.8, 7.5, 9.0, 12.0, 15.0, 20.0]
+    fed = {"train": [], "valid": []}
+    keys = ("bs_obs_ph", "bs_act_ph", "bs_delta_ph", "bs_obs_next_ph", "bs_back_delta_ph", "bs_cp_obs_ph", "bs_cp_act_ph")
+    stats_keys = ("norm_obs_mean_ph", "norm_obs_std_ph", "norm_act_mean_ph", "norm_act_std_ph", "norm_delta_mean_ph", "norm_delta_std_ph",
+                  "norm_cp_obs_mean_ph", "norm_cp_obs_std_ph", "norm_cp_act_mean_ph", "norm_cp_act_std_ph", "norm_back_delta_mean_ph",
+                  "norm_back_delta_std_ph")
+
+    class Session:
+        def run(self, fetches, feed_dict=None):
+            batch = [np.array(feed_dict[getattr(model, k)], np.float64) for k in keys]
+            stats = [np.array(feed_dict[getattr(model, k)], np.float64) for k in stats_keys]
+            if len(fetches) == 4:                    # a training step: [mse, back_mse, recon, train_op]
+                fed["train"].append((batch, stats))
+                return 1.0, 0.5, 1.25, None
+            fed["valid"].append((batch, stats))
+            return 1.0, 0.5, v_script[len(fed["valid"]) - 1]
+
+    tf.compat.v1.get_default_session = lambda: Session()
+    np.random.seed(c["seed"])
+    for k in real:
+        setattr(np.random, k, logged(k))
+    try:
+        model._dataset = None
+        model.batch_size = 16
+        model.fit(d["obs"].reshape(N, -1), d["act"].reshape(N, -1), d["obs_next"].reshape(N, -1), d["cp_obs"], d["cp_act"], d["future_bool"],
+                  epochs=len(v_script), valid_split_ratio=0.25, rolling_average_persitency=0.9)
+    finally:
+        for k, f in real.items():
+            setattr(np.random, k, f)
+    res = {case + "/fit_draw_kinds": np.array([k for k, _ in draws]), case + "/fit_v_script": np.array(v_script),
+           case + "/fit_epochs_run": np.int64(len(fed["valid"])), case + "/fit_steps_per_epoch": np.int64(len(fed["train"]) // len(fed["valid"]))}
+    for i, (k, v) in enumerate(draws):
+        res[case + "/fit_draw_%02d" % i] = v
+    names = ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
+    for which in ("train", "valid"):
+        for j, nm in enumerate(names):          # batches of one kind have equal shapes except the last of an epoch: store flattened rows
+            res[case + "/fit_%s_%s" % (which, nm)] = np.concatenate([b[j].reshape(b[j].shape[0], -1, b[j].shape[-1]) for b, _ in fed[which]], axis=1)
+        res[case + "/fit_%s_sizes" % which] = np.array([b[0].shape[1] for b, _ in fed[which]], np.int64)
+    for k, v in zip(stats_keys, fed["train"][0][1]):
+        res[case + "/fit_stat_" + k[5:-3]] = v
+    return res
+
+
 def run_case(case):
     c = gi.LOSS_CASES[case]
     inp = gi.make_loss_inputs(case)
@@ -47,7 +124,7 @@ def run_case(case):
     def placeholder(dtype, shape=None, name=None):
         arr = feed.pop(0)
         assert len(shape) == arr.ndim and all(s is None or int(s) == d for s, d in zip(shape, arr.shape)), (shape, arr.shape)
-        return arr
+        return arr.view(_PH)                         # hashable by identity: `fit` uses placeholders as feed_dict keys
 
     v1 = tf.compat.v1
     v1.placeholder = placeholder
@@ -112,6 +189,9 @@ def run_case(case):
     for k, v in zip(("obs_mean", "obs_std", "act_mean", "act_std", "delta_mean", "delta_std", "cp_obs_mean", "cp_obs_std",
                      "cp_act_mean", "cp_act_std", "back_delta_mean", "back_delta_std"), model.get_normalization_stats()):
         res[case + "/norm_" + k] = np.asarray(v, np.float64)
+    if case == "hc_cadm_prob":
+        env.targ_proc = lambda o, n: Env.targ_proc(None, o, n)
+        res.update(run_fit(model, tf, c, case))
     return res
 
 

@@ -91,6 +91,42 @@ def test_fit_rows_and_normalisation_match_the_reference_methods(case):
         np.testing.assert_allclose(v, GOLD[case + "/norm_" + k], rtol=0, atol=1e-12, err_msg=k)
 
 
+def test_fit_host_loop_matches_the_reference_fit():
+    """The reference's own `fit` (dynamics.py:382-569), run on the constructed model with a recording session that answers with
+    scripted losses: every batch it fed (training and validation, all epochs), the statistics it fed, the order in which it
+    consumed np.random, and the epoch at which its rolling-average early stop fired -- against the oracle's restatement
+    replaying the SAME draws (tests/test_gpu_fit.py ties the product's fit to that restatement on the device)."""
+    from cadm_amd.dynamics.mlp_cadm_ensemble_cem_dynamics import ReplayIndexStream
+    from oracle import envs as oenvs
+    from oracle import train as otrain
+    case = "hc_cadm_prob"
+    c = gi.LOSS_CASES[case]
+    g = lambda k: GOLD[case + "/fit_" + k]
+    kinds = [str(k) for k in g("draw_kinds")]
+    epochs_run, per_epoch = int(g("epochs_run")), int(g("steps_per_epoch"))
+    assert kinds == ["permutation", "randint"] + ["uniform"] * epochs_run            # :444, :465, then one shuffle_rows per epoch
+    draws = [GOLD[case + "/fit_draw_%02d" % i] for i in range(len(kinds))]
+    log = [("permutation", draws[0]), ("bootstrap", draws[1])] + [("epoch_order", np.argsort(u, axis=-1)) for u in draws[2:]]
+    d = gi.make_fit_inputs(case, N=23)
+    N = d["obs"].shape[0]
+    data = {k: (d[k].reshape(N, -1) if k in ("obs", "act", "obs_next") else d[k]) for k in ("obs", "act", "obs_next", "cp_obs", "cp_act", "future_bool")}
+    stats, seq = otrain.fit_feed_sequence(oenvs.make_env(c["env"]), data, ReplayIndexStream(log), c["E"], epochs_run, 16,
+                                          valid_split_ratio=0.25)
+    for k, v in stats.items():
+        np.testing.assert_allclose(v, g("stat_" + k), rtol=0, atol=1e-12, err_msg=k)
+    names = ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
+    assert sum(len(b) for b, _ in seq) == epochs_run * per_epoch
+    for nm in names:
+        got = np.concatenate([b[nm] for batches, _ in seq for b in batches], axis=1)
+        np.testing.assert_array_equal(got, g("train_" + nm), err_msg="train " + nm)
+        got = np.concatenate([vb[nm] for _, vb in seq], axis=1)
+        np.testing.assert_array_equal(got, g("valid_" + nm), err_msg="valid " + nm)
+    assert [b["obs"].shape[1] for batches, _ in seq for b in batches] == list(g("train_sizes"))
+    # the early stop: the reference stopped after `epochs_run` epochs of the scripted validation losses
+    last, _ = otrain.early_stop_trace(list(g("v_script")), 0.9)
+    assert last + 1 == epochs_run < len(g("v_script"))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", sorted(gi.LOSS_CASES))
 def test_hip_training_forward_matches_the_reference_constructor(gpu, case):
