@@ -192,6 +192,10 @@ def run_case(case):
     if case == "hc_cadm_prob":
         env.targ_proc = lambda o, n: Env.targ_proc(None, o, n)
         res.update(run_fit(model, tf, c, case))
+    if c.get("save"):        # the reference's own save() (dynamics.py:571-577) writes the checkpoint fixture: joblib list + _norm_stats
+        tf.compat.v1.get_default_session = lambda: types.SimpleNamespace(run=lambda fetches, feed_dict=None: [np.array(p) for p in fetches])
+        os.makedirs(os.path.join(HERE, "ref_ckpt"), exist_ok=True)
+        model.save(os.path.join(HERE, "ref_ckpt", "params_epoch_7"))
     return res
 
 

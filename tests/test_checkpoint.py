@@ -99,3 +99,61 @@ def test_reference_layout_checkpoint_loads_and_plans_like_the_oracle(gpu, tmp_pa
                             z, eps, E, p)
     ref = oplanner.get_action_clip(ref)
     assert np.abs(plan - ref).max() <= 2e-4, np.abs(plan - ref).max()
+
+
+# ---- a checkpoint written by the REFERENCE's own save() (dynamics.py:571-577), see tests/golden/make_loss_golden.py ----
+REF_CKPT = os.path.join(ROOT, "tests", "golden", "ref_ckpt", "params_epoch_7")
+
+
+def _ref_ckpt_truth():
+    """The variables the reference constructor created for that checkpoint, regenerated from the shared input module."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import graph_inputs as gi
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "loss_golden.npz"))
+    c = gi.LOSS_CASES["ckpt_e1"]
+    W = gi.Weights(c["seed"])
+    out = []
+    for name, shp in zip(gold["ckpt_e1/var_names"], gold["ckpt_e1/var_shapes"]):
+        parts, shape = str(name).split("/"), tuple(int(s) for s in str(shp).split(","))
+        pname = parts[3]
+        arr = W.dense(str(name), shape) if pname.endswith(("_weight", "_bias")) else \
+            W.plain(str(name), np.ones(shape) / 2.0 if pname == "max_logvar" else -np.ones(shape) * 10)
+        out.append(("%s/%s" % (parts[1], pname), arr))
+    return c, gold, out
+
+
+def test_reference_written_checkpoint_is_named_correctly():
+    c, gold, truth = _ref_ckpt_truth()
+    arrays = joblib.load(REF_CKPT)
+    info = ck.describe(arrays)
+    assert info["E"] == 1 and info["hidden_sizes"] == c["hidden"] and info["context_dim"] == c["C"] and info["back_model"]
+    named = ck.to_named(arrays)
+    assert list(named) == [k for k, _ in truth]
+    for k, v in truth:
+        np.testing.assert_array_equal(named[k], v, err_msg=k)
+    stats = joblib.load(REF_CKPT + "_norm_stats")
+    assert list(stats) == ["obs", "delta", "act", "cp_obs", "cp_act", "back_delta"]
+    np.testing.assert_allclose(stats["obs"][0], gold["ckpt_e1/norm_obs_mean"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_reference_written_checkpoint_loads_into_the_model(gpu):
+    from cadm_amd.dynamics.mlp_cadm_ensemble_cem_dynamics import MLPEnsembleCEMDynamicsModel
+    from cadm_amd.envs import make_env_spec
+    c, gold, truth = _ref_ckpt_truth()
+    model = MLPEnsembleCEMDynamicsModel("dyn", make_env_spec("halfcheetah"), hidden_sizes=c["hidden"], hidden_nonlinearity="swish",
+                                        n_forwards=c["H"], n_candidates=64, ensemble_size=c["E"], n_particles=c["p"], use_cem=True,
+                                        state_diff=1, back_coeff=c["back_coeff"], normalize_input=True, cp_hidden_sizes=c["cp_hidden"],
+                                        context_out_dim=c["C"], history_length=c["Hh"], future_length=c["F"])
+    model.load(REF_CKPT)
+    eng = model.engine
+    for key, want in truth:
+        net, pname = key.split("/")
+        np.testing.assert_array_equal(eng.nets[net][pname].cpu().numpy(), want, err_msg=key)
+    got = model.get_normalization_stats()
+    for g, k in zip(got, ("obs_mean", "obs_std", "act_mean", "act_std", "delta_mean", "delta_std", "cp_obs_mean", "cp_obs_std",
+                          "cp_act_mean", "cp_act_std", "back_delta_mean", "back_delta_std")):
+        np.testing.assert_allclose(np.asarray(g, np.float64), gold["ckpt_e1/norm_" + k], rtol=0, atol=1e-7, err_msg=k)
+    plan = model.get_action(np.zeros((1, 18)), np.zeros((1, 18 * c["Hh"])), np.zeros((1, 6 * c["Hh"])), np.zeros((1, c["H"], 6)),
+                            np.full((1, c["H"], 6), 0.25))
+    assert plan.shape == (1, c["H"], 6) and np.isfinite(plan).all()
