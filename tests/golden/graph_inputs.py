@@ -117,6 +117,14 @@ LOSS_CASES = {
     "hc_vanilla_prob": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=5, m=1, n=52, H=2, hidden=(128,) * 4, cp_hidden=(), C=0,
                             Hh=1, F=1, B=6, seed=707, deterministic=False, back_coeff=0.0, weight_decay_coeff=1.0, vanilla=True,
                             weight_decays=(0.000025, 0.00005, 0.000075, 0.000075, 0.0001), context_weight_decays=()),
+    # an env whose obs_preproc drops a dimension (ant: P = D - 1) and one with many dims, through the training graph
+    "ant_cadm_prob": dict(env="ant", D=28, A=8, P=27, E=5, p=5, m=1, n=52, H=2, hidden=(128,) * 4, cp_hidden=(16, 8), C=10, Hh=2,
+                          F=2, B=5, seed=1010, deterministic=False, back_coeff=0.5, weight_decay_coeff=1.0,
+                          weight_decays=(0.000025, 0.00005, 0.000075, 0.000075, 0.0001), context_weight_decays=(0.000025, 0.00005, 0.000075)),
+    "humanoid_cadm_prob": dict(env="slim_humanoid", D=45, A=17, P=45, E=5, p=5, m=1, n=52, H=2, hidden=(128,) * 4, cp_hidden=(16, 8),
+                               C=10, Hh=2, F=2, B=5, seed=1111, deterministic=False, back_coeff=0.0, weight_decay_coeff=1.0,
+                               weight_decays=(0.000025, 0.00005, 0.000075, 0.000075, 0.0001),
+                               context_weight_decays=(0.000025, 0.00005, 0.000075)),
     # one member, so that the checkpoint the reference's own save() writes for it stays small (tests/golden/ref_ckpt/)
     "ckpt_e1": dict(env="halfcheetah", D=18, A=6, P=18, E=1, p=1, m=1, n=52, H=2, hidden=(128,) * 4, cp_hidden=(8,), C=10, Hh=2, F=2,
                     B=4, seed=909, deterministic=False, back_coeff=0.5, weight_decay_coeff=1.0, save=True,

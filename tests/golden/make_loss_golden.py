@@ -142,7 +142,8 @@ def run_case(case):
     v1.train = types.SimpleNamespace(AdamOptimizer=_Opt)
     tf.constant = lambda v, **k: np.float32(v)
     M = importlib.import_module("cadm.dynamics.mlp_cadm_ensemble_cem_dynamics")        # the reference model, unchanged
-    Env = importlib.import_module("cadm.envs.half_cheetah_env").HalfCheetahEnv
+    mod, cls = mg.ENVS[c["env"]]
+    Env = getattr(importlib.import_module(mod), cls)
     env = types.SimpleNamespace(observation_space=types.SimpleNamespace(shape=(c["D"],)), proc_observation_space_dims=c["P"],
                                 action_space=types.SimpleNamespace(shape=(c["A"],)),
                                 obs_preproc=lambda o: Env.obs_preproc(None, o), obs_postproc=lambda o, d: Env.obs_postproc(None, o, d),

@@ -133,19 +133,22 @@ def test_hip_training_forward_matches_the_reference_constructor(gpu, case):
     from cadm_amd import synth
     c, nets, inp = rebuild(case)
     vanilla = bool(c.get("vanilla"))
+    has_back = len(nets["backward_model"]) > 0
     prob = synth.make_problem(env=c["env"], context=not vanilla, E=c["E"], m=1, hidden_sizes=c["hidden"],
-                              cp_hidden_sizes=c["cp_hidden"] or (8,), C=c["C"], Hh=c["Hh"], H=c["H"], with_back=not vanilla, seed=0)
+                              cp_hidden_sizes=c["cp_hidden"] or (8,), C=c["C"], Hh=c["Hh"], H=c["H"], with_back=has_back, seed=0)
     prob["ff"] = nets["ff_model"]
     if not vanilla:
-        prob["cp"], prob["back"] = nets["context_model"], nets["backward_model"]
+        prob["cp"] = nets["context_model"]
+    if has_back:
+        prob["back"] = nets["backward_model"]
     prob["stats"] = dict(prob["stats"], **{k: np.asarray(v, np.float64) for k, v in inp["stats"].items()
                                            if not vanilla or k.split("_")[0] in ("obs", "act", "delta")})
     eng = synth.make_engine(prob, p=c["p"], deterministic=c["deterministic"])
     eng.train_configure(1e-3, c["weight_decays"], c["context_weight_decays"], c["weight_decay_coeff"], c["back_coeff"],
                         max_batch=c["B"])
-    keys = ("obs", "act", "delta") if vanilla else ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
+    keys = ("obs", "act", "delta") + (() if vanilla else ("cp_obs", "cp_act")) + (("obs_next", "back_delta") if has_back else ())
     batch = {k: eng._t(inp["bs_" + k]) for k in keys}
     got = eng.train_step(batch, train=False).cpu().numpy()                     # [mse, back_mse, recon]
-    want = [float(GOLD[case + "/mse_loss"]), 0.0 if vanilla else float(GOLD[case + "/back_mse_loss"]), float(GOLD[case + "/recon_loss"])]
+    want = [float(GOLD[case + "/mse_loss"]), float(GOLD[case + "/back_mse_loss"]) if has_back else 0.0, float(GOLD[case + "/recon_loss"])]
     np.testing.assert_allclose(got, want, rtol=5e-5)
     eng.close()
