@@ -103,6 +103,9 @@ struct XC {
     static constexpr int BIAS_BYTES = (MAX_NH_LDS * NT + NTO) * 1024;
     static constexpr bool BIAS_LDS = CTRL + MT * 16 * 64 * 4 + BIAS_BYTES <= 154 * 1024;
     static constexpr int XDEPTH = MT > 1 ? 2 : 3;          // B-operand chunks in registers (lookahead XDEPTH - 1)
+    static size_t lds_bytes(int H, int NH) {               // dynamic LDS of a launch
+        return (size_t)CTRL + (size_t)rup(MT * 16 * H * 4, 16) + (BIAS_LDS ? (size_t)(NH * NT + NTO) * 1024 : 0);
+    }
 };
 
 template <class G>
@@ -133,16 +136,21 @@ __device__ __forceinline__ void xres_load(uintx4& dst, __amdgpu_buffer_rsrc_t rs
                  : "=a"(dst) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
 }
 __device__ __forceinline__ void xmfma_res(floatx4& acc, const uintx4& w, const f16x8& x) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
 }
 // Streamed fragments (ring registers, VGPRs) go through the same asm form so that ALL MFMAs of a sweep keep their
 // accumulators in VGPRs: a mix of asm and builtin MFMAs makes hipcc shuttle accumulators between VGPRs and AGPRs
 // right behind an MFMA whose latency it cannot see.  (Loads feeding the asm are still tracked: hipcc places the
 // s_waitcnt for any register an asm statement reads.)
 // ASM = false (geometries without resident fragments): plain builtin, hipcc then handles every hazard itself.
+// "s_nop 1" in front of every asm MFMA: under register pressure hipcc parks VGPR values (a ring slot, an operand chunk, an
+// accumulator) in spare AGPRs and copies them back with v_accvgpr_read right in front of the statement that reads them; a
+// VALU-written VGPR needs 2 wait states before an MFMA may read it, and the hazard recognizer does not look into inline asm.
+// (Found by tools/fuzz_rollout.py: cart-pole / pendulum at HID = 256 with two row tiles read a stale ring slot.)  The two
+// cycles hide behind the SIMD's other wave: measured neutral.
 template <bool ASM>
 __device__ __forceinline__ void xmfma_ring(floatx4& acc, const uintx4& w, const f16x8& x) {
-    if constexpr (ASM) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+    if constexpr (ASM) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
     else acc = xmfma(w, x, acc);
 }
 // Hazard padding the compiler cannot place for asm MFMAs.  The accumulators are "+v" operands of the padding statement,
@@ -721,10 +729,8 @@ int xdl_launch_noise(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, h
     if (per_member < 1) per_member = 1;
     args.wgs_per_member = tiles < per_member ? tiles : per_member;
     args.rows_per_member = rows_per_member;
-    size_t lds = (size_t)G::CTRL + (size_t)rup(G::MT * 16 * a.H * 4, 16);
-    const size_t bias_b = (size_t)(a.NH * G::NT + G::NTO) * 1024;
+    const size_t lds = G::lds_bytes(a.H, a.NH);
     args.bias_lds = G::BIAS_LDS;
-    if (G::BIAS_LDS) lds += bias_b;
     if (lds > 160 * 1024) {
         cadm_set_error("rollout: horizon %d with %d hidden layers needs %zu B of LDS (> 160 KiB)", a.H, a.NH, lds);
         return CADM_EINVAL;
@@ -760,6 +766,8 @@ int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a0, int rows_per_member, hipStr
     a.tile_count = tiles;
     int flavour = tiles >= 2 * per_member ? 2 : 1;
     if (const char* ev = getenv("CADM_XDL_MT")) flavour = ev[0] == '2' ? -2 : -1;        // developer override: one launch, forced flavour
+    // (wide layers / long horizons: two tiles' activation buffers do not fit the 160 KiB of LDS -- one tile per workgroup then)
+    if (XC<ENV, C, HID, 2>::lds_bytes(a0.H, a0.NH) > 160 * 1024) flavour = flavour < 0 ? -1 : 1;
     if (flavour == 1 || flavour == -1) return xdl_launch_mt<XC<ENV, C, HID, 1>>(ctx, a, rows_per_member, s);
     if (flavour == -2) return xdl_launch_mt<XC<ENV, C, HID, 2>>(ctx, a, rows_per_member, s);
     const int full = (tiles / (2 * per_member)) * 2 * per_member;         // tiles in full rounds of pairs

@@ -122,6 +122,12 @@ def test_resident_fragments_never_leave_agprs():
                         break
                     m3 = re.match(r"s_nop (\d+)", y)
                     waits += int(m3.group(1)) + 1 if m3 else 1
+            # every asm MFMA carries its own 2 wait states ("s_nop 1" in the asm statement): whatever VALU instruction hipcc puts
+            # in front of it (v_accvgpr_read of a parked operand, a zeroing v_mov), the MFMA never reads a VGPR too early
+            for i, x in enumerate(ins):
+                if x.startswith("v_mfma_f32_16x16x32_f16"):
+                    assert ins[i - 1].startswith("s_nop") and int(ins[i - 1].split()[1]) >= 1, \
+                        "%s: MFMA without wait states in front: %s / %s" % (sym, ins[i - 1].split("//")[0], x.split("//")[0])
             res = [x for x in ins if x.startswith("v_mfma_f32_16x16x32_f16") and re.search(r", a\[\d+:\d+\], v\[", x)]
             assert len(res) > 10, "%s: no MFMA reads its A operand from AGPRs -- residency is off" % sym
             checked += 1
