@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised check of the fused training step against the oracle (developer tool; needs a GPU):
+python tools/fuzz_train.py [seconds] [seed]
+
+Every round draws a random configuration (env kind, context encoder and its widths, backward model, deterministic /
+probabilistic, ensemble size, ragged batch size, hidden width incl. widths the planner is not compiled for, history length) and
+checks (i) the forward losses [mse, back_mse, recon] against the fp64 oracle, (ii) every gradient tensor of the hand-written
+backward pass -- exposed as (w_before - w_after) by one linearised Adam step -- against torch.autograd on the oracle, and
+that variables without a gradient do not move.  Same bars as tests/test_gpu_train.py."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+from cadm_amd import synth
+from oracle import train as otrain
+
+ENVS = ["halfcheetah", "cripple_halfcheetah", "ant", "slim_humanoid", "pendulum", "cartpole"]
+WD = (0.000025, 0.00005, 0.000075, 0.000075, 0.0001)
+
+
+def main():
+    t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    rounds, worst_l, worst_g = 0, 0.0, 0.0
+    while time.time() < t_end:
+        env = ENVS[rng.integers(len(ENVS))]
+        context = bool(rng.integers(2))
+        with_back = bool(context and rng.integers(2))
+        det = bool(rng.integers(3) == 0)
+        E, B = int(rng.choice([1, 2, 3, 5])), int(rng.integers(1, 300))
+        hid = int(rng.choice([64, 96, 128, 200, 256]))
+        ncp = int(rng.integers(1, 4))
+        cph = tuple(int(rng.choice([8, 24, 64, 130])) for _ in range(ncp))
+        Hh = int(rng.integers(1, 6))
+        prob = synth.make_problem(env=env, context=context, E=E, trained_like=True, with_back=with_back, hidden_sizes=(hid,) * 4,
+                                  cp_hidden_sizes=cph, Hh=Hh, seed=int(rng.integers(1 << 30)))
+        cwd = tuple(0.00003 * (i + 1) for i in range(ncp + 1))
+        cfg = dict(deterministic=det, back_coeff=0.5 if with_back else 0.0, weight_decay_coeff=1.0, weight_decays=WD,
+                   context_weight_decays=cwd, n_hidden=4, n_cp_hidden=ncp)
+        tag = "%s ctx=%d back=%d det=%d E=%d B=%d hid=%d cp=%s Hh=%d" % (env, context, with_back, det, E, B, hid, cph, Hh)
+        batch = synth.make_train_batch(prob, B=B, seed=int(rng.integers(1 << 30)))
+        keys = ["obs", "act", "delta"] + (["obs_next", "back_delta"] if with_back else []) + (["cp_obs", "cp_act"] if context else [])
+        nets64 = lambda rg: (otrain.to_torch(prob["ff"], torch.float64, rg),
+                             otrain.to_torch(prob["back"], torch.float64, rg) if with_back else None,
+                             otrain.to_torch(prob["cp"], torch.float64, rg) if context else None)
+        st = otrain.to_torch(prob["stats"], torch.float64)
+        tb = {k: torch.tensor(v, dtype=torch.float64) for k, v in batch.items()}
+        # (i) forward losses
+        eng = synth.make_engine(prob, p=E, deterministic=det)
+        eng.train_configure(1e-3, WD, cwd, 1.0, cfg["back_coeff"], max_batch=B)
+        got = eng.train_step({k: eng._t(batch[k]) for k in keys}, train=False).cpu().numpy()
+        ff, back, cp = nets64(False)
+        ref = otrain.train_losses(env, ff, back, cp, st, tb, cfg)
+        want = np.array([float(ref["mse"]), float(ref["back_mse"]), float(ref["recon"])])
+        el = float(np.max(np.abs(got - want) / (np.abs(want) + 1.0)))
+        assert el <= 1e-4, "%s: losses %r vs %r" % (tag, got, want)
+        worst_l = max(worst_l, el)
+        eng.close()
+        # (ii) gradients through one linearised Adam step
+        eng = synth.make_engine(prob, p=E, deterministic=det)
+        eng.train_configure(1e6, WD, cwd, 1.0, cfg["back_coeff"], max_batch=B, beta1=0.0, beta2=0.0, epsilon=1e6)
+        before = {n: {k: v.clone() for k, v in eng.nets[n].items()} for n in eng.net_names()}
+        eng.train_step({k: eng._t(batch[k]) for k in keys}, train=True)
+        ff, back, cp = nets64(True)
+        out = otrain.train_losses(env, ff, back, cp, st, tb, cfg)
+        grads = otrain.grads_of(out["loss"], {"ff_model": ff, "backward_model": back, "context_model": cp})
+        for net in eng.net_names():
+            for name, w0 in before[net].items():
+                g_ref = grads[net][name]
+                g_hip = (w0 - eng.nets[net][name]).cpu().numpy().astype(np.float64)
+                if g_ref is None:
+                    assert np.abs(g_hip).max() == 0.0, "%s: %s/%s moved although it has no gradient" % (tag, net, name)
+                    continue
+                g_ref = g_ref.numpy()
+                err = float(np.abs(g_hip - g_ref).max() / max(np.abs(g_ref).max(), 1e-12))
+                assert err < 2e-3, "%s: %s/%s gradient off: %.3e" % (tag, net, name, err)
+                worst_g = max(worst_g, err)
+        eng.close()
+        rounds += 1
+    print("train fuzz OK: %d random configurations; worst loss deviation %.2e, worst gradient deviation %.2e of the tensor's scale"
+          % (rounds, worst_l, worst_g))
+
+
+if __name__ == "__main__":
+    main()
