@@ -758,7 +758,6 @@ struct LossP {
     const float *delta, *back_delta;         // raw targets [E*B, D] (or through map)
     const float *dmean, *dstd, *bdmean, *bdstd, *maxlv, *minlv;
     float *dMu, *dLv, *dBmu;                 // d loss / d head pre-activation
-    float *terms;                            // [7][E*B*D]: mse, mu_loss, var_loss, back_mse, g_maxlv, g_minlv, (unused)
     long n;                                  // E*B*D
     int D, B, det, has_back;
     float back_coeff;
@@ -766,108 +765,140 @@ struct LossP {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-__global__ void loss_kernel(const LossP p) {
-    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-    if (i >= p.n) return;
-    const int d = (int)(i % p.D);
-    long srow, swin;
-    map_row(p.map, i / p.D, srow, swin);
-    const long si = srow * p.D + d;                            // this element in the caller's target tensors
-    const float s = 1.0f / ((float)p.B * (float)p.D);         // reduce_mean over b then d; reduce_sum over e
-    const float t = (p.delta[si] - p.dmean[d]) / (p.dstd[d] + 1e-10f);
-    const float mu = p.mu[i];
-    const float diff = mu - t;
-    p.terms[0 * p.n + i] = diff * diff * s;                                   // mse            (:273-274)
-    if (p.det) {
-        p.dMu[i] = 2.0f * s * diff;
-        p.dLv[i] = 0.0f;
-        p.terms[1 * p.n + i] = 0.0f; p.terms[2 * p.n + i] = 0.0f; p.terms[4 * p.n + i] = 0.0f; p.terms[5 * p.n + i] = 0.0f;
-    } else {
-        const float mx = p.maxlv[d], mn = p.minlv[d], lv0 = p.lv[i];
-        const float u = mx - tf_softplus(mx - lv0);                           // core/utils.py:356
-        const float lvc = mn + tf_softplus(u - mn);                           // core/utils.py:357
-        const float invvar = expf(-lvc);                                      // :303
-        p.terms[1 * p.n + i] = diff * diff * invvar * s;                      // mu_loss        (:304-305)
-        p.terms[2 * p.n + i] = lvc * s;                                       // var_loss       (:306-307)
-        const float g_lvc = s * (1.0f - diff * diff * invvar);
-        const float s1 = sigmoidf_(u - mn), s2 = sigmoidf_(mx - lv0);         // softplus' = sigmoid
-        p.dMu[i] = 2.0f * s * diff * invvar;
-        p.dLv[i] = g_lvc * s1 * s2;
-        p.terms[4 * p.n + i] = g_lvc * s1 * (1.0f - s2);                      // d / d max_logvar (without the 0.01 reg)
-        p.terms[5 * p.n + i] = g_lvc * (1.0f - s1);                           // d / d min_logvar
-    }
-    if (p.has_back) {
-        const float tb = (p.back_delta[si] - p.bdmean[d]) / (p.bdstd[d] + 1e-10f);
-        const float db = p.bmu[i] - tb;
-        p.terms[3 * p.n + i] = db * db * s;                                   // back_mse       (:280-281)
-        p.dBmu[i] = p.back_coeff * 2.0f * s * db;
-    } else {
-        p.terms[3 * p.n + i] = 0.0f;
-    }
-}
-
-// Deterministic reductions, one workgroup per output: block q < 4 sums terms[q] over everything; blocks 4 + d and
-// 4 + D + d sum the max / min logvar gradient terms over rows for dim d.  out: [4 + 2D].  The workgroup that
-// finishes last turns the sums into losses_out = [mse, back_mse, recon] (dynamics.py:505-507: recon = loss - reg -
-// coeff * l2) and, when training a probabilistic model, applies Adam to max/min_logvar (data term + the 0.01
-// regulariser of dynamics.py:308) -- nothing else reads them until the next step's loss kernel.
+// Deterministic reductions of the loss terms.  out: [4 + 2D] = {mse, mu_loss, var_loss, back_mse, d/d max_logvar [D],
+// d/d min_logvar [D]}.  The workgroup that finishes last turns the sums into losses_out = [mse, back_mse, recon]
+// (dynamics.py:505-507: recon = loss - reg - coeff * l2) and, when training a probabilistic model, applies Adam to
+// max/min_logvar (data term + the 0.01 regulariser of dynamics.py:308) -- nothing else reads them until the next step.
 struct ReduceP {
-    const float* terms; long n; int D; float* out; unsigned* counter;
+    float* part;                                   // [workgroups][4 + 2D] per-workgroup partial sums
+    int D; float* out; unsigned* counter;
     int det, has_back; float back_coeff; float* losses_out;
     int adam_mm;                                   // 1: update max/min_logvar
     float *maxlv, *minlv, *mx_m, *mx_v, *mn_m, *mn_v;
     float lr_t, b1, b2, eps;
 };
 
-__global__ __launch_bounds__(1024) void reduce_finalize_kernel(const ReduceP p) {
-    __shared__ float sh[1024];
+__device__ __forceinline__ float wave_sum_fixed(float v) {            // xor butterfly: the same order on every run
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// One launch for the losses, the head gradients and every reduction over them (was: a loss kernel that wrote 6 term
+// arrays + a reduction kernel that read them back).  A workgroup takes LR_THREADS consecutive elements of [E*B, D],
+// reduces its six terms in LDS in a fixed order (4 scalar sums; per-dim sums of the two logvar-bound gradients) and
+// writes 4 + 2D partials; the last workgroup to arrive sums the partials (again in a fixed order: no float atomics,
+// the result does not depend on which workgroup is last) and finalises.
+constexpr int LR_THREADS = 1024;
+
+__global__ __launch_bounds__(LR_THREADS) void loss_reduce_kernel(const LossP p, const ReduceP r) {
+    __shared__ float sh[6][LR_THREADS];
+    __shared__ float wsum[LR_THREADS / 64][64];
     __shared__ bool is_last;
-    const int q = blockIdx.x, tid = threadIdx.x;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;      // independent chains: 4 loads in flight per thread
-    if (q < 4) {
-        const float* src = p.terms + q * p.n;
-        long i = tid;
-        for (; i + 3072 < p.n; i += 4096) { a0 += src[i]; a1 += src[i + 1024]; a2 += src[i + 2048]; a3 += src[i + 3072]; }
-        for (; i < p.n; i += 1024) a0 += src[i];
-    } else {
-        const int which = (q - 4) / p.D, d = (q - 4) % p.D;
-        const float* src = p.terms + (4 + which) * p.n + d;
-        const long rows = p.n / p.D;
-        long r = tid;
-        for (; r + 3072 < rows; r += 4096) { a0 += src[r * p.D]; a1 += src[(r + 1024) * p.D]; a2 += src[(r + 2048) * p.D]; a3 += src[(r + 3072) * p.D]; }
-        for (; r < rows; r += 1024) a0 += src[r * p.D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned i0 = blockIdx.x * (unsigned)LR_THREADS;          // (host: n < 2^31 -- 32-bit div / mod)
+    const unsigned i = i0 + tid;
+    float tm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (i < (unsigned)p.n) {
+        const int d = (int)(i % (unsigned)p.D);
+        long srow, swin;
+        map_row(p.map, (long)(i / (unsigned)p.D), srow, swin);
+        const long si = srow * p.D + d;                            // this element in the caller's target tensors
+        const float s = 1.0f / ((float)p.B * (float)p.D);         // reduce_mean over b then d; reduce_sum over e
+        const float t = (p.delta[si] - p.dmean[d]) / (p.dstd[d] + 1e-10f);
+        const float mu = p.mu[i];
+        const float diff = mu - t;
+        tm[0] = diff * diff * s;                                                  // mse            (:273-274)
+        if (p.det) {
+            p.dMu[i] = 2.0f * s * diff;
+            p.dLv[i] = 0.0f;
+        } else {
+            const float mx = p.maxlv[d], mn = p.minlv[d], lv0 = p.lv[i];
+            const float u = mx - tf_softplus(mx - lv0);                           // core/utils.py:356
+            const float lvc = mn + tf_softplus(u - mn);                           // core/utils.py:357
+            const float invvar = expf(-lvc);                                      // :303
+            tm[1] = diff * diff * invvar * s;                                     // mu_loss        (:304-305)
+            tm[2] = lvc * s;                                                      // var_loss       (:306-307)
+            const float g_lvc = s * (1.0f - diff * diff * invvar);
+            const float s1 = sigmoidf_(u - mn), s2 = sigmoidf_(mx - lv0);         // softplus' = sigmoid
+            p.dMu[i] = 2.0f * s * diff * invvar;
+            p.dLv[i] = g_lvc * s1 * s2;
+            tm[4] = g_lvc * s1 * (1.0f - s2);                                     // d / d max_logvar (without the 0.01 reg)
+            tm[5] = g_lvc * (1.0f - s1);                                          // d / d min_logvar
+        }
+        if (p.has_back) {
+            const float tb = (p.back_delta[si] - p.bdmean[d]) / (p.bdstd[d] + 1e-10f);
+            const float db = p.bmu[i] - tb;
+            tm[3] = db * db * s;                                                  // back_mse       (:280-281)
+            p.dBmu[i] = p.back_coeff * 2.0f * s * db;
+        }
     }
-    sh[tid] = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) sh[q][tid] = tm[q];
     __syncthreads();
-    for (int s = 512; s > 0; s >>= 1) {
-        if (tid < s) sh[tid] += sh[tid + s];
-        __syncthreads();
+    const int NQ = 4 + 2 * r.D;
+    float* part = r.part + (size_t)blockIdx.x * NQ;
+    if (wave < 4) {                                                // scalar terms: wave q sums sh[q][*]
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LR_THREADS / 64; ++k) v += sh[wave][lane + 64 * k];
+        v = wave_sum_fixed(v);
+        if (lane == 0) part[wave] = v;
+    } else {                                                       // per-dim terms: 16 lanes per (bound, dim)
+        const int sub = tid & 15, j00 = (int)(i0 % (unsigned)r.D);
+        for (int o = (tid - 256) >> 4; o < 2 * r.D; o += (LR_THREADS - 256) >> 4) {     // (uniform per 16-lane group)
+            const int which = o / r.D, d = o % r.D;
+            float v = 0.0f;
+            for (int j = (d - j00 + r.D) % r.D + sub * r.D; j < LR_THREADS; j += 16 * r.D) v += sh[4 + which][j];
+#pragma unroll
+            for (int x = 8; x > 0; x >>= 1) v += __shfl_xor(v, x, 64);
+            if (sub == 0) part[4 + o] = v;
+        }
     }
+    __syncthreads();                                              // (every wave's partials have left for L2)
     if (tid == 0) {
-        p.out[q] = sh[0];
-        __threadfence();
-        is_last = atomicInc(p.counter, gridDim.x - 1) == gridDim.x - 1;     // wraps back to 0 for the next step
+        __threadfence();                                          // one agent-scope release per workgroup
+        is_last = atomicInc(r.counter, gridDim.x - 1) == gridDim.x - 1;     // wraps back to 0 for the next step
+        if (is_last) __threadfence();
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
-    const volatile float* red = p.out;
+    // sum of the partials: lane = output (64 at a time), the waves take interleaved workgroups, wave partials meet in LDS
+    const volatile float* all = r.part;
+    volatile float* red = r.out;
+    const int W = (int)gridDim.x;
+    for (int q0 = 0; q0 < NQ; q0 += 64) {
+        const int q = q0 + lane;
+        float v = 0.0f;
+        if (q < NQ)
+            for (int w = wave; w < W; w += LR_THREADS / 64) v += all[(size_t)w * NQ + q];
+        wsum[wave][lane] = v;
+        __syncthreads();
+        if (wave == 0 && q < NQ) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int k = 0; k < LR_THREADS / 64; ++k) tot += wsum[k][lane];
+            red[q] = tot;
+        }
+        __syncthreads();
+    }
+    __threadfence_block();
     if (tid == 0) {
         const float mse = red[0], mu_loss = red[1], var_loss = red[2], back = red[3];
-        float recon = p.det ? mse : mu_loss + var_loss;
-        if (p.has_back) recon += p.back_coeff * back;
-        p.losses_out[0] = mse;
-        p.losses_out[1] = p.has_back ? back : 0.0f;
-        p.losses_out[2] = recon;
+        float recon = r.det ? mse : mu_loss + var_loss;
+        if (r.has_back) recon += r.back_coeff * back;
+        r.losses_out[0] = mse;
+        r.losses_out[1] = r.has_back ? back : 0.0f;
+        r.losses_out[2] = recon;
     }
-    if (p.adam_mm && tid < 2 * p.D) {
-        const bool mx = tid < p.D;
-        const int d = mx ? tid : tid - p.D;
-        float* w = (mx ? p.maxlv : p.minlv) + d;
-        float* m = (mx ? p.mx_m : p.mn_m) + d;
-        float* v = (mx ? p.mx_v : p.mn_v) + d;
+    if (r.adam_mm && tid < 2 * r.D) {
+        const bool mx = tid < r.D;
+        const int d = mx ? tid : tid - r.D;
+        float* w = (mx ? r.maxlv : r.minlv) + d;
+        float* m = (mx ? r.mx_m : r.mn_m) + d;
+        float* v = (mx ? r.mx_v : r.mn_v) + d;
         float ww = *w, mm = *m, vv = *v;
-        adam_update(ww, mm, vv, red[4 + tid] + (mx ? 0.01f : -0.01f), p.lr_t, p.b1, p.b2, p.eps);
+        adam_update(ww, mm, vv, red[4 + tid] + (mx ? 0.01f : -0.01f), r.lr_t, r.b1, r.b2, r.eps);
         *w = ww; *m = mm; *v = vv;
     }
 }
@@ -969,7 +1000,7 @@ static int ensure_workspace(cadm_ctx* ctx, int B) {
     }
     const size_t omu = need(R * D), olv = need(R * D), obmu = need(R * D), oblv = need(R * D);
     const size_t odMu = need(R * D), odLv = need(R * D), odBmu = need(R * D);
-    const size_t oterms = need(7 * R * D), ored = need(4 + 2 * (size_t)D + 8);
+    const size_t oterms = need(((R * D + LR_THREADS - 1) / LR_THREADS) * (4 + 2 * (size_t)D)), ored = need(4 + 2 * (size_t)D + 8);
     CADM_CHECK_HIP(hipMalloc(&t->ws, total * sizeof(float)));
     t->ws_floats = total;
     float* w = t->ws;
@@ -1252,21 +1283,21 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     lp.mu = t->ff.mu; lp.lv = t->ff.lv; lp.bmu = t->bk.mu; lp.delta = delta; lp.back_delta = back_delta;
     lp.dmean = ctx->st.delta_mean; lp.dstd = ctx->st.delta_std; lp.bdmean = ctx->st.back_delta_mean; lp.bdstd = ctx->st.back_delta_std;
     lp.maxlv = ctx->ff_maxlv; lp.minlv = ctx->ff_minlv;
-    lp.dMu = t->dMu; lp.dLv = t->dLv; lp.dBmu = t->dBmu; lp.terms = t->terms;
+    lp.dMu = t->dMu; lp.dLv = t->dLv; lp.dBmu = t->dBmu;
     lp.n = R * D; lp.D = D; lp.B = B; lp.det = det; lp.has_back = has_back; lp.back_coeff = hp.back_coeff;
-    hipLaunchKernelGGL(loss_kernel, dim3((unsigned)((lp.n + 255) / 256)), dim3(256), 0, s, lp);
     // lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t)  (TF1 Adam)
     if (train) t->step += 1;
     const float lr_t = (float)(hp.learning_rate * sqrt(1.0 - pow((double)hp.beta2, (double)t->step)) /
                                (1.0 - pow((double)hp.beta1, (double)t->step)));
     ReduceP rp{};
-    rp.terms = t->terms; rp.n = lp.n; rp.D = D; rp.out = t->red; rp.counter = reinterpret_cast<unsigned*>(t->red + 4 + 2 * D);
+    rp.part = t->terms; rp.D = D; rp.out = t->red; rp.counter = reinterpret_cast<unsigned*>(t->red + 4 + 2 * D);
     rp.det = det; rp.has_back = has_back; rp.back_coeff = hp.back_coeff; rp.losses_out = losses_out;
     rp.adam_mm = train && !det;
     rp.maxlv = ctx->ff_maxlv; rp.minlv = ctx->ff_minlv;
     rp.mx_m = t->a_mx.m; rp.mx_v = t->a_mx.v; rp.mn_m = t->a_mn.m; rp.mn_v = t->a_mn.v;
     rp.lr_t = lr_t; rp.b1 = hp.beta1; rp.b2 = hp.beta2; rp.eps = hp.epsilon;
-    hipLaunchKernelGGL(reduce_finalize_kernel, dim3(4 + 2 * D), dim3(1024), 0, s, rp);
+    CADM_REQUIRE(lp.n < (1L << 31), "cadm_train_step: E*B*D too large");
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3((unsigned)((lp.n + LR_THREADS - 1) / LR_THREADS)), dim3(LR_THREADS), 0, s, lp, rp);
     CADM_CHECK_HIP(hipGetLastError());
     if (!train) return CADM_OK;
 
