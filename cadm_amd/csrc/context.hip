@@ -18,16 +18,20 @@ struct CpArgs {
     float* out;
 };
 
-__global__ __launch_bounds__(256) void context_kernel(const CpArgs a) {
+// 16 waves per (member, env): a layer is a latency chain of weight rows (one workgroup reads the member's whole 430 KB),
+// so the K dimension is cut 16 ways -- every wave has all of its (at most 15) rows in flight at once.
+#define CP_THREADS 1024
+#define CP_KQ (CP_THREADS / 64)
+__global__ __launch_bounds__(CP_THREADS) void context_kernel(const CpArgs a) {
     __shared__ float xa[CP_MAX_WIDTH];
     __shared__ float xb[CP_MAX_WIDTH];
-    __shared__ float red[4][256];
+    __shared__ float red[CP_KQ][256];
     const int e = blockIdx.x / a.m, mi = blockIdx.x % a.m;
     const int tid = threadIdx.x;
     const size_t in_row = a.bs ? ((size_t)e * a.m + mi) : (size_t)mi;   // tile(.., [E,1,1]) unless already [E,m,.]
-    for (int i = tid; i < a.n_obs; i += 256)
+    for (int i = tid; i < a.n_obs; i += CP_THREADS)
         xa[i] = (a.cp_obs[in_row * a.n_obs + i] - a.obs_mean[i]) / (a.obs_std[i] + 1e-10f);          // :403
-    for (int i = tid; i < a.n_act; i += 256)
+    for (int i = tid; i < a.n_act; i += CP_THREADS)
         xa[a.n_obs + i] = (a.cp_act[in_row * a.n_act + i] - a.act_mean[i]) / (a.act_std[i] + 1e-10f);  // :404
     __syncthreads();
     float* xin = xa;
@@ -37,39 +41,38 @@ __global__ __launch_bounds__(256) void context_kernel(const CpArgs a) {
         const float* W = a.W[l] + (size_t)e * K * N;
         const float* b = a.b[l] + (size_t)e * N;
         // thread (kq = tid >> 6, lane = tid & 63): 4 consecutive columns per lane (float4 weight loads when
-        // N % 4 == 0), K split in 4 contiguous quarters across the waves, partials reduced through LDS.
-        const int kq = tid >> 6, lane = tid & 63;
-        const int k0 = (K * kq) / 4, k1 = (K * (kq + 1)) / 4;
+        // N % 4 == 0), K split in CP_KQ contiguous parts across the waves, partials reduced through LDS in a fixed order.
+        const int kq = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (uniform: row addresses stay in SGPRs)
+        const int k0 = (K * kq) / CP_KQ, k1 = (K * (kq + 1)) / CP_KQ;
         const bool vec = (N & 3) == 0;
         for (int nb = 0; nb < N; nb += 256) {
             const int n = nb + lane * 4;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             if (n < N) {
                 if (vec) {
-                    int k = k0;
-                    for (; k + 8 <= k1; k += 8) {
-                        floatx4 w[8];
+                    // 16 rows in flight per pass; rows past k1 are re-reads of the last row weighted by 0 (loads stay
+                    // unconditional, so they are issued together)
+                    for (int k = k0; k < k1; k += 16) {
+                        floatx4 w[16];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const floatx4*>(W + (size_t)(k + u) * N + n);
+                        for (int u = 0; u < 16; ++u) {
+                            const int kk = k + u < k1 ? k + u : k1 - 1;
+                            w[u] = *reinterpret_cast<const floatx4*>(W + (size_t)kk * N + n);
+                        }
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const float xv = xin[k + u];
+                        for (int u = 0; u < 16; ++u) {
+                            const float xv = k + u < k1 ? xin[k + u] : 0.0f;
 #pragma unroll
                             for (int c = 0; c < 4; ++c) acc[c] = fmaf(xv, w[u][c], acc[c]);
                         }
                     }
-                    for (; k < k1; ++k) {
-                        const floatx4 w = *reinterpret_cast<const floatx4*>(W + (size_t)k * N + n);
-                        const float xv = xin[k];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) acc[c] = fmaf(xv, w[c], acc[c]);
-                    }
                 } else {
+                    // (columns past N read the last column: unconditional loads; their sums are never consumed)
+#pragma unroll 4
                     for (int k = k0; k < k1; ++k) {
                         const float xv = xin[k];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (n + c < N) acc[c] = fmaf(xv, W[(size_t)k * N + n + c], acc[c]);
+                        for (int c = 0; c < 4; ++c) acc[c] = fmaf(xv, W[(size_t)k * N + (n + c < N ? n + c : N - 1)], acc[c]);
                     }
                 }
             }
@@ -78,8 +81,11 @@ __global__ __launch_bounds__(256) void context_kernel(const CpArgs a) {
             __syncthreads();
             {
                 const int nn = nb + tid;
-                if (nn < N) {
-                    float v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid] + b[nn];
+                if (tid < 256 && nn < N) {
+                    float v = red[0][tid];
+#pragma unroll
+                    for (int q = 1; q < CP_KQ; ++q) v += red[q][tid];
+                    v += b[nn];
                     if (l + 1 < a.nlayers) v = fmaxf(v, 0.0f);   // ReLU hidden (layers.py:34), identity output
                     xout[nn] = v;
                 }
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256) void context_kernel(const CpArgs a) {
         float* t = xin; xin = xout; xout = t;
     }
     const int C = a.dims[a.nlayers];
-    for (int i = tid; i < C; i += 256) a.out[((size_t)e * a.m + mi) * C + i] = xin[i];
+    for (int i = tid; i < C; i += CP_THREADS) a.out[((size_t)e * a.m + mi) * C + i] = xin[i];
 }
 
 int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs, float* out,
@@ -117,7 +123,7 @@ int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act,
     a.n_obs = ctx->D * ctx->cfg.history_length;
     a.n_act = ctx->A * ctx->cfg.history_length;
     a.m = m; a.bs = bs; a.E = ctx->E; a.out = out;
-    hipLaunchKernelGGL(context_kernel, dim3(ctx->E * m), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(context_kernel, dim3(ctx->E * m), dim3(CP_THREADS), 0, s, a);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
 }
