@@ -37,6 +37,21 @@ def test_context_encoder(gpu, env, m):
     np.testing.assert_array_equal(got_bs, got)
 
 
+@pytest.mark.parametrize("env,Hh,cp_sizes,C", [
+    ("pendulum", 1, (8, 6), 3),              # input width 4 < 16 K-slices: most waves of the workgroup have no rows
+    ("halfcheetah", 3, (320, 100, 30), 10),  # a layer wider than one 256-column pass; widths that are not multiples of 4
+    ("ant", 2, (64,), 7),                    # one hidden layer, odd output width
+])
+def test_context_encoder_shapes(gpu, env, Hh, cp_sizes, C):
+    prob = synth.make_problem(env=env, m=2, trained_like=True, seed=5, Hh=Hh, cp_hidden_sizes=cp_sizes, C=C)
+    eng = make_engine(prob, p=5)
+    got = _np(eng.context_forward(prob["cp_obs"], prob["cp_act"]))
+    o32 = oracle_problem(prob, np.float32)
+    ref = onets.context_forward(o32["cp"], o32["cp_obs"], o32["cp_act"], o32["st"])
+    assert got.shape == (prob["E"], 2, C)
+    assert_close(got, ref, RTOL, "context encoder vs fp32 oracle")
+
+
 CASES = [  # env, context, E, p, m, n, deterministic
     ("halfcheetah", True, 5, 20, 1, 12, False),
     ("halfcheetah", True, 5, 10, 3, 7, False),      # ragged: rows/member = 42 (tail tile), m > 1
