@@ -536,6 +536,25 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
             for (int t = fg; t < H; t += 16) ctrl_s[arow * H + t] = ctrl_term<ENV>(a.actions + abase + t * A, A);
         }
         float ret = 0.0f;
+        auto gen_noise = [&](int t) {
+#pragma unroll
+            for (int pi = 0; pi < NPI; ++pi) {
+                const int dp = fg + 16 * pi;
+                if (dp >= NP) continue;                   // (wave-uniform for whole waves of unused pair slots)
+                float2 z;
+                if constexpr (NOISE == CADM_NOISE_INJECT) {
+                    const float* epp = a.eps + ((size_t)t * a.m * a.n_local * a.p + lr) * D + 2 * dp;
+                    z.x = epp[0];
+                    z.y = (2 * dp + 1 < D) ? epp[1] : 0.0f;
+                } else {
+                    uint32_t pc[4] = {grow, (uint32_t)t, (uint32_t)dp, CADM_STREAM_EPS | ((uint32_t)a.it << 8)};
+                    uint32_t pk[2] = {a.seed, a.call};
+                    philox_rounds<0, 10>(pc, pk);
+                    box_muller(u01(pc[0]), u01(pc[1]), z.x, z.y);
+                }
+                zb[((t & 1) * NPI + pi) * 256 + fg * 16 + arow] = z;
+            }
+        };
         __syncthreads();
         TS_DECL
 
@@ -612,28 +631,12 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
             }
             }
             if (t == H) break;
-            // Gaussian-head noise of THIS step (consumed by the next state phase): made by the twin thread in waves 4-7,
-            // which have nothing else to do while waves 0-3 update the state
-            if constexpr (NOISE != CADM_NOISE_NONE) {
-                if (MT > 1 || !feat) {
-#pragma unroll
-                    for (int pi = 0; pi < NPI; ++pi) {
-                        const int dp = fg + 16 * pi;
-                        if (dp >= NP) continue;                   // (wave-uniform for whole waves of unused pair slots)
-                        float2 z;
-                        if constexpr (NOISE == CADM_NOISE_INJECT) {
-                            const float* epp = a.eps + ((size_t)t * a.m * a.n_local * a.p + lr) * D + 2 * dp;
-                            z.x = epp[0];
-                            z.y = (2 * dp + 1 < D) ? epp[1] : 0.0f;
-                        } else {
-                            uint32_t pc[4] = {grow, (uint32_t)t, (uint32_t)dp, CADM_STREAM_EPS | ((uint32_t)a.it << 8)};
-                            uint32_t pk[2] = {a.seed, a.call};
-                            philox_rounds<0, 10>(pc, pk);
-                            box_muller(u01(pc[0]), u01(pc[1]), z.x, z.y);
-                        }
-                        zb[((t & 1) * NPI + pi) * 256 + fg * 16 + arow] = z;
-                    }
-                }
+            // Gaussian-head noise of THIS step (consumed by the next state phase, through the double-buffered zb).
+            // One row tile: made here by the twin thread in waves 4-7, which have nothing else to do while waves 0-3 update
+            // the state.  Two row tiles: every thread owns state and makes its own noise, but not here, where it would
+            // lengthen the state phase that everything waits for -- see the hidden layers / the head below.
+            if constexpr (NOISE != CADM_NOISE_NONE && MT == 1) {
+                if (!feat) gen_noise(t);
             }
             TS(0)
             __syncthreads();
@@ -661,6 +664,11 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                     const int nx = next_streamed(l);
                     xdl_sweep<G, NTW, NCH, NRES, GSZ, !SEQ>(ring, resH + RBASE, rsrc, lay_off(l), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
                                                  hidden_epi(l, act_out) TS_ARGS);
+                    // two row tiles: the waves that have a head tile (and one hidden tile less than the others: they would
+                    // wait at this barrier anyway) make their noise now
+                    if constexpr (NOISE != CADM_NOISE_NONE && MT > 1) {
+                        if (l == 1 && nhead) gen_noise(t);
+                    }
                     if (l == 1) { TS(4) } else if (l == 2) { TS(8) } else { TS(9) }
                     __syncthreads();
                     TS(5)
@@ -671,6 +679,10 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                 if (3 < a.NH) hidden(3, std::integral_constant<int, Q3>{}, std::integral_constant<int, Q1 + Q2>{});
                 for (int l = 4; l < a.NH; ++l) hidden(l, IC0{}, IC0{});
                 act_in = act_out;
+                // two row tiles: the waves without a head tile make their noise while the others run the head
+                if constexpr (NOISE != CADM_NOISE_NONE && MT > 1) {
+                    if (!nhead || a.NH < 2) gen_noise(t);
+                }
                 // ================= output head tile (mu | logvar of 8 dims) =================
                 if (nhead) {
                     const int nx = next_streamed(a.NH);
