@@ -3,20 +3,30 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is ONE get_action on BASELINE.json's configs[1] (halfcheetah PE-TS+CaDM, ens=5, part=20, cand=200 per GPU,
-H=30, m=1): context encoder + 5 CEM iterations x (sample, 30-step fused rollout of cand*part rows, refit).  Inputs
-(obs, history, weights, init mean/var) are resident in HBM before the timed region.  Metric: row-steps/s =
-m*n*p*H*5 / wall(get_action) (a row = one (candidate, particle) pair evaluated by exactly one member).
-N > 1 is weak scaling of the headline (200 candidates per GPU, one RCCL all-gather of per-candidate returns per CEM
-iteration, issued from inside libcadm_hip.so); the JSON line also carries `legs`: the same protocol on the other
-BASELINE configs -- among them `cfg5`, north_star's 8-GPU point (1000 candidates per GPU; at N = 1 it is the per-GPU
-share, the comparator of the ">= 6x at 8 GPUs" claim) -- and on the reference's launch shape m = 10.
+A "step" is ONE `MLPEnsembleCEMDynamicsModel.get_action` on BASELINE.json's configs[1] (halfcheetah PE-TS+CaDM, ens=5,
+part=20, cand=200 per GPU, H=30, m=1): context encoder + 5 CEM iterations x (sample, 30-step fused rollout of cand*part rows,
+refit).  Metric: row-steps/s = m*n*p*H*5 / wall_time(get_action), a row = one (candidate, particle) pair
+evaluated by exactly one member.
+
+`value` is timed THROUGH THE CLASS API the reference exposes (numpy in -> numpy out, the samplers' warm-start shift between
+calls, cadm/samplers/sampler.py:109-120), i.e. it includes the staging copy of the five tiny inputs and the return of the plan;
+`device_resident` is the same planner driven with inputs already in HBM (`cadm_cem_plan` only) -- the two differ by the
+per-call host overhead (`api_overhead_us`).  N > 1 is weak scaling of the headline (200 candidates per GPU, one RCCL all-gather
+of per-candidate returns per CEM iteration, issued from inside libcadm_hip.so); `legs` repeat the device-resident protocol on
+the other BASELINE configs -- among them `cfg5`, north_star's 8-GPU point (1000 candidates per GPU) -- and on m = 10.
+
+`roofline`: the dominant kernel (`rollout_xdl_kernel`) computes fp32 results on the f16 matrix pipe (3 f16 MFMA products of
+2-way split operands per fp32 product).  `achieved` = algorithmic fp32-equivalent FLOPs (268 000 per row-step x
+row-steps per launch) / launch time measured with hipEvents on the launch stream inside the library; `peak` = that pipe's ceiling
+for this arithmetic, 2500 TFLOP/s dense f16 / 3 products = 833 TFLOP/s; `pipe_frac` = f16 MFMA FLOPs actually issued (incl. tile
+padding) / 2500.  `mfma_busy` and `traffic` come from the committed rocprofv3 PMC passes of this command (profiles/).
 """
 import argparse
 import json
 import os
 import sys
 import time
+from collections import OrderedDict
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -24,8 +34,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"; SURVEY.md 8d's denominator
-F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide, dense f16/bf16 MFMA
+F16_MFMA_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: dense f16 / bf16 MFMA
+FP32_MFMA_PEAK_TFLOPS = 157.3   # same guide, "Peak FP32 (matrix)": what v_mfma_f32_*_f32 could reach (reported for context only)
+PMC_FILE = "r3_pmc_%s.json"     # profiles/: mean counters per rollout dispatch from separate rocprofv3 --pmc passes of this command
 
 
 def flops_per_row_step(K0, hid, D, n_hidden):
@@ -34,8 +45,8 @@ def flops_per_row_step(K0, hid, D, n_hidden):
 
 
 def executed_mfma_flops_per_row_step(K0, hid, D, n_hidden):
-    """f16 MFMA FLOPs the xdl kernel issues per row-step: 16x16x32 blocks over the padded tiles, 3 split products each
-    (4 for widths > 256), rows padded to 16 being the caller's business (cadm_amd/csrc/xdl_geo.h)."""
+    """f16 MFMA FLOPs the kernel issues per row-step: 16x16x32 blocks over the padded tiles, 3 split products each
+    (4 for widths > 256) (cadm_amd/csrc/xdl_geo.h)."""
     nt, nto = -(-hid // 16), -(-D // 8)
     nc0, nch = -(-K0 // 32), -(-nt // 2)
     blocks = nt * nc0 + (n_hidden - 1) * nt * nch + nto * nch
@@ -43,8 +54,7 @@ def executed_mfma_flops_per_row_step(K0, hid, D, n_hidden):
 
 
 def usable_cores():
-    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota
-    (os.cpu_count() reports the host's cores, which oversubscribes a quota-limited container)."""
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -76,8 +86,8 @@ def _cpu_model():
 
 
 def cpu_baseline(prob, n, p, budget_s=15.0):
-    """Op-for-op torch-CPU restatement of the TF1.15 graph on this node's host cores (baseline only).
-    The ONLY place bench.py touches oracle/ (imported here, on rank 0 at N = 1)."""
+    """Op-for-op torch-CPU restatement of the TF1.15 graph on this node's host cores (baseline only).  This leg (rank 0 at
+    N = 1) is the ONLY place bench.py touches oracle/: the timing here, and `parity_block` below which uses it as the checker."""
     from oracle import torch_baseline as tb
     cores = min(usable_cores(), 64)   # [5,800,200] batched matmuls stop scaling long before 64 threads
     tp = tb.prepare(prob)
@@ -104,12 +114,30 @@ def cpu_baseline(prob, n, p, budget_s=15.0):
                                                                           single, torch.__version__))
 
 
-def train_step_bench(device, steps=100, warmup=10, B=256):
+def parity_block():
+    """Measured in THIS run (part of the cpu_baseline leg: the oracle is the checker): error of the production kernel against the
+    fp64 numpy oracle at cfg2's full size with trained-like weights, next to the fp32 numpy oracle's own error on the same inputs
+    (tests/precision.py; the asserting twin is tests/test_gpu_precision.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import precision
+    res = precision.measure({"xdl": precision.product_engine})
+    x, o = res["xdl"], res["fp32_oracle"]
+    return {"config": "cfg2 full size (4000 rows, one teacher-forced step each; 24 candidates x 20 particles x 30 steps), trained-like weights",
+            "reference": "fp64 numpy oracle", "tolerance_north_star": 1e-5,
+            "one_step_max_rel": x["one_step_obs"]["max_rel"], "one_step_pure_rel_big": x["one_step_obs"]["pure_rel_big"],
+            "one_step_vs_fp32_oracle_pure_rel_big": x["one_step_obs_vs_fp32_oracle"]["pure_rel_big"],
+            "traj30_rel_vs_fp64": x["traj_obs"]["max_rel"], "returns_rel_vs_fp64": x["returns"]["max_rel"],
+            "fp32_oracle_vs_fp64": {"one_step_max_rel": o["one_step_obs"]["max_rel"], "traj30_rel": o["traj_obs"]["max_rel"],
+                                    "returns_rel": o["returns"]["max_rel"]},
+            "metrics": "max_rel = max|d|/max|ref|; pure_rel_big = max elementwise |d|/|ref| over |ref| >= 0.25 rms (no floor)"}
+
+
+def train_step_bench(device, lib=None, steps=100, warmup=10, B=256):
     """Second leg of the path: one fused forward/backward/Adam step of the 5-member CaDM ensemble
     (+ backward model) on a device-resident [E, B, .] bootstrap batch.  Reported beside the headline, never as it."""
     from cadm_amd import synth
     prob = synth.make_problem(env="halfcheetah", context=True, E=5, with_back=True, seed=0)
-    eng = synth.make_engine(prob, p=20, device=device)
+    eng = synth.make_engine(prob, p=20, device=device, lib=lib)
     eng.train_configure(1e-3, (0.000025, 0.00005, 0.000075, 0.000075, 0.0001), (0.000025, 0.00005, 0.000075), 1.0, 0.5,
                         max_batch=B)
     batch = {k: eng._t(v) for k, v in synth.make_train_batch(prob, B=B, seed=1).items()}
@@ -129,56 +157,109 @@ def train_step_bench(device, steps=100, warmup=10, B=256):
 
 
 class Planner:
-    """One planner problem resident on this rank's GPU (+ the in-library RCCL communicator when world > 1)."""
+    """One planner problem on this rank's GPU, built through the DROP-IN CLASS (cadm_amd.dynamics) with synthetic weights and
+    statistics; candidate-sharded over the ranks of the default process group when world > 1 (in-library RCCL)."""
 
-    def __init__(self, cfg, m, n_per_gpu, world, rank, local_rank, dist):
+    def __init__(self, cfg, m, n_per_gpu, world, rank, local_rank, dist, lib=None):
         from cadm_amd import synth
-        self.cfg, self.m, self.world, self.dist = cfg, m, world, dist
+        from cadm_amd.dynamics.mlp_cadm_ensemble_cem_dynamics import MLPEnsembleCEMDynamicsModel as CaDM
+        from cadm_amd.dynamics.mlp_ensemble_cem_dynamics import MLPEnsembleCEMDynamicsModel as Vanilla
+        from cadm_amd.envs import make_env_spec
+        self.cfg, self.m, self.world, self.rank, self.dist = cfg, m, world, rank, dist
         self.n_per_gpu, self.n = n_per_gpu, n_per_gpu * world
         self.p, self.E, self.H = cfg["p"], cfg["E"], cfg["H"]
         self.prob = prob = synth.make_problem(env=cfg["env"], context=cfg["context"], E=self.E, m=m, H=self.H, seed=0)
-        self.eng = eng = synth.make_engine(prob, p=self.p, deterministic=cfg["deterministic"], device="cuda:%d" % local_rank)
+        kw = dict(hidden_sizes=prob["hidden_sizes"], hidden_nonlinearity="swish", n_forwards=self.H, n_candidates=self.n,
+                  ensemble_size=self.E, n_particles=self.p, use_cem=True, deterministic=cfg["deterministic"], normalize_input=True,
+                  device="cuda:%d" % local_rank, process_group=dist.group.WORLD if world > 1 else None)
+        if lib is not None:
+            kw["engine_lib"] = lib
+        if cfg["context"]:
+            self.model = CaDM("dyn_model", make_env_spec(cfg["env"]), cp_hidden_sizes=prob["cp_hidden_sizes"], context_out_dim=prob["C"],
+                              history_length=prob["Hh"], state_diff=1, **kw)
+        else:
+            self.model = Vanilla("dyn_model", make_env_spec(cfg["env"]), **kw)
+        self.eng = eng = self.model.engine
+        if prob["cp"] is not None:
+            eng.set_net("context_model", prob["cp"])
+        eng.set_net("ff_model", prob["ff"])
+        st = prob["stats"]
+        self.model.set_normalization(OrderedDict((k, (st[k + "_mean"], st[k + "_std"])) for k in ("obs", "delta", "act", "cp_obs", "cp_act", "back_delta")))
+        self.model._push_stats()
+        eng.set_stats(st)       # the synthetic statistics verbatim (state_diff would zero the history statistics)
         self.obs, self.cp_obs, self.cp_act = eng._t(prob["obs"]), eng._t(prob["cp_obs"]), eng._t(prob["cp_act"])
         self.init_mean, self.init_var = eng._t(prob["init_mean"]), eng._t(prob["init_var"])
         self.collective, self.rccl_nranks = "none", 1
-        if world > 1:
+
+    # ---- numpy in -> numpy out through the class (the reference's call, dynamics.py:344-367 / vanilla :191-207)
+    def api_call(self, prev_sol):
+        prob = self.prob
+        if self.cfg["context"]:
+            return self.model.get_action(prob["obs"], prob["cp_obs"], prob["cp_act"], prev_sol, prob["init_var"])
+        return self.model.get_action(prob["obs"], prev_sol, prob["init_var"])
+
+    def check_rccl(self):
+        if self.world > 1:
             # RCCL communicator inside libcadm_hip.so: one ncclAllGather per CEM iteration, all on-stream.  No fallback:
             # a SCALE run that silently used another path would not measure north_star's design -- fail loudly instead.
-            eng.dist_init()
-            self.rccl_nranks, rccl_rank = eng.dist_info()
-            if self.rccl_nranks != world or rccl_rank != rank:
+            self.rccl_nranks, rccl_rank = self.eng.dist_info()
+            if self.eng.dist_world != self.world or self.rccl_nranks != self.world or rccl_rank != self.rank:
                 raise RuntimeError("in-library RCCL communicator reports nranks=%d rank=%d, expected %d / %d"
-                                   % (self.rccl_nranks, rccl_rank, world, rank))
+                                   % (self.rccl_nranks, rccl_rank, self.world, self.rank))
             self.collective = "rccl all-gather in libcadm_hip.so"
-
-    def step(self, call):
-        return self.eng.cem_plan(self.obs, self.cp_obs, self.cp_act, self.init_mean, self.init_var, self.n, seed=0, call=call)
 
     def barrier(self):
         if self.dist is not None:
             self.dist.barrier()
         torch.cuda.synchronize(self.eng.device)
 
-    def run(self, steps, warmup):
-        """-> dict(elapsed [s, max over ranks], kern_ms, kern_launches)."""
+    def _max_over_ranks(self, elapsed):
+        if self.dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.eng.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def run_api(self, steps, warmup):
+        """K get_action calls through the class, warm start shifted between calls (sampler.py:118-120)."""
+        prev = self.prob["init_mean"].copy()
+        for _ in range(warmup):
+            plan = self.api_call(prev)
+        self.check_rccl()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            plan = self.api_call(prev)
+            prev[:, :-1] = plan[:, 1:]
+            prev[:, -1] = 0.0
+        self.barrier()
+        elapsed = self._max_over_ranks(time.perf_counter() - t0)
+        assert np.isfinite(plan).all() and np.abs(plan).max() <= 1.0
+        return elapsed
+
+    def run_device(self, steps, warmup):
+        """K planner calls on HBM-resident inputs (cadm_cem_plan only), the rollout launches and the all-gathers bracketed by
+        hipEvents on the launch stream inside the library.  -> dict(elapsed [s, max over ranks], kern_ms, kern_launches, ag_*)."""
         eng = self.eng
+        if self.world > 1 and eng.dist_world == 1:
+            eng.dist_init(self.dist.group.WORLD)
+        self.check_rccl()
+        step = lambda c: eng.cem_plan(self.obs, self.cp_obs if self.cfg["context"] else None, self.cp_act if self.cfg["context"] else None,
+                                      self.init_mean, self.init_var, self.n, seed=0, call=c)
         for w in range(warmup):
-            self.step(w)
+            step(w)
         eng.profile_enable(True)
         self.barrier()
         t0 = time.perf_counter()
         for k in range(steps):
-            plan = self.step(warmup + k)
+            plan = step(warmup + k)
         self.barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed = self._max_over_ranks(time.perf_counter() - t0)
         kern_ms, kern_launches = eng.profile_read()
+        ag_ms, ag_calls = eng.profile_read_collective()
         eng.profile_enable(False)
-        if self.dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            elapsed = float(t.item())
         assert torch.isfinite(plan).all()
-        return dict(elapsed=elapsed, kern_ms=kern_ms, kern_launches=kern_launches)
+        return dict(elapsed=elapsed, kern_ms=kern_ms, kern_launches=kern_launches, ag_ms=ag_ms, ag_calls=ag_calls)
 
     def summary(self, r, steps):
         row_steps = self.m * self.n * self.p * self.H * self.eng.num_cem_iters
@@ -190,7 +271,8 @@ class Planner:
         return dict(value=row_steps * steps / r["elapsed"], ms_per_get_action=r["elapsed"] / steps * 1e3,
                     kernel_avg_launch_ms=kavg * 1e3, launches=r["kern_launches"], row_steps_per_launch=rows_per_launch,
                     achieved_tflops=rows_per_launch * fl / kavg / 1e12, executed_f16_mfma_tflops=rows_per_launch * xfl / kavg / 1e12,
-                    flops_per_row_step=fl)
+                    flops_per_row_step=fl, row_steps_per_get_action=row_steps,
+                    allgather_us=(r["ag_ms"] * 1e3 / r["ag_calls"]) if r["ag_calls"] else None, allgather_calls=r["ag_calls"])
 
     def close(self):
         torch.cuda.synchronize(self.eng.device)
@@ -210,10 +292,12 @@ def main():
     ap.add_argument("--config", default="cfg2", help="headline workload: cfg2 (BASELINE metric) | cfg3 | cfg4 | cfg5 | m10")
     ap.add_argument("--cand-per-gpu", type=int, default=None)
     ap.add_argument("--legs", default=None, help="comma list of extra legs (default: cfg3,cfg4,cfg5,m10 at N=1; cfg5 at N>1; 'none')")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline leg (and the parity block measured inside it)")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no legs, no training-step leg, no cpu baseline / parity")
+    ap.add_argument("--lib", default=None, help="DEVELOPER: bind the run to another build of the library (tools/ab.sh); default = the product")
     args = ap.parse_args()
 
-    from cadm_amd import synth
+    from cadm_amd import _lib, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -225,75 +309,94 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    lib = _lib.load_dev(args.lib) if args.lib else None
 
     def make(name, cand=None):
         cfgname, m, n_per_gpu = LEGS[name] if name in LEGS else (name, 1, synth.CONFIGS[name]["n"])
-        return Planner(dict(synth.CONFIGS[cfgname]), m, cand or n_per_gpu, world, rank, local_rank, dist), cfgname, m
+        return Planner(dict(synth.CONFIGS[cfgname]), m, cand or n_per_gpu, world, rank, local_rank, dist, lib), cfgname, m
 
     head, cfgname, m = make(args.config, args.cand_per_gpu)
-    r = head.run(args.steps, args.warmup)
+    api_elapsed = head.run_api(args.steps, args.warmup)
+    r = head.run_device(args.steps, args.warmup)
     s = head.summary(r, args.steps)
     cfg = head.cfg
-    # HBM/fabric traffic of the dominant kernel: PMC counters cannot be read from inside this process; they come from
-    # separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of THIS command, committed under profiles/
-    # (KB per launch).  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide coalesced reads at half
-    # their bytes -> doubled.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r2_pmc_traffic_%s.json" % args.config)
+    api_ms = api_elapsed / args.steps * 1e3
+    api_value = s["row_steps_per_get_action"] * args.steps / api_elapsed
+
+    # counters of the dominant kernel: PMC counters cannot be read from inside this process; they come from separate
+    # `rocprofv3 --pmc` passes of THIS command (tools/profile_round.sh), committed under profiles/ as means per rollout dispatch.
+    # gfx950 (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide coalesced reads at half their bytes -> doubled; KB -> bytes.
+    traffic = mfma_busy = pmc_src = None
+    tpath = os.path.join(ROOT, "profiles", PMC_FILE % args.config)
     if world == 1 and args.cand_per_gpu is None and os.path.exists(tpath):
         raw = json.load(open(tpath))
-        traffic = (2.0 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"]) * 1024.0
+        pmc_src = "profiles/" + PMC_FILE % args.config
+        if "FETCH_SIZE" in raw and "WRITE_SIZE" in raw:
+            traffic = (2.0 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"]) * 1024.0
+        # SIMD-cycles the matrix pipe was busy / SIMD-cycles of the launch (tools/pmc_extract.py: SQ_VALU_MFMA_BUSY_CYCLES /
+        # (4 SIMDs x CUs x GRBM_GUI_ACTIVE))
+        mfma_busy = raw.get("mfma_busy_frac")
+    peak_equiv = F16_MFMA_PEAK_TFLOPS / 3.0
     out = {
         "metric": "CEM rollout row-steps/s (cand x part x horizon x 5 CEM iters per get_action; ens=%d members)" % cfg["E"],
-        "value": s["value"], "unit": "row-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": s["ms_per_get_action"], "get_action_latency_ms": s["ms_per_get_action"],
-        "plans_per_s": 1e3 / s["ms_per_get_action"], "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (each fp32 product as 3 f16 MFMA products of 2-way split operands, fp32 accumulate; "
-                                      "error <= 2^-22 per product, parity 1e-5 vs the fp32 oracle)",
+        "value": api_value, "unit": "row-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": api_ms, "get_action_latency_ms": api_ms, "plans_per_s": 1e3 / api_ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "value_note": "wall time of the drop-in class's get_action, numpy in -> numpy out, warm-start shift between calls (SURVEY.md 8d); "
+                      "`device_resident` = the same planner with inputs already in HBM",
+        "device_resident": {"value": s["value"], "unit": "row-steps/s", "device_ms_per_get_action": s["ms_per_get_action"]},
+        "api_overhead_us": (api_ms - s["ms_per_get_action"]) * 1e3,
+        "dtype": "f32 (each fp32 product as 3 f16 MFMA products of 2-way split operands, fp32 accumulate; error <= 2^-22 per product; "
+                 "measured parity: see `parity`)",
         "data": "synthetic",
         "config": {"workload": "%s: %s PE-TS+CaDM get_action, ens=%d part=%d cand=%d (%d/GPU) H=%d m=%d, random-init weights"
                                % (args.config, cfg["env"], cfg["E"], cfg["p"], head.n, head.n_per_gpu, cfg["H"], m),
                    "global_candidates": head.n, "parallelism": "candidate-shard x%d" % world, "collective": head.collective,
-                   "rccl_nranks": head.rccl_nranks},
-        "roofline": {"bound": "mfma", "achieved": s["achieved_tflops"], "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": s["achieved_tflops"] / FP32_MFMA_PEAK_TFLOPS,
-                     "peak_note": "fp32 matrix peak = the roofline of fp32 arithmetic on this part (SURVEY.md 8d); the kernel "
-                                  "computes the same fp32 result on the f16 matrix pipe (3 split products), so frac may exceed "
-                                  "what v_mfma_f32_16x16x4_f32 could ever reach",
+                   "rccl_nranks": head.rccl_nranks, "allgather_us": s["allgather_us"], "allgathers_timed": s["allgather_calls"]},
+        "roofline": {"bound": "mfma", "achieved": s["achieved_tflops"], "peak": peak_equiv, "unit": "TFLOP/s",
+                     "frac": s["achieved_tflops"] / peak_equiv,
+                     "peak_note": "fp32-equivalent ceiling of the pipe the kernel executes on: dense f16 MFMA peak 2500 TFLOP/s / 3 split "
+                                  "products per fp32 product (v_mfma_f32_16x16x32_f16); `achieved` counts the algorithmic fp32 FLOPs of SURVEY 8d",
                      "pipe": "v_mfma_f32_16x16x32_f16", "pipe_peak": F16_MFMA_PEAK_TFLOPS,
                      "pipe_executed": s["executed_f16_mfma_tflops"], "pipe_frac": s["executed_f16_mfma_tflops"] / F16_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic,
-                     "traffic_note": "bytes/launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/r2_pmc_traffic_%s.json (a separate "
-                                     "rocprofv3 --pmc pass of this command, NOT measured in this run)" % args.config,
+                     "mfma_busy": mfma_busy, "traffic": traffic, "pmc_source": pmc_src,
+                     "pmc_note": "mfma_busy (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of the launch) and traffic (bytes/launch = 2*FETCH_SIZE + "
+                                 "WRITE_SIZE) are read from the committed rocprofv3 --pmc passes of this command, NOT measured in this run",
+                     "fp32_matrix_peak_for_context": FP32_MFMA_PEAK_TFLOPS,
                      "kernel": "rollout_xdl_kernel", "avg_launch_ms": s["kernel_avg_launch_ms"], "launches": s["launches"],
-                     "launch_note": "one 'launch' = one rollout of all rows over the horizon, bracketed by hipEvents inside libcadm_hip.so "
-                                    "(a single kernel at cfg2; at >= 2 row tiles per workgroup slot the launcher issues a tile-pair kernel "
-                                    "plus a single-tile kernel for the remainder)",
+                     "launch_note": "one 'launch' = one rollout of all rows over the horizon, bracketed by hipEvents inside libcadm_hip.so on "
+                                    "the launch stream (a single kernel at cfg2; at >= 2 row tiles per workgroup slot the launcher issues a "
+                                    "tile-pair kernel plus a single-tile kernel for the remainder)",
                      "flops_per_row_step": s["flops_per_row_step"], "row_steps_per_launch": s["row_steps_per_launch"]},
     }
     prob_head, n_head, p_head = head.prob, head.n, head.p
     head.close()
 
-    # extra legs, same protocol (barrier + sync bracketed, max over ranks)
+    # extra legs, device-resident protocol (barrier + sync bracketed, max over ranks)
     legs = args.legs if args.legs is not None else ("cfg3,cfg4,cfg5,m10" if world == 1 else "cfg5")
+    if args.no_extras:
+        legs = "none"
     out["legs"] = {}
     for name in [x for x in legs.split(",") if x and x != "none" and x != args.config]:
         pl, lcfg, lm = make(name)
         lsteps = max(5, min(args.steps, 20))
-        ls = pl.summary(pl.run(lsteps, 2), lsteps)
+        ls = pl.summary(pl.run_device(lsteps, 2), lsteps)
         out["legs"][name] = {"workload": "%s env=%s m=%d cand=%d (%d/GPU)" % (lcfg, pl.cfg["env"], lm, pl.n, pl.n_per_gpu),
-                             "value": ls["value"], "unit": "row-steps/s", "ms_per_get_action": ls["ms_per_get_action"],
+                             "value": ls["value"], "unit": "row-steps/s", "protocol": "device-resident inputs",
+                             "ms_per_get_action": ls["ms_per_get_action"],
                              "kernel_avg_launch_ms": ls["kernel_avg_launch_ms"], "achieved_tflops": ls["achieved_tflops"],
-                             "frac_of_fp32_mfma_peak": ls["achieved_tflops"] / FP32_MFMA_PEAK_TFLOPS, "steps": lsteps,
-                             "collective": pl.collective, "rccl_nranks": pl.rccl_nranks}
+                             "roofline_frac": ls["achieved_tflops"] / peak_equiv,
+                             "pipe_frac": ls["executed_f16_mfma_tflops"] / F16_MFMA_PEAK_TFLOPS, "steps": lsteps,
+                             "collective": pl.collective, "rccl_nranks": pl.rccl_nranks, "allgather_us": ls["allgather_us"]}
         pl.close()
 
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(prob_head, n_head, p_head)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        if world == 1:
-            out["train_step"] = train_step_bench("cuda:%d" % local_rank)
+            out["parity"] = parity_block()
+        if world == 1 and not args.no_extras:
+            out["train_step"] = train_step_bench("cuda:%d" % local_rank, lib)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -9,10 +9,11 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CADM_HIP_LIB") or os.path.join(_HERE, "libcadm_hip.so")   # env override: developer builds (timing)
+LIB_PATH = os.path.join(_HERE, "libcadm_hip.so")              # the product; nothing in the environment redirects it
+DEV_LIB_PATH = os.path.join(_HERE, "libcadm_hip_dev.so")      # product objects + csrc/dev/ (comparison kernel, developer hooks)
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_HIDDEN_LAYERS = 8
 MAX_CP_LAYERS = 8
 
@@ -78,7 +79,7 @@ SIGNATURES = {
     "cadm_predict": (_i, [_P, _P, _P, _P, _P, _i, _P, _P, _P]),
     "cadm_profile_enable": (_i, [_P, _i]),
     "cadm_profile_read": (_i, [_P, C.POINTER(C.c_float), C.POINTER(_i)]),
-    "cadm_debug_set_timing_buffer": (_i, [_P, _P]),
+    "cadm_profile_read_collective": (_i, [_P, C.POINTER(C.c_float), C.POINTER(_i)]),
     "cadm_warm_start_shift": (_i, [_P, _P, _i, _P, _P, _P]),
     "cadm_history_update": (_i, [_P, _P, _P, _P, _P, _i, _i, _P, _P, _P, _P, _P]),
     "cadm_build_windows": (_i, [_P, _P, _P, _P, _i, _i, _i, _i, _i, _P, _P, _P, _i, _i, _P, _P, _P, _P, _P, _P, _P]),
@@ -88,7 +89,15 @@ SIGNATURES = {
     "cadm_dist_info": (_i, [_P, C.POINTER(_i), C.POINTER(_i)]),
 }
 
+# developer entry points (csrc/dev/dev_api.h): only in libcadm_hip_dev.so, typed by load_dev()
+DEV_SIGNATURES = {
+    "cadm_dev_set_rollout": (_i, [_P, _i, _i]),
+    "cadm_dev_set_timing_buffer": (_i, [_P, _P]),
+}
+DEV_ROLLOUT_XDL, DEV_ROLLOUT_F32 = 0, 1
+
 _lib = None
+_dev_libs = {}
 
 
 def build(verbose=False):
@@ -117,20 +126,42 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    _lib = _open(LIB_PATH, SIGNATURES)
+    return _lib
+
+
+def _open(path, signatures):
+    lib = C.CDLL(path)
+    for name, (res, args) in signatures.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
     if lib.cadm_abi_version() != ABI_VERSION:
-        raise CadmError("libcadm_hip.so ABI %d != binding ABI %d" % (lib.cadm_abi_version(), ABI_VERSION))
-    _lib = lib
+        raise CadmError("%s ABI %d != binding ABI %d" % (os.path.basename(path), lib.cadm_abi_version(), ABI_VERSION))
     return lib
 
 
-def check(rc, what=""):
+def load_dev(path=None):
+    """The DEVELOPER library (tests and tools/ only; no product module calls this): the product's objects plus the
+    fp32-MFMA comparison kernel and the hooks of csrc/dev/dev_api.h.  A separate dlopen handle -- an engine is bound
+    to it explicitly with HipEngine(..., lib=load_dev()); the product library and its engines are unaffected."""
+    path = os.path.abspath(path or DEV_LIB_PATH)
+    if path not in _dev_libs:
+        if not os.path.exists(path):
+            raise CadmError("%s is not built (make -C cadm_amd/csrc dev)" % path)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        sigs = dict(SIGNATURES)
+        sigs.update(DEV_SIGNATURES)
+        _dev_libs[path] = _open(path, sigs)
+    return _dev_libs[path]
+
+
+def check(rc, what="", lib=None):
     if rc != 0:
-        msg = load().cadm_last_error()
+        msg = (lib or load()).cadm_last_error()
         raise CadmError("%s failed (code %d): %s" % (what or "libcadm_hip call", rc,
                                                      msg.decode() if msg else "?"))
 

@@ -10,7 +10,7 @@ bookkeeping: `act(obs)` = one planner call + warm-start shift, `observe(...)` = 
 import numpy as np
 import torch
 
-from ._lib import check, ptr
+from ._lib import ptr
 
 
 class DevicePlannerState:
@@ -36,7 +36,7 @@ class DevicePlannerState:
         obs = eng._t(obs)
         plan = eng.cem_plan(obs, self.hist_obs if self.context else None, self.hist_act if self.context else None,
                             self.prev_sol, self.init_var, model.n_candidates, seed=model.seed, call=model._next_call())
-        check(eng.lib.cadm_warm_start_shift(eng._ctx, ptr(plan), self.m, ptr(self.prev_sol), ptr(self.action), eng.stream),
+        eng._check(eng.lib.cadm_warm_start_shift(eng._ctx, ptr(plan), self.m, ptr(self.prev_sol), ptr(self.action), eng.stream),
               "cadm_warm_start_shift")
         return self.action
 
@@ -48,7 +48,7 @@ class DevicePlannerState:
         obs, action, next_obs = eng._t(obs), eng._t(action), eng._t(next_obs)
         d = None if done is None else eng._t(np.asarray(done, dtype=np.int32) if not isinstance(done, torch.Tensor) else done,
                                              dtype=torch.int32)
-        check(eng.lib.cadm_history_update(eng._ctx, ptr(obs), ptr(next_obs), ptr(action), ptr(d), self.m,
+        eng._check(eng.lib.cadm_history_update(eng._ctx, ptr(obs), ptr(next_obs), ptr(action), ptr(d), self.m,
                                           int(bool(self.model.state_diff)), ptr(self.counts), ptr(self.hist_obs),
                                           ptr(self.hist_act), ptr(self.prev_sol), eng.stream), "cadm_history_update")
 

@@ -22,21 +22,6 @@ void cadm_set_error(const char* fmt, ...) {
 extern "C" const char* cadm_last_error(void) { return g_err; }
 extern "C" int cadm_abi_version(void) { return CADM_ABI_VERSION; }
 
-static LayerGeo make_geo(int K, int ntiles, int head, int nout) {
-    LayerGeo g;
-    g.K = K;
-    g.nch = (K + 15) / 16;
-    g.ntiles = ntiles;
-    g.nfo = ntiles / 4;
-    g.nso = ntiles % 4;
-    g.head = head;
-    g.nout = nout;
-    // head layers whose tiles are all K-split use the chunk-split stream (rollout.hip CSPLIT) when the
-    // producer layer has exactly one K-split tile as its last chunk (HID % 64 in (0,16], e.g. 200)
-    g.csplit = (head && g.nfo == 0 && g.nso > 0 && (g.nch % 4) == 1) ? 1 : 0;
-    return g;
-}
-
 extern "C" int cadm_ctx_create(const cadm_config* cfg, cadm_ctx** out) {
     CADM_REQUIRE(cfg && out, "cadm_ctx_create: null argument");
     CADM_REQUIRE(cfg->abi_version == CADM_ABI_VERSION, "cadm_ctx_create: ABI version %d != %d", cfg->abi_version,
@@ -69,28 +54,18 @@ extern "C" int cadm_ctx_create(const cadm_config* cfg, cadm_ctx** out) {
     c->ff.resize(c->NH + 2);
     c->back.resize(c->NH + 2);
     c->cp.resize(cfg->n_cp_hidden + 1);
-    const int NT = (c->HID + 15) / 16;
-    c->g0 = make_geo(c->K0, NT, 0, c->HID);
-    c->gh = make_geo(c->HID, NT, 0, c->HID);
-    c->go = make_geo(c->HID, (c->D + 7) / 8, 1, c->D);
-    c->wstream_member_floats = c->g0.layer_floats() + (size_t)(c->NH - 1) * c->gh.layer_floats() + c->go.layer_floats();
-    c->bstream_member_floats = c->g0.bias_floats() + (size_t)(c->NH - 1) * c->gh.bias_floats() + c->go.bias_floats();
     c->xg = make_xdl_geo(c->K0, c->HID, c->D, c->NH);
     {
-        const char* sel = getenv("CADM_ROLLOUT");
-        c->use_xdl = !(sel && strcmp(sel, "f32") == 0);
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
     }
     hipError_t e4 = hipMalloc(&c->xw, (size_t)c->xg.member_frags() * CADM_XDL_FRAG_BYTES * c->E);
     hipError_t e5 = hipMalloc(&c->xb, (size_t)c->xg.bias_tiles() * 256 * sizeof(float) * c->E);
     hipError_t e6 = hipMalloc(&c->xflag, sizeof(int));
-    hipError_t e1 = hipMalloc(&c->wstream, c->wstream_member_floats * c->E * sizeof(float));
-    hipError_t e2 = hipMalloc(&c->bstream, c->bstream_member_floats * c->E * sizeof(float));
     const size_t nst = 2 * (size_t)c->P + 2 * c->A + 4 * (size_t)c->D + 2 * (size_t)(c->D + c->A) * cfg->history_length;
     hipError_t e3 = hipMalloc(&c->st.buf, nst * sizeof(float));
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess) {
-        const hipError_t bad = e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3 != hipSuccess ? e3 : e4 != hipSuccess ? e4 : e5 != hipSuccess ? e5 : e6;
+    if (e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess || e6 != hipSuccess) {
+        const hipError_t bad = e3 != hipSuccess ? e3 : e4 != hipSuccess ? e4 : e5 != hipSuccess ? e5 : e6;
         cadm_set_error("cadm_ctx_create: hipMalloc failed (%s)", hipGetErrorString(bad));
         cadm_ctx_destroy(c);
         return CADM_ENOMEM;
@@ -111,14 +86,14 @@ extern "C" int cadm_ctx_destroy(cadm_ctx* ctx) {
     if (!ctx) return CADM_OK;
     cadm_train_free(ctx);
     cadm_dist_destroy(ctx);
-    if (ctx->wstream) (void)hipFree(ctx->wstream);
-    if (ctx->bstream) (void)hipFree(ctx->bstream);
+    if (ctx->dev_free) ctx->dev_free(ctx);
     if (ctx->xw) (void)hipFree(ctx->xw);
     if (ctx->xb) (void)hipFree(ctx->xb);
     if (ctx->xflag) (void)hipFree(ctx->xflag);
     if (ctx->st.buf) (void)hipFree(ctx->st.buf);
     if (ctx->cp_scratch) (void)hipFree(ctx->cp_scratch);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->prof_ag) (void)hipEventDestroy(e);
     delete ctx;
     return CADM_OK;
 }
@@ -150,6 +125,21 @@ extern "C" int cadm_set_logvar_bounds(cadm_ctx* ctx, int net, float* max_logvar,
     return CADM_OK;
 }
 
+// (Re)pack the planner's weight stream from the registered master weights.
+int cadm_pack_streams(cadm_ctx* ctx, hipStream_t s) {
+    for (int l = 0; l < ctx->NH + 2; ++l) {
+        if (!ctx->ff[l].W || !ctx->ff[l].b) {
+            cadm_set_error("cadm_repack: ff_model layer %d has no registered weights", l);
+            return CADM_ESTATE;
+        }
+    }
+    int rc = cadm_pack_xdl(ctx, s);
+    if (rc) return rc;
+    if (ctx->dev_pack && (rc = ctx->dev_pack(ctx, s))) return rc;       // developer library only (common.h)
+    ctx->packed = true;
+    return CADM_OK;
+}
+
 extern "C" int cadm_repack(cadm_ctx* ctx, void* stream) {
     CADM_REQUIRE(ctx, "cadm_repack: null ctx");
     CADM_ON_DEVICE(ctx);
@@ -172,6 +162,35 @@ extern "C" int cadm_set_norm_stats(cadm_ctx* ctx, const float* const host_stats[
     }
     (void)stream;
     ctx->st.set = true;
+    return CADM_OK;
+}
+
+// next start/stop event pair of a profiling list (grown on demand)
+static int prof_pair(std::vector<hipEvent_t>& ev, size_t& used, hipEvent_t* e0, hipEvent_t* e1) {
+    if (used + 2 > ev.size()) {
+        hipEvent_t a, b;
+        CADM_CHECK_HIP(hipEventCreate(&a));
+        CADM_CHECK_HIP(hipEventCreate(&b));
+        ev.push_back(a);
+        ev.push_back(b);
+    }
+    *e0 = ev[used];
+    *e1 = ev[used + 1];
+    used += 2;
+    return CADM_OK;
+}
+
+static int prof_sum(std::vector<hipEvent_t>& ev, size_t& used, float* total_ms_out, int* launches_out) {
+    float tot = 0.0f;
+    for (size_t i = 0; i + 1 < used; i += 2) {
+        CADM_CHECK_HIP(hipEventSynchronize(ev[i + 1]));
+        float ms = 0.0f;
+        CADM_CHECK_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        tot += ms;
+    }
+    *total_ms_out = tot;
+    *launches_out = (int)(used / 2);
+    used = 0;
     return CADM_OK;
 }
 
@@ -207,16 +226,7 @@ extern "C" int cadm_rollout_returns(cadm_ctx* ctx, const float* obs, const float
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof) {
-        if (ctx->prof_used + 2 > ctx->prof_ev.size()) {
-            hipEvent_t a, b;
-            CADM_CHECK_HIP(hipEventCreate(&a));
-            CADM_CHECK_HIP(hipEventCreate(&b));
-            ctx->prof_ev.push_back(a);
-            ctx->prof_ev.push_back(b);
-        }
-        e0 = ctx->prof_ev[ctx->prof_used];
-        e1 = ctx->prof_ev[ctx->prof_used + 1];
-        ctx->prof_used += 2;
+        if ((rc = prof_pair(ctx->prof_ev, ctx->prof_used, &e0, &e1))) return rc;
         CADM_CHECK_HIP(hipEventRecord(e0, (hipStream_t)stream));
     }
     rc = cadm_launch_rollout(ctx, obs, obs_rows, ctx_vec, actions, eps, norm_actions, seed, call, it, cand_offset,
@@ -225,32 +235,35 @@ extern "C" int cadm_rollout_returns(cadm_ctx* ctx, const float* obs, const float
     return rc;
 }
 
-extern "C" int cadm_debug_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf) {
-    CADM_REQUIRE(ctx, "cadm_debug_set_timing_buffer: null ctx");
-    ctx->tbuf = (unsigned long long*)dev_u64_buf;
-    return CADM_OK;
-}
-
 extern "C" int cadm_profile_enable(cadm_ctx* ctx, int enable) {
     CADM_REQUIRE(ctx, "cadm_profile_enable: null ctx");
     ctx->prof = enable != 0;
     ctx->prof_used = 0;
+    ctx->prof_ag_used = 0;
     return CADM_OK;
 }
 
 extern "C" int cadm_profile_read(cadm_ctx* ctx, float* total_ms_out, int* launches_out) {
     CADM_REQUIRE(ctx && total_ms_out && launches_out, "cadm_profile_read: null argument");
-    float tot = 0.0f;
-    for (size_t i = 0; i + 1 < ctx->prof_used; i += 2) {
-        CADM_CHECK_HIP(hipEventSynchronize(ctx->prof_ev[i + 1]));
-        float ms = 0.0f;
-        CADM_CHECK_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
-        tot += ms;
+    return prof_sum(ctx->prof_ev, ctx->prof_used, total_ms_out, launches_out);
+}
+
+extern "C" int cadm_profile_read_collective(cadm_ctx* ctx, float* total_ms_out, int* calls_out) {
+    CADM_REQUIRE(ctx && total_ms_out && calls_out, "cadm_profile_read_collective: null argument");
+    return prof_sum(ctx->prof_ag, ctx->prof_ag_used, total_ms_out, calls_out);
+}
+
+// the path's one collective, bracketed by hipEvents when profiling is on
+static int allgather_timed(cadm_ctx* ctx, const float* send, float* recv, size_t count, hipStream_t s) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc;
+    if (ctx->prof) {
+        if ((rc = prof_pair(ctx->prof_ag, ctx->prof_ag_used, &e0, &e1))) return rc;
+        CADM_CHECK_HIP(hipEventRecord(e0, s));
     }
-    *total_ms_out = tot;
-    *launches_out = (int)(ctx->prof_used / 2);
-    ctx->prof_used = 0;
-    return CADM_OK;
+    rc = cadm_dist_allgather(ctx, send, recv, count, s);
+    if (ctx->prof && rc == CADM_OK) CADM_CHECK_HIP(hipEventRecord(e1, s));
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -310,7 +323,7 @@ extern "C" int cadm_cem_plan(cadm_ctx* ctx, const float* obs, const float* cp_ob
                                        call, it, off, n, m, nl, w.rows, nullptr, stream))) return rc;
         if (G > 1) {   // the one collective of the path: [m, n/G] per rank -> [G, m, n/G] everywhere
             if ((rc = cadm_particle_mean(ctx, w.rows, m, nl, w.cand, stream))) return rc;
-            if ((rc = cadm_dist_allgather(ctx, w.cand, w.gath, (size_t)m * nl, s))) return rc;
+            if ((rc = allgather_timed(ctx, w.cand, w.gath, (size_t)m * nl, s))) return rc;
             if ((rc = cadm_launch_refit(ctx, w.gath, nullptr, G, nl, w.actions, m, mean_in, var_in, w.mean, w.var, nullptr, plan, s))) return rc;
         } else {       // single rank: the particle mean is taken inside the refit kernel
             if ((rc = cadm_launch_refit(ctx, nullptr, w.rows, 1, nl, w.actions, m, mean_in, var_in, w.mean, w.var, nullptr, plan, s))) return rc;
@@ -346,7 +359,7 @@ extern "C" int cadm_rs_plan(cadm_ctx* ctx, const float* obs, const float* cp_obs
     if ((rc = cadm_particle_mean(ctx, w.rows, m, nl, w.cand, stream))) return rc;
     const float* cand = w.cand;
     if (G > 1) {
-        if ((rc = cadm_dist_allgather(ctx, w.cand, w.gath, (size_t)m * nl, s))) return rc;
+        if ((rc = allgather_timed(ctx, w.cand, w.gath, (size_t)m * nl, s))) return rc;
         cand = w.gath;
     }
     int32_t* best = (int32_t*)w.mean;  // scratch reuse: m ints

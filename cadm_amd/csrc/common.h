@@ -84,6 +84,7 @@ struct NormStats {  // device copies of the 12 stat vectors + derived
 };
 
 struct TrainState;  // train.hip
+struct RolloutArgs;  // rollout_args.h
 
 struct cadm_ctx {
     cadm_config cfg;
@@ -92,18 +93,23 @@ struct cadm_ctx {
     // master weights
     std::vector<DenseRef> ff, back, cp;   // ff/back: NH hidden + mu + logvar; cp: n_cp_hidden + out
     float *ff_maxlv = nullptr, *ff_minlv = nullptr, *back_maxlv = nullptr, *back_minlv = nullptr;
-    // planner streams (ff net only)
-    LayerGeo g0, gh, go;
-    float* wstream = nullptr;    // [E][ L0 | hidden x (NH-1) | OUT ] layer streams
-    float* bstream = nullptr;    // [E][ L0 | hidden x (NH-1) | OUT ] D-layout bias tiles
-    size_t wstream_member_floats = 0, bstream_member_floats = 0;
     bool packed = false;
-    // split-f16 ("xdl") planner stream (xdl_geo.h): the production rollout kernel
+    // planner weight stream (ff net only): split-f16 fragments of the rollout kernel (xdl_geo.h)
     XdlGeo xg;
     unsigned short* xw = nullptr;   // [E][member_frags] fragments of 2 KB
     float* xb = nullptr;            // [E][bias_tiles][64][4] D-layout bias tiles
     int* xflag = nullptr;           // device flag: a weight did not fit the f16 range
-    bool use_xdl = true;            // CADM_ROLLOUT=f32 selects the fp32-MFMA kernel (developer comparison)
+    // Developer hooks.  The product library never sets them (no entry point does, and it reads no environment variable);
+    // libcadm_hip_dev.so adds dev/dev_api.hip, whose cadm_dev_set_rollout installs the fp32-MFMA comparison kernel of
+    // round 1 (dev/rollout_f32.h) or forces a row-tile flavour of the production kernel.
+    int (*dev_rollout)(cadm_ctx*, const struct RolloutArgs&, int rows_per_member, hipStream_t) = nullptr;
+    int (*dev_pack)(cadm_ctx*, hipStream_t) = nullptr;
+    void (*dev_free)(cadm_ctx*) = nullptr;
+    int dev_force_mt = 0;           // 0: launcher's choice; 1 / 2: one launch with that many row tiles per workgroup
+    LayerGeo g0, gh, go;            // fp32 fragment stream of the comparison kernel (allocated and packed by dev_pack only)
+    float* wstream = nullptr;
+    float* bstream = nullptr;
+    size_t wstream_member_floats = 0, bstream_member_floats = 0;
     int n_cus = 256;
     std::unordered_set<const void*> attr_done;   // kernels whose dynamic-LDS attribute is set on THIS ctx's device
     NormStats st;
@@ -113,9 +119,11 @@ struct cadm_ctx {
     size_t cp_scratch_floats = 0;
     // optional hipEvent bracketing of the rollout launches (cadm_profile_*)
     bool prof = false;
-    std::vector<hipEvent_t> prof_ev;   // start/stop pairs
+    std::vector<hipEvent_t> prof_ev;   // start/stop pairs around the rollout launches
     size_t prof_used = 0;
-    unsigned long long* tbuf = nullptr;   // cadm_debug_set_timing_buffer
+    std::vector<hipEvent_t> prof_ag;   // start/stop pairs around the per-iteration ncclAllGather (sharded planner)
+    size_t prof_ag_used = 0;
+    unsigned long long* tbuf = nullptr;   // cadm_dev_set_timing_buffer (developer library only)
     // RCCL communicator for candidate-sharded planning (dist.hip)
     void* comm = nullptr;
     int nranks = 1, rank = 0;

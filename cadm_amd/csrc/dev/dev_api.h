@@ -1,0 +1,19 @@
+/* Developer C ABI of libcadm_hip_dev.so (= the product objects + dev/): NOT part of the product interface
+ * (include/cadm_hip.h) and absent from libcadm_hip.so. */
+#ifndef CADM_DEV_API_H
+#define CADM_DEV_API_H
+#include "../../../include/cadm_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+#define CADM_DEV_ROLLOUT_XDL 0   /* the production split-f16 kernel (rollout_xdl.h) */
+#define CADM_DEV_ROLLOUT_F32 1   /* round 1's fp32-MFMA kernel (dev/rollout_f32.h): comparison only */
+/* kind: which kernel cadm_rollout_returns / the planners launch on this ctx; row_tiles: 0 = launcher's choice,
+ * 1 / 2 = one launch of the production kernel with that many 16-row tiles per workgroup. */
+int cadm_dev_set_rollout(cadm_ctx* ctx, int kind, int row_tiles);
+/* device buffer of 8*24 uint64 that the CADM_PHASE_TIMING build (make timing) fills with per-phase s_memtime sums of workgroup 0 */
+int cadm_dev_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,66 @@
+// Developer entry points, linked ONLY into libcadm_hip_dev.so (never into the product libcadm_hip.so):
+//   * the fp32-MFMA rollout kernel of round 1 (dev/rollout_f32.h) as a comparison kernel for the production split-f16 kernel
+//     (tests/test_gpu_precision.py, tools/xdl_vs_f32.py, tools/fuzz_rollout.py),
+//   * a forced row-tile flavour of the production kernel (tests/test_gpu_rowtiles.py),
+//   * the phase-timing buffer of the CADM_PHASE_TIMING build (tools/phase_timing.py).
+// Selection is per ctx and explicit (these calls); nothing reads the environment.
+#include "../rollout_args.h"
+#include "dev_api.h"
+
+int cadm_dev_pack_f32(cadm_ctx* ctx, hipStream_t s);
+void cadm_dev_free_f32(cadm_ctx* ctx);
+int cadm_rollout_f32_env_halfcheetah(cadm_ctx*, const RolloutArgs&, int, hipStream_t);
+int cadm_rollout_f32_env_ant(cadm_ctx*, const RolloutArgs&, int, hipStream_t);
+int cadm_rollout_f32_env_slim_humanoid(cadm_ctx*, const RolloutArgs&, int, hipStream_t);
+int cadm_rollout_f32_env_cartpole(cadm_ctx*, const RolloutArgs&, int, hipStream_t);
+int cadm_rollout_f32_env_pendulum(cadm_ctx*, const RolloutArgs&, int, hipStream_t);
+
+static int rollout_f32(cadm_ctx* ctx, const RolloutArgs& a0, int rpm, hipStream_t s) {
+    RolloutArgs a = a0;
+    a.wstream = ctx->wstream;
+    a.bstream = ctx->bstream;
+    const size_t wbytes = ctx->wstream_member_floats * ctx->E * sizeof(float);
+    if (wbytes >= (1ull << 31)) {
+        cadm_set_error("fp32 comparison rollout: weight stream of %zu bytes exceeds the 2 GiB buffer-descriptor range", wbytes);
+        return CADM_EINVAL;
+    }
+    a.wbytes = (unsigned)wbytes;
+    a.wmember_b = (unsigned)(ctx->wstream_member_floats * sizeof(float));
+    a.w_l0_b = (unsigned)(ctx->g0.layer_floats() * sizeof(float));
+    a.w_lh_b = (unsigned)(ctx->gh.layer_floats() * sizeof(float));
+    a.w_lo_b = (unsigned)(ctx->go.layer_floats() * sizeof(float));
+    a.bmember = ctx->bstream_member_floats;
+    a.b_l0 = ctx->g0.bias_floats();
+    a.b_lh = ctx->gh.bias_floats();
+    switch (ctx->cfg.env_kind) {
+        case CADM_ENV_HALFCHEETAH: return cadm_rollout_f32_env_halfcheetah(ctx, a, rpm, s);
+        case CADM_ENV_ANT: return cadm_rollout_f32_env_ant(ctx, a, rpm, s);
+        case CADM_ENV_SLIM_HUMANOID: return cadm_rollout_f32_env_slim_humanoid(ctx, a, rpm, s);
+        case CADM_ENV_CARTPOLE: return cadm_rollout_f32_env_cartpole(ctx, a, rpm, s);
+        case CADM_ENV_PENDULUM: return cadm_rollout_f32_env_pendulum(ctx, a, rpm, s);
+    }
+    return CADM_EINVAL;
+}
+
+extern "C" int cadm_dev_set_rollout(cadm_ctx* ctx, int kind, int row_tiles) {
+    CADM_REQUIRE(ctx, "cadm_dev_set_rollout: null ctx");
+    CADM_REQUIRE(kind == CADM_DEV_ROLLOUT_XDL || kind == CADM_DEV_ROLLOUT_F32, "cadm_dev_set_rollout: unknown kind %d", kind);
+    CADM_REQUIRE(row_tiles >= 0 && row_tiles <= 2, "cadm_dev_set_rollout: row_tiles must be 0 (launcher's choice), 1 or 2");
+    ctx->dev_force_mt = row_tiles;
+    if (kind == CADM_DEV_ROLLOUT_F32) {
+        ctx->dev_rollout = rollout_f32;
+        ctx->dev_pack = cadm_dev_pack_f32;
+        ctx->dev_free = cadm_dev_free_f32;
+        ctx->packed = false;            // the fp32 stream is packed with the next repack / rollout
+    } else {
+        ctx->dev_rollout = nullptr;
+        ctx->dev_pack = nullptr;
+    }
+    return CADM_OK;
+}
+
+extern "C" int cadm_dev_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf) {
+    CADM_REQUIRE(ctx, "cadm_dev_set_timing_buffer: null ctx");
+    ctx->tbuf = (unsigned long long*)dev_u64_buf;
+    return CADM_OK;
+}

@@ -1,6 +1,6 @@
 // Packs the raw TF-layout weights W[E,in,out] (core/utils.py:636-641 of the reference) into the
 // planner's MFMA-fragment "weight streams" (layout in common.h / DESIGN.md).
-#include "common.h"
+#include "../common.h"
 
 // output unit of A-operand row i (= lane & 15) of output tile `tile`.
 //   hidden layers: D-layout lane (q,row) register r holds unit 16*tile + 4*r + q, and the MFMA puts
@@ -92,15 +92,43 @@ __global__ void pack_bias_kernel(const float* __restrict__ b, const float* __res
     }
 }
 
-int cadm_pack_streams(cadm_ctx* ctx, hipStream_t s) {
+// fp32 fragment stream of the comparison kernel: allocated on first use, (re)packed after the production stream
+// (installed as ctx->dev_pack by cadm_dev_set_rollout)
+static LayerGeo make_geo(int K, int ntiles, int head, int nout) {
+    LayerGeo g;
+    g.K = K;
+    g.nch = (K + 15) / 16;
+    g.ntiles = ntiles;
+    g.nfo = ntiles / 4;
+    g.nso = ntiles % 4;
+    g.head = head;
+    g.nout = nout;
+    // head layers whose tiles are all K-split use the chunk-split stream (rollout_f32.h CSPLIT) when the
+    // producer layer has exactly one K-split tile as its last chunk (HID % 64 in (0,16], e.g. 200)
+    g.csplit = (head && g.nfo == 0 && g.nso > 0 && (g.nch % 4) == 1) ? 1 : 0;
+    return g;
+}
+
+void cadm_dev_free_f32(cadm_ctx* ctx) {
+    if (ctx->wstream) (void)hipFree(ctx->wstream);
+    if (ctx->bstream) (void)hipFree(ctx->bstream);
+    ctx->wstream = ctx->bstream = nullptr;
+}
+
+int cadm_dev_pack_f32(cadm_ctx* ctx, hipStream_t s) {
     const int NH = ctx->NH, E = ctx->E;
-    for (int l = 0; l < NH + 2; ++l) {
-        if (!ctx->ff[l].W || !ctx->ff[l].b) {
-            cadm_set_error("cadm_repack: ff_model layer %d has no registered weights", l);
-            return CADM_ESTATE;
-        }
+    if (!ctx->wstream) {
+        const int NT = (ctx->HID + 15) / 16;
+        ctx->g0 = make_geo(ctx->K0, NT, 0, ctx->HID);
+        ctx->gh = make_geo(ctx->HID, NT, 0, ctx->HID);
+        ctx->go = make_geo(ctx->HID, (ctx->D + 7) / 8, 1, ctx->D);
+        ctx->wstream_member_floats = ctx->g0.layer_floats() + (size_t)(NH - 1) * ctx->gh.layer_floats() + ctx->go.layer_floats();
+        ctx->bstream_member_floats = ctx->g0.bias_floats() + (size_t)(NH - 1) * ctx->gh.bias_floats() + ctx->go.bias_floats();
+        CADM_CHECK_HIP(hipMalloc(&ctx->wstream, ctx->wstream_member_floats * E * sizeof(float)));
+        CADM_CHECK_HIP(hipMalloc(&ctx->bstream, ctx->bstream_member_floats * E * sizeof(float)));
     }
     size_t woff = 0, boff = 0;
+
     auto pack = [&](const LayerGeo& g, const DenseRef& a, const DenseRef* a2) {
         const size_t total = g.layer_floats() * E;
         const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -118,8 +146,5 @@ int cadm_pack_streams(cadm_ctx* ctx, hipStream_t s) {
     for (int l = 1; l < NH; ++l) pack(ctx->gh, ctx->ff[l], nullptr);
     pack(ctx->go, ctx->ff[NH], &ctx->ff[NH + 1]);
     CADM_CHECK_HIP(hipGetLastError());
-    const int rc = cadm_pack_xdl(ctx, s);
-    if (rc) return rc;
-    ctx->packed = true;
     return CADM_OK;
 }

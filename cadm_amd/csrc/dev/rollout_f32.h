@@ -1,4 +1,7 @@
 #pragma once
+// DEVELOPER COMPARISON KERNEL (round 1's fp32-MFMA rollout): linked only into libcadm_hip_dev.so, selected only through
+// cadm_dev_set_rollout (dev/dev_api.hip).  The product library has ONE rollout path, rollout_xdl.h.
+//
 // Fused trajectory-sampling rollout: ONE launch advances every (candidate, particle) row through
 // the whole horizon -- input assembly, the 6-matmul ensemble MLP, Gaussian head, state update and
 // reward accumulation (reference core/utils.py:431-472; SURVEY.md groups G3..G6).
@@ -19,10 +22,9 @@
 #include <type_traits>
 #include <utility>
 
-#include "common.h"
-#include "rollout_args.h"
-#include "rollout_env.h"
-#include "rollout_xdl.h"
+#include "../common.h"
+#include "../rollout_args.h"
+#include "../rollout_env.h"
 
 
 namespace {
@@ -692,40 +694,4 @@ int launch(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipStream_t
     return launch_noise<G, CADM_NOISE_PHILOX>(ctx, a, rows_per_member, s);
 }
 
-// Context widths compiled in: 0 (vanilla PE-TS) and 10 (the reference default `--context_out_dim`,
-// run_cadm_pets.py:135); override with  make CTXS="0 10 16"  (one more instantiation per env and hidden width each).
-#ifndef CADM_CTX_LIST
-#define CADM_CTX_LIST 0, 10
-#endif
-#define CADM_STR2(...) #__VA_ARGS__
-#define CADM_STR(...) CADM_STR2(__VA_ARGS__)
-template <int ENV, int HID, int... CS>
-int dispatch_ctx_list(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) {
-    int rc = CADM_EINVAL;
-    bool hit = false;
-    ((ctx->C == CS ? (hit = true, rc = ctx->use_xdl ? xdl_launch<ENV, CS, HID>(ctx, a, rpm, s) : launch<RC<ENV, CS, HID, 1>>(ctx, a, rpm, s), 0) : 0), ...);
-    if (!hit) cadm_set_error("rollout: context_out_dim %d not compiled in (built with CTXS = " CADM_STR(CADM_CTX_LIST) ")", ctx->C);
-    return rc;
-}
-template <int ENV, int HID>
-int dispatch_ctx(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) {
-    return dispatch_ctx_list<ENV, HID, CADM_CTX_LIST>(ctx, a, rpm, s);
-}
-
 }  // namespace
-
-// Hidden widths compiled in (all hidden layers equal).  200 is the reference default (`--hidden_size`,
-// run_cadm_pets.py:129); override with  make HIDS="128 200 256"  (each width is one more instantiation per env).
-#ifndef CADM_HID_LIST
-#define CADM_HID_LIST 200
-#endif
-template <int ENV, int... HIDS>
-int dispatch_hid(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) {
-    int rc = CADM_EINVAL;
-    bool hit = false;
-    ((ctx->HID == HIDS ? (hit = true, rc = dispatch_ctx<ENV, HIDS>(ctx, a, rpm, s), 0) : 0), ...);
-    if (!hit) cadm_set_error("rollout: hidden width %d not compiled in (built with HIDS = " CADM_STR(CADM_HID_LIST) ")", ctx->HID);
-    return rc;
-}
-#define CADM_ROLLOUT_ENV(NAME, ENV) \
-    int cadm_rollout_env_##NAME(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) { return dispatch_hid<ENV, CADM_HID_LIST>(ctx, a, rpm, s); }

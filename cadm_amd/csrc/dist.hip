@@ -73,6 +73,17 @@ extern "C" int cadm_dist_init(cadm_ctx* ctx, const char id[128], int nranks, int
     memcpy(blob.b, id, 128);
     void* comm = nullptr;
     if ((rc = check_nccl(g_rccl.init_rank(&comm, nranks, blob, rank), "ncclCommInitRank"))) return rc;
+    // the communicator RCCL built must be the one asked for (the id travels by value through ncclCommInitRank)
+    if (g_rccl.count && g_rccl.user_rank) {
+        int cnt = -1, ur = -1;
+        rc = check_nccl(g_rccl.count(comm, &cnt), "ncclCommCount");
+        if (!rc) rc = check_nccl(g_rccl.user_rank(comm, &ur), "ncclCommUserRank");
+        if (!rc && (cnt != nranks || ur != rank)) {
+            cadm_set_error("cadm_dist_init: RCCL communicator has %d ranks / rank %d, expected %d / %d", cnt, ur, nranks, rank);
+            rc = CADM_EINVAL;
+        }
+        if (rc) { g_rccl.destroy(comm); return rc; }
+    }
     ctx->comm = comm;
     ctx->nranks = nranks;
     ctx->rank = rank;

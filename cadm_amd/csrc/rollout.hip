@@ -1,5 +1,5 @@
 // Host launcher of the fused rollout kernel: fills the argument block and dispatches to the
-// per-env translation units (rollout_<env>.hip, all generated from rollout_impl.h).
+// per-env translation units (rollout_<env>.hip -> rollout_dispatch.h -> rollout_xdl.h).
 #include "rollout_args.h"
 
 int cadm_rollout_env_halfcheetah(cadm_ctx*, const RolloutArgs&, int, hipStream_t);
@@ -13,27 +13,17 @@ int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, 
                         uint32_t call, int it, int cand_offset, int n_global, int m, int n_local,
                         float* returns_rows, float* traj_out, hipStream_t s) {
     RolloutArgs a{};
-    a.wstream = ctx->wstream;
-    a.bstream = ctx->bstream;
-    const size_t wbytes = ctx->wstream_member_floats * ctx->E * sizeof(float);
-    if (wbytes >= (1ull << 31)) {
-        cadm_set_error("rollout: weight stream of %zu bytes exceeds the 2 GiB buffer-descriptor range", wbytes);
+    const size_t xbytes = (size_t)ctx->xg.member_frags() * CADM_XDL_FRAG_BYTES * ctx->E;
+    if (xbytes >= (1ull << 31)) {
+        cadm_set_error("rollout: weight stream of %zu bytes exceeds the 2 GiB buffer-descriptor range", xbytes);
         return CADM_EINVAL;
     }
-    a.wbytes = (unsigned)wbytes;
-    a.wmember_b = (unsigned)(ctx->wstream_member_floats * sizeof(float));
-    a.w_l0_b = (unsigned)(ctx->g0.layer_floats() * sizeof(float));
-    a.w_lh_b = (unsigned)(ctx->gh.layer_floats() * sizeof(float));
-    a.w_lo_b = (unsigned)(ctx->go.layer_floats() * sizeof(float));
     a.xw = ctx->xw;
-    a.xw_bytes = (unsigned)((size_t)ctx->xg.member_frags() * CADM_XDL_FRAG_BYTES * ctx->E);
+    a.xw_bytes = (unsigned)xbytes;
     a.xw_member_b = (unsigned)((size_t)ctx->xg.member_frags() * CADM_XDL_FRAG_BYTES);
     for (int w = 0, off = 0; w < CADM_XDL_WAVES; ++w) { a.xw_wave_b[w] = (unsigned)off; off += ctx->xg.wave_frags(w) * CADM_XDL_FRAG_BYTES; }
     a.xb = ctx->xb;
     a.xb_member = (size_t)ctx->xg.bias_tiles() * 256;
-    a.bmember = ctx->bstream_member_floats;
-    a.b_l0 = ctx->g0.bias_floats();
-    a.b_lh = ctx->gh.bias_floats();
     a.obs = obs; a.obs_rows = obs_rows; a.ctx_vec = ctx_vec; a.actions = actions; a.eps = eps;
     a.obs_mean = ctx->st.obs_mean; a.obs_std = ctx->st.obs_std;
     a.act_mean = ctx->st.act_mean; a.act_std = ctx->st.act_std;
@@ -51,6 +41,7 @@ int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, 
         return CADM_EINVAL;
     }
     const int rpm = m * n_local * a.PE;
+    if (ctx->dev_rollout) return ctx->dev_rollout(ctx, a, rpm, s);      // developer library only (common.h)
     switch (ctx->cfg.env_kind) {
         case CADM_ENV_HALFCHEETAH: return cadm_rollout_env_halfcheetah(ctx, a, rpm, s);
         case CADM_ENV_ANT: return cadm_rollout_env_ant(ctx, a, rpm, s);

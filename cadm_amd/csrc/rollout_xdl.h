@@ -424,7 +424,13 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         }
     }
     const int a0 = (fg - (NP & 15) + 16) & 15;                          // first action feature of this thread
+    // Non-finite inputs: the clamp below would turn a NaN / inf feature into a finite one, so the row would carry on with a
+    // plausible-looking return.  Every feature is folded into the thread's reward sum first (0 * v = NaN iff v is NaN or inf,
+    // else +-0): a row that ever saw a non-finite observation, action or context value returns NaN -- what the reference's
+    // matmuls do to it (core/utils.py:441-472).  tests/test_gpu_precision.py pins this.
+    float ret = 0.0f;
     auto put_x = [&](int off, float v) {                                // both split parts of one input feature
+        ret = fmaf(0.0f, v, ret);
         v = fminf(fmaxf(v, -65000.0f), 65000.0f);                       // f16 range (only diverged rows ever get here)
         _Float16 h1, h2;
         xsplit(v, h1, h2);
@@ -535,7 +541,6 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
             }
             for (int t = fg; t < H; t += 16) ctrl_s[arow * H + t] = ctrl_term<ENV>(a.actions + abase + t * A, A);
         }
-        float ret = 0.0f;
         auto gen_noise = [&](int t) {
 #pragma unroll
             for (int pi = 0; pi < NPI; ++pi) {
@@ -700,6 +705,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         float* ret_s = ofull;                      // (this row tile's head buffer, free between tiles)
         __syncthreads();
         if (feat) ret_s[arow * 16 + fg] = ret;
+        ret = 0.0f;
         __syncthreads();
         if (feat && fg == 0 && valid) {
             float r = 0.0f;
@@ -777,7 +783,7 @@ int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a0, int rows_per_member, hipStr
     a.tile0 = 0;
     a.tile_count = tiles;
     int flavour = tiles >= 2 * per_member ? 2 : 1;
-    if (const char* ev = getenv("CADM_XDL_MT")) flavour = ev[0] == '2' ? -2 : -1;        // developer override: one launch, forced flavour
+    if (ctx->dev_force_mt) flavour = ctx->dev_force_mt == 2 ? -2 : -1;       // developer library only (dev/dev_api.hip): one launch, forced flavour
     // (wide layers / long horizons: two tiles' activation buffers do not fit the 160 KiB of LDS -- one tile per workgroup then)
     if (XC<ENV, C, HID, 2>::lds_bytes(a0.H, a0.NH) > 160 * 1024) flavour = flavour < 0 ? -1 : 1;
     if (flavour == 1 || flavour == -1) return xdl_launch_mt<XC<ENV, C, HID, 1>>(ctx, a, rows_per_member, s);

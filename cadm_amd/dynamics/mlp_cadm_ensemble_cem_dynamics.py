@@ -14,7 +14,9 @@ Differences a caller can see (all opt-in except the first):
   * extra kwargs: `reference_quirks` (default True: reproduce the context-layout quirks Q1/Q2
     of core/utils.py:434-435), `seed` (device Philox key; the reference never seeds TF),
     `device`, `process_group` (OPT-IN: shard candidates over the ranks of that torch.distributed group; every
-    rank must then call get_action with the same observations -- None, the default, never shards);
+    rank must then call get_action with the same observations -- None, the default, never shards; the first
+    `check_replicated_calls` sharded calls verify that with one extra all-reduce, later calls run only the path's own
+    collectives);
   * `predict(obs, act, cp_obs, cp_act)` -- thin alias the north-star asks for: one-step mean
     prediction of every ensemble member (the reference has no public predict).
 """
@@ -136,6 +138,8 @@ class MLPEnsembleCEMDynamicsModel(object):
                  seed=0,
                  device=None,
                  process_group=None,
+                 check_replicated_calls=2,
+                 engine_lib=None,
                  ):
         self.env = env
         self.name = name
@@ -191,11 +195,13 @@ class MLPEnsembleCEMDynamicsModel(object):
         self.seed = int(seed)
         self._call = 0
         self._group = process_group
+        self._check_replicated_left = int(check_replicated_calls)   # sharded get_action calls that still verify replicated inputs
         self.engine = HipEngine(self.env_kind, ensemble_size, n_particles, obs_space_dims, self.action_space_dims,
                                 self.proc_obs_space_dims, context_out_dim, hidden_sizes, n_forwards,
                                 deterministic=deterministic, discrete=self.discrete,
                                 reference_quirks=reference_quirks, history_length=history_length,
-                                cp_hidden_sizes=cp_hidden_sizes, back_model=back_coeff > 0.0, device=device)
+                                cp_hidden_sizes=cp_hidden_sizes, back_model=back_coeff > 0.0, device=device,
+                                lib=engine_lib)      # engine_lib: developer builds only (tools/ab.sh); None = the product library
         # tf.global_variables_initializer() equivalent (mb_trainer.py:164)
         self.engine.init_weights(np.random.default_rng(self.seed))
         self._train_ready = False
@@ -265,12 +271,19 @@ class MLPEnsembleCEMDynamicsModel(object):
         shard, fused = self._sharding()
         if not any(isinstance(x, torch.Tensor) for x in (obs, cp_obs, cp_act, cem_init_mean, cem_init_var)):
             obs, cp_obs, cp_act, cem_init_mean, cem_init_var = self.engine.stage((obs, cp_obs, cp_act, cem_init_mean, cem_init_var))
-        if shard.world > 1:
+        if shard.world > 1 and self._check_replicated_left > 0:      # first calls only: two blocking collectives + a host sync
+            self._check_replicated_left -= 1
             _planner.check_replicated([self.engine._t(x) for x in (obs, cp_obs, cp_act, cem_init_mean) if x is not None], shard)
         if cem_init_mean is not None:
             if fused:
-                action = self.engine.cem_plan(obs, cp_obs, cp_act, cem_init_mean, cem_init_var, self.n_candidates,
-                                              seed=self.seed, call=call)
+                # the plan lands in a persistent pinned host buffer (written by the last refit kernel): one stream
+                # synchronisation instead of an allocation + D2H copy per call
+                eng = self.engine
+                host = eng.host_out((m, self.n_forwards, self.action_space_dims))
+                eng.cem_plan(obs, cp_obs, cp_act, cem_init_mean, cem_init_var, self.n_candidates, seed=self.seed, call=call, out=host)
+                torch.cuda.current_stream(eng.device).synchronize()
+                action = host.numpy().copy()
+                return action if self.discrete else np.minimum(np.maximum(action, -1.0), 1.0)
             else:
                 action = _planner.cem_plan(self.engine, obs, cp_obs, cp_act, cem_init_mean, cem_init_var,
                                            self.n_candidates, seed=self.seed, call=call, shard=shard)
@@ -317,10 +330,12 @@ class MLPEnsembleCEMDynamicsModel(object):
 
     def fit(self, obs, act, obs_next, cp_obs, cp_act, future_bool, epochs=1000, compute_normalization=True,
             valid_split_ratio=None, rolling_average_persitency=None, verbose=False, log_tabular=False,
-            max_logging=5000, rng=None, index_stream=None):
+            max_logging=5000, rng=None, index_stream=None, keep_trace=None):
         """reference :382-569.  `rng` (numpy Generator) replaces the reference's global np.random; `index_stream`
-        (see FitIndexStream) replaces the draws themselves.  `self.last_fit_trace` keeps the per-step training losses
-        and per-epoch validation losses [mse, back_mse, recon] of the call."""
+        (see FitIndexStream) replaces the draws themselves -- without one, the per-epoch shuffles are drawn ON THE DEVICE
+        (an [E, n_train] argsort per epoch is ~1 s of host time and an 80 MB copy at 2 M rows).  `self.last_fit_trace` keeps
+        the per-epoch validation losses and, with `keep_trace` (default: only when an index stream is injected), one
+        [steps, 3] array of training losses [mse, back_mse, recon] per epoch."""
         D, A, F, Hh = self.obs_space_dims, self.action_space_dims, self.future_length, self.history_length
         assert obs.ndim == 2 and obs.shape[1] == D * F
         assert obs_next.ndim == 2 and obs_next.shape[1] == D * F
@@ -333,8 +348,11 @@ class MLPEnsembleCEMDynamicsModel(object):
         if rolling_average_persitency is None:
             rolling_average_persitency = self.rolling_average_persitency
         assert 1 > valid_split_ratio >= 0
+        injected = index_stream is not None
         if index_stream is None:
             index_stream = FitIndexStream(rng if rng is not None else np.random.default_rng(self.seed + 7919 * (self._call + 1)))
+        if keep_trace is None:
+            keep_trace = injected
 
         obs = obs.reshape(-1, D)
         obs_next = obs_next.reshape(-1, D)
@@ -366,7 +384,8 @@ class MLPEnsembleCEMDynamicsModel(object):
         dev = self._upload_dataset(ds)
         train_rows = self._row_index(ds["future_bool"], perm[n_valid:])
         valid_rows = self._row_index(ds["future_bool"], perm[:n_valid]) if n_valid > 0 else None
-        return self._fit_loop(dev, train_rows, valid_rows, epochs, rolling_average_persitency, verbose, log_tabular, index_stream)
+        return self._fit_loop(dev, train_rows, valid_rows, epochs, rolling_average_persitency, verbose, log_tabular, index_stream,
+                              device_shuffle=not injected, keep_trace=keep_trace)
 
     _BATCH_KEYS = ("obs", "act", "delta", "obs_next", "back_delta", "cp_obs", "cp_act")
 
@@ -393,7 +412,8 @@ class MLPEnsembleCEMDynamicsModel(object):
         out["cp_act"] = dev["cp_act"][w]
         return out
 
-    def _fit_loop(self, dev, train_rows, valid_rows, epochs, persistency, verbose, log_tabular, stream):
+    def _fit_loop(self, dev, train_rows, valid_rows, epochs, persistency, verbose, log_tabular, stream,
+                  device_shuffle=False, keep_trace=True):
         """Epoch / batch loop (reference :460-569): bootstrap indices, shuffle_rows, one fused
         fwd/bwd/Adam step per batch, validation, rolling-average early stop."""
         self._ensure_train()
@@ -407,6 +427,10 @@ class MLPEnsembleCEMDynamicsModel(object):
             bootstrap_idx = np.tile(np.arange(n_train, dtype="int64"), (E, 1))  # :467
         didx = torch.as_tensor(bootstrap_idx.astype(np.int64), device=eng.device)
         trace = self.last_fit_trace = dict(train=[], valid=[])
+        gen = None
+        if device_shuffle:      # keyed by the host stream, so a seeded `rng` still fixes the whole fit
+            gen = torch.Generator(device=eng.device)
+            gen.manual_seed(int(stream.rng.integers(0, 2 ** 62)))
         dev_valid = None
         if valid_rows is not None and valid_rows[0].shape[0] > 0:
             vw = torch.as_tensor(valid_rows[0], device=eng.device)
@@ -416,9 +440,12 @@ class MLPEnsembleCEMDynamicsModel(object):
         epoch = -1
         for epoch in range(epochs):
             t0 = time.time()
-            # shuffle_rows (:472-474,483): independent permutation of every member's index row (argsort of uniforms);
-            # drawn on the host so that the whole index stream is injectable -- [E, n_train] int64 per epoch
-            order = torch.as_tensor(np.asarray(stream.epoch_order(E, n_train)).astype(np.int64), device=eng.device)
+            # shuffle_rows (:472-474,483): independent permutation of every member's index row (argsort of uniforms) --
+            # on the device by default; from the host stream when one is injected (parity tests replay the reference's draws)
+            if gen is not None:
+                order = torch.argsort(torch.rand((E, n_train), device=eng.device, generator=gen), dim=-1)
+            else:
+                order = torch.as_tensor(np.asarray(stream.epoch_order(E, n_train)).astype(np.int64), device=eng.device)
             didx = torch.gather(didx, 1, order)
             losses = []
             for b in range(int(np.ceil(n_train / self.batch_size))):
@@ -426,7 +453,8 @@ class MLPEnsembleCEMDynamicsModel(object):
                 # the step reads its rows through (row id -> window, offset) inside the kernels: no gathered batch
                 losses.append(eng.train_step_rows(dev, self.future_length, row_w, row_f, bi, train=True))
             step_losses = torch.stack(losses).cpu().numpy() if losses else np.zeros((0, 3))
-            trace["train"].extend(step_losses)
+            if keep_trace:
+                trace["train"].append(step_losses)          # one [steps, 3] array per epoch
             tl = step_losses.mean(0) if losses else np.zeros(3)
             if dev_valid is not None:
                 v_mse, v_back, v_recon = eng.train_step(dev_valid, train=False).cpu().numpy()

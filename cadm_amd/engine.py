@@ -41,11 +41,13 @@ def ctx_param_names(n_cp_hidden):
 class HipEngine:
     def __init__(self, env_kind, E, p, D, A, P, C, hidden_sizes, H, deterministic=False, discrete=False,
                  reference_quirks=True, history_length=10, cp_hidden_sizes=(256, 128, 64), back_model=False,
-                 num_elites=50, num_cem_iters=5, alpha=0.1, lower_bound=-1.0, upper_bound=1.0, device=None):
+                 num_elites=50, num_cem_iters=5, alpha=0.1, lower_bound=-1.0, upper_bound=1.0, device=None, lib=None):
         if not torch.cuda.is_available():
             raise _lib.CadmError("no HIP device visible: the CaDM planner runs only on the GPU "
                                  "(libcadm_hip.so); there is no CPU fallback")
-        self.lib = _lib.load()
+        # lib: a developer build (tests / tools: _lib.load_dev()); the product always binds libcadm_hip.so
+        self.lib = lib if lib is not None else _lib.load()
+        self._check = lambda rc, what="": check(rc, what, self.lib)
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         hs = tuple(int(h) for h in hidden_sizes)
         if len(set(hs)) != 1:
@@ -76,7 +78,7 @@ class HipEngine:
         self.num_elites, self.num_cem_iters = num_elites, num_cem_iters
         self._ctx = C_void_p()
         with torch.cuda.device(self.device):
-            check(self.lib.cadm_ctx_create(ct.byref(cfg), ct.byref(self._ctx)), "cadm_ctx_create")
+            self._check(self.lib.cadm_ctx_create(ct.byref(cfg), ct.byref(self._ctx)), "cadm_ctx_create")
         self.nets = OrderedDict()   # net name -> OrderedDict(param name -> tensor)
         self._ws = None
         self._ws_key = None
@@ -194,7 +196,7 @@ class HipEngine:
         if cur is None:
             self._register(net)
         if net == "ff_model":
-            check(self.lib.cadm_repack(self._ctx, self.stream), "cadm_repack")
+            self._check(self.lib.cadm_repack(self._ctx, self.stream), "cadm_repack")
 
     def _register(self, net):
         prm = self.nets[net]
@@ -204,14 +206,14 @@ class HipEngine:
         else:
             layers = ["hidden_%d" % i for i in range(self.NH)] + ["output_mu", "output_logvar"]
         for li, base in enumerate(layers):
-            check(self.lib.cadm_set_weights(self._ctx, nid, li, ptr(prm[base + "_weight"]), ptr(prm[base + "_bias"])),
+            self._check(self.lib.cadm_set_weights(self._ctx, nid, li, ptr(prm[base + "_weight"]), ptr(prm[base + "_bias"])),
                   "cadm_set_weights")
         if net != "context_model":
-            check(self.lib.cadm_set_logvar_bounds(self._ctx, nid, ptr(prm["max_logvar"]), ptr(prm["min_logvar"])),
+            self._check(self.lib.cadm_set_logvar_bounds(self._ctx, nid, ptr(prm["max_logvar"]), ptr(prm["min_logvar"])),
                   "cadm_set_logvar_bounds")
 
     def repack(self):
-        check(self.lib.cadm_repack(self._ctx, self.stream), "cadm_repack")
+        self._check(self.lib.cadm_repack(self._ctx, self.stream), "cadm_repack")
 
     def params_list(self):
         """Flat list of numpy arrays in the reference's tf.trainable_variables() order
@@ -239,14 +241,14 @@ class HipEngine:
             if a.size != n:
                 raise ValueError("stat %s has %d entries, expected %d" % (k, a.size, n))
         ptrs = (ct.c_void_p * 12)(*[a.ctypes.data_as(ct.c_void_p) for a in arrs])
-        check(self.lib.cadm_set_norm_stats(self._ctx, ptrs, self.stream), "cadm_set_norm_stats")
+        self._check(self.lib.cadm_set_norm_stats(self._ctx, ptrs, self.stream), "cadm_set_norm_stats")
 
     # ------------------------------------------------------------------ planner primitives
     def context_forward(self, cp_obs, cp_act, bs=False):
         cp_obs, cp_act = self._t(cp_obs), self._t(cp_act)
         m = cp_obs.shape[1] if bs else cp_obs.shape[0]
         out = torch.empty((self.E, m, self.C), dtype=torch.float32, device=self.device)
-        check(self.lib.cadm_context_forward(self._ctx, ptr(cp_obs), ptr(cp_act), m, int(bs), ptr(out), self.stream),
+        self._check(self.lib.cadm_context_forward(self._ctx, ptr(cp_obs), ptr(cp_act), m, int(bs), ptr(out), self.stream),
               "cadm_context_forward")
         return out
 
@@ -255,14 +257,14 @@ class HipEngine:
         m = mean.shape[0]
         z = None if z is None else self._t(z)
         out = torch.empty((m, n_global, self.H, self.A), dtype=torch.float32, device=self.device)
-        check(self.lib.cadm_sample_actions(self._ctx, ptr(mean), ptr(var), ptr(z), seed, call, it, m, n_global,
+        self._check(self.lib.cadm_sample_actions(self._ctx, ptr(mean), ptr(var), ptr(z), seed, call, it, m, n_global,
                                            ptr(out), self.stream), "cadm_sample_actions")
         return out
 
     def sample_uniform(self, m, n_global, seed=0, call=0):
         out = torch.empty((m, n_global, self.H, self.A), dtype=torch.float32, device=self.device)
         raw = torch.empty((m, n_global, self.H), dtype=torch.int32, device=self.device) if self.discrete else None
-        check(self.lib.cadm_sample_uniform(self._ctx, seed, call, m, n_global, ptr(out), ptr(raw), self.stream),
+        self._check(self.lib.cadm_sample_uniform(self._ctx, seed, call, m, n_global, ptr(out), ptr(raw), self.stream),
               "cadm_sample_uniform")
         return out, raw
 
@@ -277,7 +279,7 @@ class HipEngine:
         rows = torch.empty((m, n_local, self.p), dtype=torch.float32, device=self.device)
         traj = (torch.empty((self.H, m, n_local, self.p, self.D), dtype=torch.float32, device=self.device)
                 if want_traj else None)
-        check(self.lib.cadm_rollout_returns(self._ctx, ptr(obs), ptr(obs_rows), ptr(ctx_vec), ptr(actions), ptr(eps),
+        self._check(self.lib.cadm_rollout_returns(self._ctx, ptr(obs), ptr(obs_rows), ptr(ctx_vec), ptr(actions), ptr(eps),
                                             int(norm_actions), seed, call, it, cand_offset, n_global, m, n_local,
                                             ptr(rows), ptr(traj), self.stream), "cadm_rollout_returns")
         return (rows, traj) if want_traj else rows
@@ -285,7 +287,7 @@ class HipEngine:
     def particle_mean(self, rows):
         m, n_local = rows.shape[0], rows.shape[1]
         out = torch.empty((m, n_local), dtype=torch.float32, device=self.device)
-        check(self.lib.cadm_particle_mean(self._ctx, ptr(rows), m, n_local, ptr(out), self.stream), "cadm_particle_mean")
+        self._check(self.lib.cadm_particle_mean(self._ctx, ptr(rows), m, n_local, ptr(out), self.stream), "cadm_particle_mean")
         return out
 
     def cem_refit(self, cand, actions, mean, var, G=1, want_elites=False):
@@ -293,7 +295,7 @@ class HipEngine:
         m = actions.shape[0]
         n_local = actions.shape[1] // G
         el = torch.empty((m, self.num_elites), dtype=torch.int32, device=self.device) if want_elites else None
-        check(self.lib.cadm_cem_refit(self._ctx, ptr(cand), G, n_local, ptr(actions), m, ptr(mean), ptr(var), ptr(el),
+        self._check(self.lib.cadm_cem_refit(self._ctx, ptr(cand), G, n_local, ptr(actions), m, ptr(mean), ptr(var), ptr(el),
                                       self.stream), "cadm_cem_refit")
         return el
 
@@ -302,7 +304,7 @@ class HipEngine:
         n_local = actions.shape[1] // G
         out = torch.empty((m, self.A), dtype=torch.float32, device=self.device)
         best = torch.empty((m,), dtype=torch.int32, device=self.device)
-        check(self.lib.cadm_rs_select(self._ctx, ptr(cand), G, n_local, ptr(actions), m, ptr(out), ptr(best),
+        self._check(self.lib.cadm_rs_select(self._ctx, ptr(cand), G, n_local, ptr(actions), m, ptr(out), ptr(best),
                                       self.stream), "cadm_rs_select")
         return out, best
 
@@ -315,14 +317,24 @@ class HipEngine:
             self._ws_key = key
         return self._ws
 
-    def cem_plan(self, obs, cp_obs, cp_act, init_mean, init_var, n, seed=0, call=0):
+    def host_out(self, shape):
+        """Persistent PINNED host buffer the planners can write their (tiny) result into directly: the last kernel of a plan
+        stores over PCIe, the caller only synchronises the stream -- no D2H copy launch, no allocation per call."""
+        n = int(np.prod(shape))
+        if getattr(self, "_host_out", None) is None or self._host_out.numel() < n:
+            self._host_out = torch.empty(max(n, 1024), dtype=torch.float32).pin_memory()
+        return self._host_out[:n].view(tuple(shape))
+
+    def cem_plan(self, obs, cp_obs, cp_act, init_mean, init_var, n, seed=0, call=0, out=None):
+        """`out`: optional [m,H,A] float32 destination (device tensor, or a pinned host tensor such as `host_out`)."""
         obs, init_mean, init_var = self._t(obs), self._t(init_mean), self._t(init_var)
         cp_obs = None if cp_obs is None else self._t(cp_obs)
         cp_act = None if cp_act is None else self._t(cp_act)
         m = obs.shape[0]
         ws = self._workspace(m, n)
-        out = torch.empty((m, self.H, self.A), dtype=torch.float32, device=self.device)
-        check(self.lib.cadm_cem_plan(self._ctx, ptr(obs), ptr(cp_obs), ptr(cp_act), ptr(init_mean), ptr(init_var), m, n,
+        if out is None:
+            out = torch.empty((m, self.H, self.A), dtype=torch.float32, device=self.device)
+        self._check(self.lib.cadm_cem_plan(self._ctx, ptr(obs), ptr(cp_obs), ptr(cp_act), ptr(init_mean), ptr(init_var), m, n,
                                      seed, call, ptr(ws), ptr(out), self.stream), "cadm_cem_plan")
         return out
 
@@ -334,7 +346,7 @@ class HipEngine:
         ws = self._workspace(m, n)
         out = torch.empty((m, self.A), dtype=torch.float32, device=self.device)
         raw = torch.empty((m,), dtype=torch.int32, device=self.device) if self.discrete else None
-        check(self.lib.cadm_rs_plan(self._ctx, ptr(obs), ptr(cp_obs), ptr(cp_act), m, n, seed, call, ptr(ws), ptr(out),
+        self._check(self.lib.cadm_rs_plan(self._ctx, ptr(obs), ptr(cp_obs), ptr(cp_act), m, n, seed, call, ptr(ws), ptr(out),
                                     ptr(raw), self.stream), "cadm_rs_plan")
         return raw if self.discrete else out
 
@@ -354,7 +366,7 @@ class HipEngine:
             for i in range(ncp):
                 hp.context_weight_decays[i] = cwd[i]
             hp.context_weight_decays[ncp] = cwd[-1]   # cp_output (core/utils.py:610)
-        check(self.lib.cadm_train_configure(self._ctx, ct.byref(hp), int(max_batch)), "cadm_train_configure")
+        self._check(self.lib.cadm_train_configure(self._ctx, ct.byref(hp), int(max_batch)), "cadm_train_configure")
         self._train_B = int(max_batch)
 
     def train_step(self, batch, train=True):
@@ -363,7 +375,7 @@ class HipEngine:
         B = batch["obs"].shape[1]
         g = lambda k: ptr(batch.get(k))
         losses = torch.empty((3,), dtype=torch.float32, device=self.device)
-        check(self.lib.cadm_train_step(self._ctx, g("obs"), g("act"), g("delta"), g("obs_next"), g("back_delta"),
+        self._check(self.lib.cadm_train_step(self._ctx, g("obs"), g("act"), g("delta"), g("obs_next"), g("back_delta"),
                                        g("cp_obs"), g("cp_act"), B, int(train), ptr(losses), self.stream),
               "cadm_train_step")
         return losses
@@ -376,7 +388,7 @@ class HipEngine:
             idx = idx.contiguous()
         g = lambda k: ptr(dev.get(k))
         losses = torch.empty((3,), dtype=torch.float32, device=self.device)
-        check(self.lib.cadm_train_step_rows(self._ctx, g("obs"), g("act"), g("delta"), g("obs_next"), g("back_delta"),
+        self._check(self.lib.cadm_train_step_rows(self._ctx, g("obs"), g("act"), g("delta"), g("obs_next"), g("back_delta"),
                                             g("cp_obs"), g("cp_act"), int(F), ptr(row_w), ptr(row_f), ptr(idx), int(idx.stride(0)), B,
                                             int(train),
                                             ptr(losses), self.stream), "cadm_train_step_rows")
@@ -390,33 +402,60 @@ class HipEngine:
         import torch.distributed as dist
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         buf = ct.create_string_buffer(128)
+        # rank 0 ALWAYS reaches the broadcast: a failure to draw the id (librccl missing, ...) travels as a status byte, so
+        # the other ranks never wait in a broadcast that rank 0 skipped (mismatched collectives would hang)
+        status, err = 1, None
         if rank == 0:
-            check(self.lib.cadm_dist_unique_id(buf), "cadm_dist_unique_id")
-        t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=self.device if dist.get_backend(group) == "nccl" else "cpu")
+            try:
+                self._check(self.lib.cadm_dist_unique_id(buf), "cadm_dist_unique_id")
+            except _lib.CadmError as exc:
+                status, err = 0, exc
+        t = torch.tensor(list(buf.raw) + [status], dtype=torch.uint8, device=self.device if dist.get_backend(group) == "nccl" else "cpu")
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ident = bytes(t.cpu().tolist())
+        raw = t.cpu().tolist()
+        if raw[128] != 1:
+            raise err if err is not None else _lib.CadmError("cadm_dist_unique_id failed on rank 0 of the group")
+        ident = bytes(raw[:128])
         with torch.cuda.device(self.device):
-            check(self.lib.cadm_dist_init(self._ctx, ident, world, rank), "cadm_dist_init")
+            self._check(self.lib.cadm_dist_init(self._ctx, ident, world, rank), "cadm_dist_init")
+        nr, rk = self.dist_info()
+        if nr != world or rk != rank:
+            raise _lib.CadmError("RCCL communicator reports nranks=%d rank=%d, expected %d / %d" % (nr, rk, world, rank))
         self.dist_world, self.dist_rank = world, rank
 
     def dist_destroy(self):
-        check(self.lib.cadm_dist_destroy(self._ctx), "cadm_dist_destroy")
+        self._check(self.lib.cadm_dist_destroy(self._ctx), "cadm_dist_destroy")
         self.dist_world, self.dist_rank = 1, 0
 
     def dist_info(self):
         """(nranks, rank) as RCCL itself reports them for the ctx's communicator (ncclCommCount / ncclCommUserRank)."""
         n, r = ct.c_int(0), ct.c_int(0)
-        check(self.lib.cadm_dist_info(self._ctx, ct.byref(n), ct.byref(r)), "cadm_dist_info")
+        self._check(self.lib.cadm_dist_info(self._ctx, ct.byref(n), ct.byref(r)), "cadm_dist_info")
         return int(n.value), int(r.value)
 
     # ------------------------------------------------------------------ in-library kernel timing
     def profile_enable(self, on=True):
-        check(self.lib.cadm_profile_enable(self._ctx, int(on)), "cadm_profile_enable")
+        self._check(self.lib.cadm_profile_enable(self._ctx, int(on)), "cadm_profile_enable")
 
     def profile_read(self):
         """-> (total milliseconds, launches) of the rollout kernel since the last read."""
         ms, cnt = ct.c_float(0.0), ct.c_int(0)
-        check(self.lib.cadm_profile_read(self._ctx, ct.byref(ms), ct.byref(cnt)), "cadm_profile_read")
+        self._check(self.lib.cadm_profile_read(self._ctx, ct.byref(ms), ct.byref(cnt)), "cadm_profile_read")
+        return float(ms.value), int(cnt.value)
+
+    # ------------------------------------------------------------------ developer hooks (libcadm_hip_dev.so only)
+    def dev_set_rollout(self, kind="xdl", row_tiles=0):
+        """Select the fp32-MFMA comparison kernel ("f32") / force a row-tile flavour of the production kernel on THIS engine.
+        Exists only when the engine was built on the developer library (HipEngine(..., lib=_lib.load_dev()))."""
+        if not hasattr(self.lib, "cadm_dev_set_rollout"):
+            raise _lib.CadmError("dev_set_rollout needs the developer library (HipEngine(..., lib=_lib.load_dev()))")
+        self._check(self.lib.cadm_dev_set_rollout(self._ctx, {"xdl": _lib.DEV_ROLLOUT_XDL, "f32": _lib.DEV_ROLLOUT_F32}[kind],
+                                                  int(row_tiles)), "cadm_dev_set_rollout")
+
+    def profile_read_collective(self):
+        """-> (total milliseconds, calls) of the in-library ncclAllGather since the last read (sharded planner)."""
+        ms, cnt = ct.c_float(0.0), ct.c_int(0)
+        self._check(self.lib.cadm_profile_read_collective(self._ctx, ct.byref(ms), ct.byref(cnt)), "cadm_profile_read_collective")
         return float(ms.value), int(cnt.value)
 
     def predict_heads(self, obs, act, cp_obs=None, cp_act=None):
@@ -427,12 +466,12 @@ class HipEngine:
         B = obs.shape[1]
         mu = torch.empty((self.E, B, self.D), dtype=torch.float32, device=self.device)
         lv = None if self.deterministic else torch.empty_like(mu)
-        check(self.lib.cadm_predict(self._ctx, ptr(obs), ptr(act), ptr(cp_obs), ptr(cp_act), B, ptr(mu), ptr(lv), self.stream),
+        self._check(self.lib.cadm_predict(self._ctx, ptr(obs), ptr(act), ptr(cp_obs), ptr(cp_act), B, ptr(mu), ptr(lv), self.stream),
               "cadm_predict")
         return mu, lv
 
     def train_reset(self):
-        check(self.lib.cadm_train_reset(self._ctx, self.stream), "cadm_train_reset")
+        self._check(self.lib.cadm_train_reset(self._ctx, self.stream), "cadm_train_reset")
 
 
 def C_void_p():

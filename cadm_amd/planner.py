@@ -39,15 +39,25 @@ class Shard:
 
 
 def check_replicated(tensors, shard):
-    """Cheap guard for sharded planning: the per-rank checksum of the replicated inputs must agree across ranks
-    (one tiny MIN/MAX all-reduce); raises instead of silently ranking candidates rolled out from different states."""
+    """Guard for sharded planning: the replicated inputs must be the same on every rank of the group.  ONE all-reduce (MAX of
+    [h, -h] gives max and -min of a position-weighted, NaN-aware checksum) plus a host sync -- so the planner runs it on the
+    first few sharded calls of a model only (`MLPEnsembleCEMDynamicsModel(check_replicated_calls=...)`), not on every
+    `get_action`: the steady-state call has exactly the path's own collectives (one all-gather per CEM iteration)."""
     if shard.world == 1:
         return
     import torch.distributed as dist
-    s = torch.stack([t.double().sum() for t in tensors if t is not None])
-    lo, hi = s.clone(), s.clone()
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=shard.group)
-    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=shard.group)
+    sums = []
+    for t in tensors:
+        if t is None:
+            continue
+        x = torch.nan_to_num(t.double().reshape(-1), nan=12345.678, posinf=1.0e300, neginf=-1.0e300)
+        w = torch.arange(1, x.numel() + 1, device=x.device, dtype=torch.float64)      # position-weighted: permutations differ
+        sums.append((x * w).sum())
+        sums.append(x.sum())
+    h = torch.stack(sums)
+    both = torch.cat([h, -h])
+    dist.all_reduce(both, op=dist.ReduceOp.MAX, group=shard.group)
+    hi, lo = both[:h.numel()], -both[h.numel():]
     if not torch.equal(lo, hi):
         raise RuntimeError("candidate-sharded planning needs identical obs / history / warm start on every rank of the "
                            "group (checksums differ: %s vs %s)" % (lo.tolist(), hi.tolist()))

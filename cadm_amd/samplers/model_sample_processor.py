@@ -29,9 +29,6 @@ def _discount_cumsum(x, discount):
 class ModelSampleProcessor(object):
     def __init__(self, discount=0.99, max_path_length=200, recurrent=False, context=False, writer=None, future_length=10,
                  device=None):
-        if recurrent:
-            raise NotImplementedError("recurrent=True stacks whole paths (tensor_utils.concat_tensor_list(.., True)); "
-                                      "run_cadm_pets.py / run_pets.py never set it")
         self.discount = discount
         self.max_path_length = max_path_length
         self.recurrent = recurrent
@@ -45,15 +42,22 @@ class ModelSampleProcessor(object):
         for path in paths:                                                        # :37-41
             path["returns"] = _discount_cumsum(path["rewards"], self.discount)
         self._log_path_stats(paths, log, log_prefix, itr)
-        cat = lambda xs: np.concatenate(xs, axis=0)
+        # tensor_utils.concat_tensor_list (cadm/utils/tensor_utils.py:119-123): recurrent -> np.array(list), i.e. one leading
+        # axis per path (paths of equal length; numpy refuses ragged ones), else concatenation along the steps
+        cat = (lambda xs: np.array(xs)) if self.recurrent else (lambda xs: np.concatenate(xs, axis=0))
         data = dict(observations=cat([p["observations"][:-1] for p in paths]),                              # :45-51
                     next_observations=cat([p["observations"][1:] for p in paths]),
                     actions=cat([p["actions"][:-1] for p in paths]),
-                    timesteps=cat([np.arange(len(p["observations"]) - 1) for p in paths]),
+                    timesteps=np.concatenate([np.arange(len(p["observations"]) - 1) for p in paths], axis=0),
                     rewards=cat([p["rewards"][:-1] for p in paths]),
                     returns=cat([p["returns"] for p in paths]))
         if self.context:
-            data.update(self._windows(paths, as_device))
+            win, rows = self._windows(paths, as_device)
+            if self.recurrent:          # the flat [N, .] device result, cut per path
+                if len(set(int(r) for r in rows)) != 1:
+                    raise ValueError("recurrent=True needs paths of equal length (np.array of ragged per-path arrays)")
+                win = {k: v.reshape((len(paths), int(rows[0])) + tuple(v.shape[1:])) for k, v in win.items()}
+            data.update(win)
         return data
 
     # ------------------------------------------------------------------ device part
@@ -95,18 +99,25 @@ class ModelSampleProcessor(object):
             if rem:
                 for key in ("observations", "actions", "cp_obs", "cp_act"):
                     p[key] = np.concatenate([p[key], np.zeros((rem, np.asarray(p[key]).shape[1]))], axis=0)
-        return out if as_device else {k: v.cpu().numpy() for k, v in out.items()}
+        if not as_device:
+            # the reference builds the windows in float64 whenever zero padding is concatenated (np.zeros): numpy out is
+            # float64 like its output; device tensors keep the paths' dtype
+            out = {k: v.cpu().numpy().astype(np.float64, copy=False) for k, v in out.items()}
+        return out, rows
 
     def _log_path_stats(self, paths, log, log_prefix, itr):                      # cadm/samplers/base.py:222-250
-        if not log:
-            return
         undiscounted = [float(np.sum(p["rewards"])) for p in paths]
+        w = self.writer
         if log == "reward":
             logger.logkv(log_prefix + "AverageReturn", np.mean(undiscounted))
-        else:
-            logger.logkv(log_prefix + "AverageDiscountedReturn", np.mean([p["returns"][0] for p in paths]))
-            logger.logkv(log_prefix + "AverageReturn", np.mean(undiscounted))
-            logger.logkv(log_prefix + "NumTrajs", len(paths))
-            logger.logkv(log_prefix + "StdReturn", np.std(undiscounted))
-            logger.logkv(log_prefix + "MaxReturn", np.max(undiscounted))
-            logger.logkv(log_prefix + "MinReturn", np.min(undiscounted))
+            if w is not None:
+                w.add_scalar("log/AverageReturn", np.mean(undiscounted))
+        elif log == "all" or log is True:
+            stats = (("AverageDiscountedReturn", np.mean([p["returns"][0] for p in paths])), ("AverageReturn", np.mean(undiscounted)),
+                     ("NumTrajs", len(paths)), ("StdReturn", np.std(undiscounted)), ("MaxReturn", np.max(undiscounted)),
+                     ("MinReturn", np.min(undiscounted)))
+            for k, v in stats:
+                logger.logkv(log_prefix + k, v)
+            if w is not None:                                                     # TensorBoard scalars, base.py:243-249
+                for k, v in stats:
+                    w.add_scalar("log/" + k, v, itr)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CADM_ABI_VERSION 1
+#define CADM_ABI_VERSION 2
 
 #define CADM_OK 0
 #define CADM_EINVAL (-1)      /* bad argument / unsupported configuration */
@@ -254,10 +254,11 @@ int cadm_dist_info(cadm_ctx* ctx, int* nranks_out, int* rank_out);
  * since the last read, and resets both. */
 int cadm_profile_enable(cadm_ctx* ctx, int enable);
 int cadm_profile_read(cadm_ctx* ctx, float* total_ms_out, int* launches_out);
-/* Developer aid: device buffer of 4*24 uint64 that the CADM_PHASE_TIMING build of the rollout
- * kernel (make -C cadm_amd/csrc timing) fills with per-phase s_memtime sums of workgroup 0.
- * Ignored by the production build. */
-int cadm_debug_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf);
+/* Same for the sharded planner's collective: every ncclAllGather issued by cadm_cem_plan / cadm_rs_plan while profiling is
+ * enabled is bracketed too; returns the summed milliseconds and the number of all-gathers since the last read. */
+int cadm_profile_read_collective(cadm_ctx* ctx, float* total_ms_out, int* calls_out);
+/* (Developer hooks -- comparison kernel, forced launch flavours, phase timing -- are NOT part of this interface and not
+ * in libcadm_hip.so: cadm_amd/csrc/dev/dev_api.h, libcadm_hip_dev.so.  The product reads no environment variable.) */
 
 #ifdef __cplusplus
 }

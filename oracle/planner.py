@@ -127,10 +127,13 @@ def rollout_literal(env, dyn, st, obs, T, actions, eps, E, p, deterministic, nor
 
 
 def rollout_indexed(env, dyn, st, obs, T, actions, eps, E, p, deterministic, norm_actions=True,
-                    raw_actions=None, return_traj=False, obs_rows=None, ctx_rows=None):
+                    raw_actions=None, return_traj=False, obs_rows=None, ctx_rows=None,
+                    hidden_act=nets.swish, out_act=nets.ACTIVATIONS[None], x_transform=None):
     """Index-mapped form: row (mi,ni,j) is evaluated by member j // (p/E) with
     context T[mi, j % E] (or an explicit ``ctx_rows`` [m,p,C]).  ``obs_rows``
-    [m,n,p,D] optionally overrides the tiled start state (teacher forcing)."""
+    [m,n,p,D] optionally overrides the tiled start state (teacher forcing).
+    ``hidden_act`` / ``out_act``: the ctor's nonlinearities (dynamics.py:17-24,104-105).  ``x_transform``
+    (tests of the kernels' documented range clamps only) is applied to the assembled network input."""
     m, D = obs.shape
     _, n, H, A = actions.shape
     pe = p // E
@@ -153,13 +156,16 @@ def rollout_indexed(env, dyn, st, obs, T, actions, eps, E, p, deterministic, nor
         nobs = nets.normalize(env.obs_preproc(observation), st["obs_mean"], st["obs_std"])
         feats = [nobs, nact] + ([crow] if crow is not None else [])
         x = np.concatenate(feats, axis=-1)                                   # [m,n,p,K0]
+        if x_transform is not None:
+            x = x_transform(x)
         delta = np.empty((m, n, p, D), obs.dtype)
         for e in range(E):
             js = slice(e * pe, (e + 1) * pe)
             xe = x[:, :, js, :].reshape(1, -1, x.shape[-1])
             ee = eps[t][:, :, js, :].reshape(1, -1, D)
             dyn_e = {k: (v[e:e + 1] if v.ndim == 3 else v) for k, v in dyn.items()}
-            d_e, _, _ = nets.dynamics_forward(dyn_e, xe, st["delta_mean"], st["delta_std"], ee, deterministic)
+            d_e, _, _ = nets.dynamics_forward(dyn_e, xe, st["delta_mean"], st["delta_std"], ee, deterministic,
+                                              hidden_act=hidden_act, out_act=out_act)
             delta[:, :, js, :] = d_e.reshape(m, n, pe, D)
         next_observation = env.obs_postproc(observation, delta)
         if raw_actions is not None:

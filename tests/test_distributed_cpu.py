@@ -79,3 +79,36 @@ def test_shard_validation():
         Shard(10, 0, 4)
     s = Shard(12, 2, 4)
     assert s.n_local == 3 and s.offset == 6
+
+
+def _repl_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cadm_amd import planner as hplanner
+    shard = hplanner.Shard.from_group(8, dist.group.WORLD)
+    res = []
+    same = [torch.arange(6.0).reshape(2, 3), torch.tensor([1.0, float("nan"), 3.0])]      # NaN at the same place on every rank: equal
+    cases = {"same": same,
+             "differs": [same[0] + (0.5 if rank == 1 else 0.0), same[1]],
+             "permuted": [same[0].flip(0) if rank == 1 else same[0], same[1]],              # same plain sum, different order
+             "nan_moved": [same[0], torch.tensor([1.0, 3.0, float("nan")]) if rank == 1 else same[1]]}
+    for name, ts in cases.items():
+        try:
+            hplanner.check_replicated(ts, shard)
+            res.append((name, "ok"))
+        except RuntimeError:
+            res.append((name, "raised"))
+    np.save(os.path.join(out_dir, "repl_%d.npy" % rank), np.array(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_check_replicated_is_nan_aware_and_order_sensitive(tmp_path):
+    """the replicated-input guard of sharded planning -- ONE all-reduce, NaN-aware (a NaN observation on every rank is
+    'equal'), sensitive to permutations (a plain sum is not)."""
+    mp.spawn(_repl_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = dict(np.load(tmp_path / ("repl_%d.npy" % r)))
+        assert got == {"same": "ok", "differs": "raised", "permuted": "raised", "nan_moved": "raised"}, got

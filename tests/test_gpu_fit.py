@@ -39,7 +39,7 @@ def test_fit_matches_oracle_on_injected_index_stream(gpu, back_coeff):
     data = _windows(np.random.default_rng(2), 30)
     rec = RecordingIndexStream(FitIndexStream(np.random.default_rng(9)))
     model.fit(epochs=epochs, index_stream=rec, **data)
-    got_train = np.asarray(model.last_fit_trace["train"], np.float64)
+    got_train = np.concatenate(model.last_fit_trace["train"]).astype(np.float64)
     got_valid = np.asarray(model.last_fit_trace["valid"], np.float64)
     kinds = [k for k, _ in rec.log]
     assert kinds == ["permutation", "bootstrap"] + ["epoch_order"] * epochs      # the reference's np.random call order

@@ -1,27 +1,25 @@
 """The rollout kernel exists in two flavours -- one or two 16-row tiles per workgroup (rollout_xdl.h: XC<.., MT>); the
 launcher picks by batch size.  A row's arithmetic is the same in both, so they must agree BIT FOR BIT on any input; this
-forces each flavour (developer override CADM_XDL_MT) on ragged problem sizes: row counts that are not a multiple of 16,
+forces each flavour (developer library: cadm_dev_set_rollout) on ragged problem sizes: row counts that are not a multiple of 16,
 odd tile counts (the last workgroup's second tile is empty), single-tile members, every noise mode."""
-import os
-
 import numpy as np
 import pytest
 import torch
 
-from cadm_amd import synth
+from cadm_amd import _lib, synth
 from helpers import make_engine
 
 pytestmark = pytest.mark.gpu
 
 
 def _run(eng, prob, ctx, acts, eps, flavour, **kw):
-    os.environ["CADM_XDL_MT"] = flavour
+    eng.dev_set_rollout("xdl", row_tiles=int(flavour))
     try:
         rows, traj = eng.rollout_returns(prob["obs"], ctx, acts, eps=eps, want_traj=True, **kw)
         torch.cuda.synchronize()
         return rows.cpu().numpy(), traj.cpu().numpy()
     finally:
-        os.environ.pop("CADM_XDL_MT", None)
+        eng.dev_set_rollout("xdl", row_tiles=0)
 
 
 @pytest.mark.parametrize("env,context,E,p,n,m", [
@@ -35,7 +33,7 @@ def _run(eng, prob, ctx, acts, eps, flavour, **kw):
 def test_one_and_two_row_tiles_per_workgroup_agree_bitwise(gpu, env, context, E, p, n, m):
     H = 12
     prob = synth.make_problem(env=env, context=context, E=E, m=m, H=H, trained_like=True, seed=21)
-    eng = make_engine(prob, p=p)
+    eng = make_engine(prob, p=p, lib=_lib.load_dev())
     rng = np.random.default_rng(4)
     acts = eng._t(rng.uniform(-1, 1, (m, n, H, prob["A"])).astype(np.float32))
     ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"]) if context else None
@@ -51,7 +49,7 @@ def test_one_and_two_row_tiles_per_workgroup_agree_bitwise(gpu, env, context, E,
 
 def test_deterministic_model_both_flavours(gpu):
     prob = synth.make_problem(env="halfcheetah", context=False, E=1, m=1, H=8, trained_like=True, seed=2)
-    eng = make_engine(prob, p=1, deterministic=True)
+    eng = make_engine(prob, p=1, deterministic=True, lib=_lib.load_dev())
     acts = eng._t(np.random.default_rng(0).uniform(-1, 1, (1, 45, 8, prob["A"])).astype(np.float32))
     r1, t1 = _run(eng, prob, None, acts, None, "1")
     r2, t2 = _run(eng, prob, None, acts, None, "2")

@@ -10,8 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
 
-from cadm_amd import synth
-from cadm_amd._lib import check
+from cadm_amd import _lib, synth
 from cadm_amd.synth import make_engine
 
 
@@ -19,10 +18,10 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     hid = int(os.environ.get("CHAIN_HID", "200"))
     prob = synth.make_problem(env="halfcheetah", context=True, E=5, with_back=True, seed=0, hidden_sizes=(hid,) * 4)
-    eng = make_engine(prob, p=20)
+    eng = make_engine(prob, p=20, lib=_lib.load_dev())
     batch = {k: eng._t(v) for k, v in synth.make_train_batch(prob, B=B, seed=1).items()}
     tbuf = torch.zeros(4096, dtype=torch.int64, device=eng.device)
-    check(eng.lib.cadm_debug_set_timing_buffer(eng._ctx, ct.c_void_p(tbuf.data_ptr())))
+    eng._check(eng.lib.cadm_dev_set_timing_buffer(eng._ctx, ct.c_void_p(tbuf.data_ptr())))
     eng.train_configure(1e-3, (0.000025, 0.00005, 0.000075, 0.000075, 0.0001), (0.000025, 0.00005, 0.000075), 1.0, 0.5, max_batch=B)
     for _ in range(3):
         eng.train_step(batch, train=True)

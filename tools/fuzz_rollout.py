@@ -17,30 +17,28 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from cadm_amd import synth
+from cadm_amd import _lib, synth
 
 ENVS = ["halfcheetah", "cripple_halfcheetah", "ant", "slim_humanoid", "pendulum", "cartpole"]
 
 
 def run(eng, prob, ctx, acts, eps, flavour, **kw):
     if flavour:
-        os.environ["CADM_XDL_MT"] = flavour
-    try:
-        rows, traj = eng.rollout_returns(prob["obs"], ctx, acts, eps=eps, want_traj=True, **kw)
-        torch.cuda.synchronize()
-        return rows.cpu().numpy(), traj.cpu().numpy()
-    finally:
-        os.environ.pop("CADM_XDL_MT", None)
+        eng.dev_set_rollout("xdl", row_tiles=int(flavour))
+    rows, traj = eng.rollout_returns(prob["obs"], ctx, acts, eps=eps, want_traj=True, **kw)
+    torch.cuda.synchronize()
+    return rows.cpu().numpy(), traj.cpu().numpy()
 
 
-def main():
-    t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+def fuzz(seconds=60.0, seed=0, hids=(128, 200, 200, 256, 512)):
+    """-> (rounds, worst xdl-vs-fp32 deviation); raises AssertionError on the first failing problem."""
+    t_end = time.time() + seconds
+    rng = np.random.default_rng(seed)
     rounds, worst = 0, 0.0
     while time.time() < t_end:
         env = ENVS[rng.integers(len(ENVS))]
         context = bool(rng.integers(2))
-        hid = int(rng.choice([128, 200, 200, 256, 512]))
+        hid = int(rng.choice(list(hids)))
         E = int(rng.choice([1, 2, 5]))
         p = E * int(rng.integers(1, 5))
         m, n, H = int(rng.integers(1, 4)), int(rng.integers(1, 120)), int(rng.integers(1, 12))
@@ -57,10 +55,9 @@ def main():
         kw = dict(norm_actions=not discrete, it=int(rng.integers(2)))
         out = {}
         for kind in ("f32", "xdl"):
+            eng = synth.make_engine(prob, p=p, deterministic=det, lib=_lib.load_dev())
             if kind == "f32":
-                os.environ["CADM_ROLLOUT"] = "f32"
-            eng = synth.make_engine(prob, p=p, deterministic=det)
-            os.environ.pop("CADM_ROLLOUT", None)
+                eng.dev_set_rollout("f32")
             ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"]) if context else None
             a_dev = eng._t(acts)
             mode = int(rng.integers(2)) if kind == "f32" else mode
@@ -96,6 +93,11 @@ def main():
         worst = max(worst, err)
         assert err <= 2e-4 * max(1, H), "%s: xdl vs fp32 kernel %.2e" % (tag, err)
         rounds += 1
+    return rounds, worst
+
+
+def main():
+    rounds, worst = fuzz(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     print("fuzz OK: %d random problems; worst xdl-vs-fp32 trajectory deviation %.2e of the rms" % (rounds, worst))
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase cycle breakdown of the rollout kernel (workgroup 0) using the CADM_PHASE_TIMING build.
-   make -C cadm_amd/csrc timing && CADM_HIP_LIB=cadm_amd/libcadm_hip_timing.so python tools/phase_timing.py [cfg]"""
+   make -C cadm_amd/csrc timing && python tools/phase_timing.py [cfg] [f32]      (loads cadm_amd/libcadm_hip_timing.so)"""
 import os
 import sys
 
@@ -12,8 +12,7 @@ import ctypes as ct
 import numpy as np
 import torch
 
-from cadm_amd import synth
-from cadm_amd._lib import check
+from cadm_amd import _lib, synth
 from cadm_amd.synth import make_engine
 
 XDL_NAMES = ["state+noise", "bar", "L0 rest", "bar", "hidden 1 rest", "hidden bars", "head rest", "bar", "hidden 2 rest", "hidden 3+ rest",
@@ -26,10 +25,14 @@ def main():
     cfgname = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
     cfg = synth.CONFIGS[cfgname]
     prob = synth.make_problem(env=cfg["env"], context=cfg["context"], E=cfg["E"], m=1, H=cfg["H"], seed=0)
-    eng = make_engine(prob, p=cfg["p"], deterministic=cfg["deterministic"])
-    NW = 4 if os.environ.get("CADM_ROLLOUT") == "f32" else 8
+    f32 = len(sys.argv) > 2 and sys.argv[2] == "f32"
+    eng = make_engine(prob, p=cfg["p"], deterministic=cfg["deterministic"],
+                      lib=_lib.load_dev(os.path.join(ROOT, "cadm_amd", "libcadm_hip_timing.so")))
+    if f32:
+        eng.dev_set_rollout("f32")
+    NW = 4 if f32 else 8
     tbuf = torch.zeros(NW * 24, dtype=torch.int64, device=eng.device)
-    check(eng.lib.cadm_debug_set_timing_buffer(eng._ctx, ct.c_void_p(tbuf.data_ptr())))
+    eng._check(eng.lib.cadm_dev_set_timing_buffer(eng._ctx, ct.c_void_p(tbuf.data_ptr())))
     n = cfg["n"]
     mean, var = eng._t(prob["init_mean"]), eng._t(prob["init_var"])
     ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"]) if cfg["context"] else None
@@ -37,7 +40,7 @@ def main():
     for _ in range(3):
         eng.rollout_returns(prob["obs"], ctx, acts, seed=1, call=1)
     torch.cuda.synchronize()
-    names = NAMES if os.environ.get("CADM_ROLLOUT") == "f32" else XDL_NAMES
+    names = NAMES if f32 else XDL_NAMES
     t = tbuf.cpu().numpy().reshape(NW, 24)[:, :len(names)].astype(np.float64) / cfg["H"]
     print("cycles per step (s_memtime ticks), workgroup 0, per wave:")
     fmt = "%-16s" + " %8s" * NW

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential check of the two rollout kernels on the same inputs: the split-f16 "xdl" kernel (production) against the
-fp32-MFMA kernel (CADM_ROLLOUT=f32), per problem variant.  Developer tool; needs a GPU."""
+fp32-MFMA comparison kernel of the developer library (cadm_dev_set_rollout), per problem variant.  Developer tool; needs a GPU."""
 import os
 import sys
 
@@ -9,14 +9,13 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 
-from cadm_amd import synth
+from cadm_amd import _lib, synth
 
 
 def engines(prob, p, det=False):
-    os.environ["CADM_ROLLOUT"] = "f32"
-    e32 = synth.make_engine(prob, p=p, deterministic=det)
-    os.environ.pop("CADM_ROLLOUT")
-    ex = synth.make_engine(prob, p=p, deterministic=det)
+    e32 = synth.make_engine(prob, p=p, deterministic=det, lib=_lib.load_dev())
+    e32.dev_set_rollout("f32")
+    ex = synth.make_engine(prob, p=p, deterministic=det)          # the product library
     return e32, ex
 
 
