@@ -20,6 +20,9 @@ MAX_CP_LAYERS = 8
 ENV_KINDS = {"halfcheetah": 0, "cripple_halfcheetah": 0, "ant": 1, "slim_humanoid": 2,
              "cartpole": 3, "pendulum": 4}
 NET_FF, NET_BACK, NET_CTX = 0, 1, 2
+# hidden nonlinearity codes (include/cadm_hip.h CADM_ACT_*; the reference's `_activations`, dynamics.py:17-24)
+ACT_KINDS = {"swish": 0, "relu": 1, "tanh": 2, "sigmoid": 3, None: 4}
+NOISE_PHILOX, NOISE_INJECT, NOISE_NONE = 0, 1, 2
 
 
 class CadmError(RuntimeError):
@@ -36,7 +39,7 @@ class Config(C.Structure):
         ("n_cp_hidden", C.c_int32), ("cp_hidden", C.c_int32 * MAX_CP_LAYERS),
         ("num_elites", C.c_int32), ("num_cem_iters", C.c_int32), ("alpha", C.c_float),
         ("lower_bound", C.c_float), ("upper_bound", C.c_float), ("back_model", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("hidden_act", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -66,6 +69,9 @@ SIGNATURES = {
     "cadm_sample_actions": (_i, [_P, _P, _P, _P, _u32, _u32, _i, _i, _i, _P, _P]),
     "cadm_sample_uniform": (_i, [_P, _u32, _u32, _i, _i, _P, _P, _P]),
     "cadm_rollout_returns": (_i, [_P, _P, _P, _P, _P, _P, _i, _u32, _u32, _i, _i, _i, _i, _i, _P, _P, _P]),
+    "cadm_rollout_builtin": (_i, [_P]),
+    "cadm_register_rollout": (_i, [_P, _i, _P, C.POINTER(_i)]),
+    "cadm_rollout_check": (_i, [_P, _i, _i, _i]),
     "cadm_particle_mean": (_i, [_P, _P, _i, _i, _P, _P]),
     "cadm_cem_refit": (_i, [_P, _P, _i, _i, _P, _i, _P, _P, _P, _P]),
     "cadm_rs_select": (_i, [_P, _P, _i, _i, _P, _i, _P, _P, _P]),

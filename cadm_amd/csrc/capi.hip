@@ -43,10 +43,12 @@ extern "C" int cadm_ctx_create(const cadm_config* cfg, cadm_ctx** out) {
     CADM_REQUIRE(cfg->context_dim >= 0, "cadm_ctx_create: negative context_dim");
     CADM_REQUIRE(cfg->n_cp_hidden >= 0 && cfg->n_cp_hidden <= CADM_MAX_CP_LAYERS, "cadm_ctx_create: bad n_cp_hidden");
     CADM_REQUIRE(cfg->num_elites >= 1 && cfg->num_cem_iters >= 1, "cadm_ctx_create: bad CEM constants");
+    CADM_REQUIRE(cfg->hidden_act >= CADM_ACT_SWISH && cfg->hidden_act <= CADM_ACT_NONE, "cadm_ctx_create: unknown hidden_act %d", cfg->hidden_act);
 
     cadm_ctx* c = new (std::nothrow) cadm_ctx();
     if (!c) { cadm_set_error("cadm_ctx_create: out of host memory"); return CADM_ENOMEM; }
     c->cfg = *cfg;
+    c->set_error = &cadm_set_error;
     CADM_CHECK_HIP(hipGetDevice(&c->device));
     c->D = cfg->obs_dim; c->A = cfg->act_dim; c->P = cfg->proc_obs_dim; c->C = cfg->context_dim;
     c->E = cfg->ensemble_size; c->p = cfg->n_particles; c->H = cfg->horizon; c->HID = cfg->hidden;
@@ -232,6 +234,38 @@ extern "C" int cadm_rollout_returns(cadm_ctx* ctx, const float* obs, const float
     rc = cadm_launch_rollout(ctx, obs, obs_rows, ctx_vec, actions, eps, norm_actions, seed, call, it, cand_offset,
                              n_global, m, n_local, returns_rows, traj_out, (hipStream_t)stream);
     if (ctx->prof && rc == CADM_OK) CADM_CHECK_HIP(hipEventRecord(e1, (hipStream_t)stream));
+    return rc;
+}
+
+int cadm_rollout_builtin_env(cadm_ctx* ctx);     // rollout.hip
+
+extern "C" int cadm_rollout_builtin(cadm_ctx* ctx) {
+    if (!ctx) return 0;
+    return cadm_rollout_builtin_env(ctx);
+}
+
+extern "C" int cadm_register_rollout(cadm_ctx* ctx, int noise_mode, void* fn, const int d[8]) {
+    CADM_REQUIRE(ctx && fn && d && noise_mode >= 0 && noise_mode <= 2, "cadm_register_rollout: bad arguments");
+    CADM_REQUIRE(d[0] == CADM_CTX_LAYOUT_TAG && d[7] == (int)sizeof(cadm_ctx),
+                 "cadm_register_rollout: module built against another library layout (tag %d / %d bytes, library %d / %d): rebuild it",
+                 d[0], d[7], CADM_CTX_LAYOUT_TAG, (int)sizeof(cadm_ctx));
+    CADM_REQUIRE(d[1] == ctx->cfg.env_kind && d[2] == ctx->C && d[3] == ctx->HID && d[4] == ctx->NH && d[5] == ctx->cfg.hidden_act && d[6] == noise_mode,
+                 "cadm_register_rollout: module is for env %d C %d hidden %d x %d act %d noise %d, the ctx needs env %d C %d hidden %d x %d act %d noise %d",
+                 d[1], d[2], d[3], d[4], d[5], d[6], ctx->cfg.env_kind, ctx->C, ctx->HID, ctx->NH, ctx->cfg.hidden_act, noise_mode);
+    ctx->jit_rollout[noise_mode] = (int (*)(cadm_ctx*, const RolloutArgs*, int, void*))fn;
+    return CADM_OK;
+}
+
+extern "C" int cadm_rollout_check(cadm_ctx* ctx, int noise_mode, int m, int n_local) {
+    CADM_REQUIRE(ctx && noise_mode >= 0 && noise_mode <= 2 && m > 0 && n_local > 0, "cadm_rollout_check: bad arguments");
+    CADM_ON_DEVICE(ctx);
+    // dummy non-null pointers select the noise mode; nothing is dereferenced or launched
+    const float* eps = noise_mode == 1 ? (const float*)ctx->xb : nullptr;
+    const int det = ctx->cfg.deterministic;
+    ctx->cfg.deterministic = noise_mode == 2;
+    const int rc = cadm_launch_rollout(ctx, (const float*)ctx->xb, nullptr, (const float*)ctx->xb, (const float*)ctx->xb, eps, 1, 0, 0, 0, 0, n_local, m,
+                                       n_local, (float*)ctx->xb, nullptr, nullptr, 1);
+    ctx->cfg.deterministic = det;
     return rc;
 }
 

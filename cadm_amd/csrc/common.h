@@ -13,7 +13,21 @@
 // ---------------------------------------------------------------------------------------------
 // error plumbing (no exceptions cross the C ABI)
 // ---------------------------------------------------------------------------------------------
+#ifdef CADM_JIT_MODULE      // side modules (rollout_jit.hip) report through the pointer the ctx carries
+extern void (*cadm_jit_set_error)(const char*, ...);
+#define cadm_set_error(...) cadm_jit_set_error(__VA_ARGS__)
+#else
 void cadm_set_error(const char* fmt, ...);
+#endif
+// (hidden width, context width) lists compiled into the library (Makefile HIDS / CTXS)
+#ifndef CADM_CTX_LIST
+#define CADM_CTX_LIST 0, 10            // 0 = vanilla PE-TS, 10 = the reference default --context_out_dim (run_cadm_pets.py:135)
+#endif
+#ifndef CADM_HID_LIST
+#define CADM_HID_LIST 200              // the reference default --hidden_size (run_cadm_pets.py:129)
+#endif
+// bumped whenever cadm_ctx / RolloutArgs change: a side module built against another layout is refused
+#define CADM_CTX_LAYOUT_TAG 3001
 
 #define CADM_CHECK_HIP(expr)                                                                   \
     do {                                                                                       \
@@ -102,6 +116,9 @@ struct cadm_ctx {
     // Developer hooks.  The product library never sets them (no entry point does, and it reads no environment variable);
     // libcadm_hip_dev.so adds dev/dev_api.hip, whose cadm_dev_set_rollout installs the fp32-MFMA comparison kernel of
     // round 1 (dev/rollout_f32.h) or forces a row-tile flavour of the production kernel.
+    // side modules for geometries that are not compiled in (rollout_jit.hip, registered by cadm_register_rollout), per noise mode
+    int (*jit_rollout[3])(cadm_ctx*, const struct RolloutArgs*, int rows_per_member, void* stream) = {nullptr, nullptr, nullptr};
+    void (*set_error)(const char*, ...) = nullptr;      // = cadm_set_error of the library that owns the ctx
     int (*dev_rollout)(cadm_ctx*, const struct RolloutArgs&, int rows_per_member, hipStream_t) = nullptr;
     int (*dev_pack)(cadm_ctx*, hipStream_t) = nullptr;
     void (*dev_free)(cadm_ctx*) = nullptr;
@@ -149,7 +166,7 @@ int cadm_pack_xdl(cadm_ctx* ctx, hipStream_t s);
 int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, const float* ctx_vec,
                         const float* actions, const float* eps, int norm_actions, uint32_t seed,
                         uint32_t call, int it, int cand_offset, int n_global, int m, int n_local,
-                        float* returns_rows, float* traj_out, hipStream_t s);
+                        float* returns_rows, float* traj_out, hipStream_t s, int dry_run = 0);
 int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs,
                         float* out, hipStream_t s);
 void cadm_train_free(cadm_ctx* ctx);

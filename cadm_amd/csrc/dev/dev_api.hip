@@ -16,6 +16,7 @@ int cadm_rollout_f32_env_cartpole(cadm_ctx*, const RolloutArgs&, int, hipStream_
 int cadm_rollout_f32_env_pendulum(cadm_ctx*, const RolloutArgs&, int, hipStream_t);
 
 static int rollout_f32(cadm_ctx* ctx, const RolloutArgs& a0, int rpm, hipStream_t s) {
+    if (a0.dry_run) return CADM_OK;       // cadm_rollout_check: nothing to validate for the comparison kernel
     RolloutArgs a = a0;
     a.wstream = ctx->wstream;
     a.bstream = ctx->bstream;

@@ -11,7 +11,7 @@ int cadm_rollout_env_pendulum(cadm_ctx*, const RolloutArgs&, int, hipStream_t);
 int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, const float* ctx_vec,
                         const float* actions, const float* eps, int norm_actions, uint32_t seed,
                         uint32_t call, int it, int cand_offset, int n_global, int m, int n_local,
-                        float* returns_rows, float* traj_out, hipStream_t s) {
+                        float* returns_rows, float* traj_out, hipStream_t s, int dry_run) {
     RolloutArgs a{};
     const size_t xbytes = (size_t)ctx->xg.member_frags() * CADM_XDL_FRAG_BYTES * ctx->E;
     if (xbytes >= (1ull << 31)) {
@@ -40,8 +40,11 @@ int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, 
         cadm_set_error("rollout: problem too large for 32-bit row indexing (m*n*p = %lld)", rows_total);
         return CADM_EINVAL;
     }
+    a.dry_run = dry_run;
     const int rpm = m * n_local * a.PE;
     if (ctx->dev_rollout) return ctx->dev_rollout(ctx, a, rpm, s);      // developer library only (common.h)
+    const int mode = a.deterministic ? 2 : a.eps ? 1 : 0;               // CADM_NOISE_*
+    if (ctx->jit_rollout[mode]) return ctx->jit_rollout[mode](ctx, &a, rpm, (void*)s);      // side module for this geometry
     switch (ctx->cfg.env_kind) {
         case CADM_ENV_HALFCHEETAH: return cadm_rollout_env_halfcheetah(ctx, a, rpm, s);
         case CADM_ENV_ANT: return cadm_rollout_env_ant(ctx, a, rpm, s);
@@ -51,4 +54,15 @@ int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, 
     }
     cadm_set_error("rollout: unknown env kind %d", ctx->cfg.env_kind);
     return CADM_EINVAL;
+}
+
+// 1 if the library carries a kernel for the ctx's geometry (rollout_dispatch.h: HIDS x CTXS, 4 hidden layers, swish)
+int cadm_rollout_builtin_env(cadm_ctx* ctx) {
+    static const int hids[] = {CADM_HID_LIST};
+    static const int ctxs[] = {CADM_CTX_LIST};
+    if (ctx->NH != 4 || ctx->cfg.hidden_act != CADM_ACT_SWISH) return 0;
+    bool h = false, c = false;
+    for (int v : hids) h = h || v == ctx->HID;
+    for (int v : ctxs) c = c || v == ctx->C;
+    return h && c ? 1 : 0;
 }

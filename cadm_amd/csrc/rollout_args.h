@@ -21,5 +21,6 @@ struct RolloutArgs {
     int wgs_per_member, rows_per_member;
     int tile0, tile_count;            // xdl kernel: row tiles [tile0, tile0 + tile_count) of every member in this launch
     int bias_lds;                     // xdl kernel: bias tiles staged in LDS
+    int dry_run;                      // launcher: validate the geometry (LDS, instantiation) without launching
     unsigned long long* tbuf;   // CADM_PHASE_TIMING builds only
 };

@@ -38,9 +38,14 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 // MT = row tiles (of 16 rows) a workgroup advances together.  2 for large batches: every weight fragment then feeds two sets
 // of MFMAs (half the weight stream, half the barriers and sweep start-ups per row), all 512 threads hold rollout state.
-template <int ENV_, int C_, int HID_, int MT_ = 1>
+// NH = number of hidden layers, compile-time: the per-layer stream offsets, residency tables and the layer loop fold to
+// constants (runtime NH cost 3 % at cfg2: ~100 scalar instructions per sweep boundary and SGPR spills).  ACT = hidden
+// nonlinearity (CADM_ACT_*; the reference's `_activations`, dynamics.py:17-24).  Geometries that are not compiled in are
+// built on demand from rollout_jit.hip (cadm_amd/jit.py).
+template <int ENV_, int C_, int HID_, int MT_, int NH_, int ACT_>
 struct XC {
-    static constexpr int ENV = ENV_, C = C_, HID = HID_, MT = MT_;
+    static constexpr int ENV = ENV_, C = C_, HID = HID_, MT = MT_, NHC = NH_, ACT = ACT_;
+    static_assert(NH_ >= 2 && NH_ <= CADM_MAX_HIDDEN_LAYERS, "number of hidden layers");
     static constexpr int D = env_D(ENV), A = env_A(ENV), P = env_P(ENV);
     static constexpr int K0 = P + A + C;
     static constexpr int NC0 = (K0 + 31) / 32;            // chunks of layer 0
@@ -69,8 +74,18 @@ struct XC {
     // being held in ~26 registers across the MFMA sweeps
     static constexpr int TABW = 28;                                     // floats per (pair slot, fg) entry
     static constexpr int TAB = STATS + rup((2 * P + 2 * A) * 4, 16);
+    // One observation dim per thread (instead of a pair) for the state update of small observation spaces, one row tile:
+    // thread (row, d) with d = tid / 16 < D owns dim d, the LAST NP of the 32 dim slots make the Gaussian-head noise of one pair
+    // each.  The state update is one wave's dependent chain (softplus -> exp -> .. -> f16 split): half the dims per thread halve
+    // it, over 4.5 of the 8 waves instead of 2.25.  A row's arithmetic is unchanged (bit-identical to the pair layout).
+#ifndef CADM_XDL_ONED
+#define CADM_XDL_ONED 1
+#endif
+    static constexpr bool ONED = CADM_XDL_ONED && MT == 1 && NPI == 1 && D + NP <= 32 && A <= D;
+    static constexpr int TABD = 16;                                     // ONED: floats per dim entry
+    static constexpr int TAB_BYTES = ONED ? 32 * TABD * 4 : NPI * 16 * TABW * 4;
     // Gaussian-head noise, produced by waves 4-7 while waves 0-3 run the state update: [step parity][pair slot][fg][row] x 2
-    static constexpr int ZB = TAB + NPI * 16 * TABW * 4;
+    static constexpr int ZB = TAB + TAB_BYTES;
     static constexpr int ZB_T = 2 * NPI * 256 * 8;                      // bytes per row tile
     static constexpr int CTRL = ZB + MT * ZB_T;                         // + MT * 16 * H floats (dynamic)
     // Bias tiles (fp32, D layout) live in LDS when they fit next to the rest (a bias read from global memory in a tile's
@@ -96,15 +111,15 @@ struct XC {
     static constexpr bool ASM_MFMA = CADM_XDL_RES && NCH <= 8;     // asm MFMAs (AGPR-resident operands) vs builtins
     static constexpr int res_frags(int ntw) {      // (wide observations keep two pair slots of rollout state per thread)
         return (!CADM_XDL_RES || NCH > 8) ? 0
-               : MT > 1 ? (ntw >= 2 ? CADM_XDL_RES_FRAGS_X : CADM_XDL_RES_FRAGS) - (NPI > 1 ? 2 : 0) - CADM_XDL_RES_MT2_LESS
+               : MT > 1 ? (ntw >= 2 ? CADM_XDL_RES_FRAGS_X : CADM_XDL_RES_FRAGS) - (NPI > 1 ? 2 : 0) - CADM_XDL_RES_MT2_LESS - (NT >= 15 ? 1 : 0)
                         : (ntw == BASE ? CADM_XDL_RES_FRAGS : CADM_XDL_RES_FRAGS_X) - (NPI > 1 ? 2 : 0);
     }
-    static constexpr int MAX_NH_LDS = 4;
+    static constexpr int MAX_NH_LDS = NH_;
     static constexpr int BIAS_BYTES = (MAX_NH_LDS * NT + NTO) * 1024;
     static constexpr bool BIAS_LDS = CTRL + MT * 16 * 64 * 4 + BIAS_BYTES <= 154 * 1024;
     static constexpr int XDEPTH = MT > 1 ? 2 : 3;          // B-operand chunks in registers (lookahead XDEPTH - 1)
-    static size_t lds_bytes(int H, int NH) {               // dynamic LDS of a launch
-        return (size_t)CTRL + (size_t)rup(MT * 16 * H * 4, 16) + (BIAS_LDS ? (size_t)(NH * NT + NTO) * 1024 : 0);
+    static size_t lds_bytes(int H) {                       // dynamic LDS of a launch
+        return (size_t)CTRL + (size_t)rup(MT * 16 * H * 4, 16) + (BIAS_LDS ? (size_t)(NHC * NT + NTO) * 1024 : 0);
     }
 };
 
@@ -155,11 +170,16 @@ __device__ __forceinline__ void xmfma_ring(floatx4& acc, const uintx4& w, const 
 }
 // Hazard padding the compiler cannot place for asm MFMAs.  The accumulators are "+v" operands of the padding statement,
 // so every instruction that defines them (the zeroing moves) stays before it and every reader (the epilogue) after it.
+// (the third accumulator exists only with 4 products per block: naming it here would keep 4 dead registers per tile alive)
+template <bool LL>
 __device__ __forceinline__ void xdl_result_nops(floatx4& a, floatx4& b, floatx4& c) {      // XDL write -> VALU read (4-pass op)
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c));
+    if constexpr (LL) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b), "+v"(c));
+    else asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(a), "+v"(b));
 }
+template <bool LL>
 __device__ __forceinline__ void xdl_operand_nops(floatx4& a, floatx4& b, floatx4& c) {     // VALU write -> XDL read as srcC
-    asm volatile("s_nop 4" : "+v"(a), "+v"(b), "+v"(c));
+    if constexpr (LL) asm volatile("s_nop 4" : "+v"(a), "+v"(b), "+v"(c));
+    else asm volatile("s_nop 4" : "+v"(a), "+v"(b));
 }
 
 // split an fp32 value for the f16 pipe: hi = f16(v), lo = f16((v - hi) * 2^11)
@@ -194,17 +214,31 @@ struct XHiddenEpi {
                 float pre = fmaf(lo[r], 4.8828125e-4f, hi[r]);
                 if constexpr (G::NPROD == 4) pre = fmaf(ll[r], 2.384185791015625e-7f, pre);
                 st.v[r] = fminf(pre, 60000.0f);
-                st.s[r] = st.v[r] * -1.4426950408889634f;
+                st.s[r] = st.v[r] * (G::ACT == CADM_ACT_TANH ? -2.0f * 1.4426950408889634f : -1.4426950408889634f);
             }
         } else if constexpr (S == 1) {
+            if constexpr (G::ACT != CADM_ACT_RELU && G::ACT != CADM_ACT_NONE) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) st.s[r] = __builtin_amdgcn_exp2f(st.s[r]);
+                for (int r = 0; r < 4; ++r) st.s[r] = __builtin_amdgcn_exp2f(st.s[r]);
+            }
         } else if constexpr (S == 2) {
+            if constexpr (G::ACT != CADM_ACT_RELU && G::ACT != CADM_ACT_NONE) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) st.s[r] = __builtin_amdgcn_rcpf(1.0f + st.s[r]);
-        } else if constexpr (S == 3) {     // swish (dynamics.py:23) and the high f16 part
+                for (int r = 0; r < 4; ++r) st.s[r] = __builtin_amdgcn_rcpf(1.0f + st.s[r]);
+            }
+        } else if constexpr (S == 3) {     // the nonlinearity (dynamics.py:17-24) and the high f16 part
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { st.v[r] = st.v[r] * st.s[r]; st.h1[r] = (_Float16)st.v[r]; }
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (G::ACT == CADM_ACT_SWISH) st.v[r] = st.v[r] * st.s[r];                 // x * sigmoid(x), :23
+                else if constexpr (G::ACT == CADM_ACT_SIGMOID) st.v[r] = st.s[r];                    // 1 / (1 + e^-x)
+                else if constexpr (G::ACT == CADM_ACT_TANH) {      // 2 sigmoid(2x) - 1 (s was built from 2x); odd series near 0, where that cancels
+                    const float x = st.v[r], x2 = x * x;
+                    const float ser = x * fmaf(x2, fmaf(x2, fmaf(x2, -0.05396825396825397f, 0.13333333333333333f), -0.3333333333333333f), 1.0f);
+                    st.v[r] = fabsf(x) < 0.1f ? ser : fmaf(2.0f, st.s[r], -1.0f);
+                } else if constexpr (G::ACT == CADM_ACT_RELU) st.v[r] = fmaxf(st.v[r], 0.0f);
+                else if constexpr (G::ACT == CADM_ACT_NONE) st.v[r] = fmaxf(st.v[r], -60000.0f);       // f16 range, both sides
+                st.h1[r] = (_Float16)st.v[r];
+            }
         } else if constexpr (S == 4) {     // low part: (h - hi) * 2^11, exact in fp32
 #pragma unroll
             for (int r = 0; r < 4; ++r) st.h2[r] = (_Float16)fmaf((float)st.h1[r], -2048.0f, st.v[r] * 2048.0f);
@@ -296,7 +330,7 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
 #pragma unroll
         for (int k = 0; k < gs; ++k)
 #pragma unroll
-            for (int h = 0; h < MT; ++h) xdl_operand_nops(hi[gp][k][h], lo[gp][k][h], ll[gp][k][h]);      // VALU-zeroed accumulators -> MFMA srcC
+            for (int h = 0; h < MT; ++h) xdl_operand_nops<G::NPROD == 4>(hi[gp][k][h], lo[gp][k][h], ll[gp][k][h]);      // VALU-zeroed accumulators -> MFMA srcC
         static_for(std::make_integer_sequence<int, NCHL>{}, [&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int j0 = GS * g * NCHL + c * gs;
@@ -334,7 +368,7 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
 #pragma unroll
             for (int k = 0; k < gs; ++k)
 #pragma unroll
-                for (int h = 0; h < MT; ++h) xdl_result_nops(hi[gp][k][h], lo[gp][k][h], ll[gp][k][h]);
+                for (int h = 0; h < MT; ++h) xdl_result_nops<G::NPROD == 4>(hi[gp][k][h], lo[gp][k][h], ll[gp][k][h]);
             static_for(std::make_integer_sequence<int, NST>{}, [&](auto sc) {
 #pragma unroll
                 for (int k = 0; k < gs; ++k)
@@ -355,6 +389,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     constexpr int D = G::D, A = G::A, P = G::P, C = G::C, K0 = G::K0, NC0 = G::NC0, NCH = G::NCH, NTO = G::NTO;
     constexpr int NP = G::NP, NPI = G::NPI, NAI = G::NAI, ENV = G::ENV, R = G::R;
     constexpr int MT = G::MT;
+    constexpr int XNH = G::NHC;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -364,7 +399,10 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     const int arow = tid & 15, fg = (tid >> 4) & 15;
     // feature threads (rollout state, input assembly): MT = 1: waves 0-3, their twins in waves 4-7 make the noise;
     // MT = 2: everybody -- waves 0-3 hold row tile 0, waves 4-7 row tile 1, and make their own noise
-    const bool feat = MT > 1 || wave < 4;
+    constexpr bool ONED = G::ONED;
+    const int sd = tid >> 4;                                    // ONED: dim slot 0..31 of this thread (arow = its row)
+    const bool feat = ONED ? sd < D : (MT > 1 || wave < 4);
+    const bool nzt = ONED && sd >= 32 - NP;                     // ONED: noise thread of pair sd - (32 - NP)
     const int rt = MT > 1 ? (wave >> 2) : 0;                   // row tile of this thread's state
     const int ntiles = a.tile_count;                            // row tiles of this launch: [tile0, tile0 + tile_count) of the member
     float* stats = reinterpret_cast<float*>(xsmem + G::STATS);
@@ -387,7 +425,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     for (int i = tid; i < (G::OFULL - G::XIN) / 16; i += G::NTHR) reinterpret_cast<uintx4*>(xsmem + G::XIN)[i] = uintx4{0u, 0u, 0u, 0u};
     if (bias_lds) {
         const uintx4* src = reinterpret_cast<const uintx4*>(a.xb + (size_t)(blockIdx.x / a.wgs_per_member) * a.xb_member);
-        for (int i = tid; i < (a.NH * G::NT + NTO) * 64; i += G::NTHR) reinterpret_cast<uintx4*>(xsmem + bias_off)[i] = src[i];
+        for (int i = tid; i < (XNH * G::NT + NTO) * 64; i += G::NTHR) reinterpret_cast<uintx4*>(xsmem + bias_off)[i] = src[i];
     }
 
     // byte offset (part 0) of input feature f of row 0 inside x_in; row arow adds arow * 16
@@ -395,7 +433,27 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     const int arow16 = arow * 16;
     auto xin_off = [&](int f) { return xin_base(f) + arow16; };
     float* tab = reinterpret_cast<float*>(xsmem + G::TAB);
-    if (arow == 0 && wave < 4) {
+    if constexpr (ONED) {
+        if (arow == 0 && sd < D) {      // per-dim constants: head statistics, the (up to two) input features this dim feeds
+            float* te = tab + sd * G::TABD;
+            te[0] = a.delta_mean[sd];
+            te[1] = a.delta_std[sd] + 1e-10f;
+            te[2] = 2.0f * logf(a.delta_std[sd]);                       // core/utils.py:360
+            te[3] = a.maxlv[sd];
+            te[4] = a.minlv[sd];
+            int ff[2], fop[2];
+            const int nf = dim_feats<ENV>(sd, ff, fop);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool on = i < nf;
+                const int f = on ? ff[i] : 0;
+                te[5 + i] = a.obs_mean[f];
+                te[7 + i] = 1.0f / (a.obs_std[f] + 1e-10f);
+                te[9 + i] = __builtin_bit_cast(float, on ? xin_base(f) : -1);
+                te[11 + i] = __builtin_bit_cast(float, on ? fop[i] : 0);
+            }
+        }
+    } else if (arow == 0 && wave < 4) {
 #pragma unroll
         for (int pi = 0; pi < NPI; ++pi) {
             float* te = tab + (pi * 16 + fg) * G::TABW;
@@ -448,7 +506,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     const int nhead = ht < NTO ? 1 : 0;
     const int l0_nf = my_ntw * NC0, lh_nf = my_ntw * NCH, hd_nf = nhead * NCH;
     const unsigned w_l0 = wbase, w_h1 = w_l0 + l0_nf * CADM_XDL_FRAG_BYTES;
-    const unsigned w_hd = w_h1 + (a.NH - 1) * lh_nf * CADM_XDL_FRAG_BYTES;
+    const unsigned w_hd = w_h1 + (XNH - 1) * lh_nf * CADM_XDL_FRAG_BYTES;
 
     // layer ids: 0 = layer 0, 1 .. NH-1 = hidden, NH = head.
     // Register-resident fragments (never re-read from L2): the whole head tile on the waves that have one and registers to
@@ -462,14 +520,14 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     constexpr int Q1 = cmin((RREM + 2) / 3, NFH), Q2 = cmin((RREM - Q1 + 1) / 2, NFH), Q3 = cmin(RREM - Q1 - Q2, NFH);
     constexpr int NRESH = Q1 + Q2 + Q3;
     auto hq = [&](int l) { return l == 1 ? Q1 : l == 2 ? Q2 : l == 3 ? Q3 : 0; };
-    auto lay_res = [&](int l) { return l == 0 ? 0 : l < a.NH ? hq(l) : RESO ? hd_nf : 0; };
+    auto lay_res = [&](int l) { return l == 0 ? 0 : l < XNH ? hq(l) : RESO ? hd_nf : 0; };
     auto lay_off = [&](int l) {          // first streamed fragment of layer l
-        return (l == 0 ? w_l0 : l < a.NH ? w_h1 + (l - 1) * lh_nf * CADM_XDL_FRAG_BYTES : w_hd) + lay_res(l) * CADM_XDL_FRAG_BYTES;
+        return (l == 0 ? w_l0 : l < XNH ? w_h1 + (l - 1) * lh_nf * CADM_XDL_FRAG_BYTES : w_hd) + lay_res(l) * CADM_XDL_FRAG_BYTES;
     };
-    auto lay_nf = [&](int l) { return (l == 0 ? l0_nf : l < a.NH ? lh_nf : hd_nf) - lay_res(l); };
+    auto lay_nf = [&](int l) { return (l == 0 ? l0_nf : l < XNH ? lh_nf : hd_nf) - lay_res(l); };
     auto next_streamed = [&](int l) {    // next layer (cyclically over steps) with a streamed part
-        for (int k = 0; k <= a.NH; ++k) {
-            l = l == a.NH ? 0 : l + 1;
+        for (int k = 0; k <= XNH; ++k) {
+            l = l == XNH ? 0 : l + 1;
             if (lay_nf(l) > 0) break;
         }
         return l;                         // (nothing streamed at all: a layer with lay_nf = 0, no loads are issued for it)
@@ -479,7 +537,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         constexpr int q = decltype(qc)::value;
         constexpr int l = q < Q1 ? 1 : q < Q1 + Q2 ? 2 : 3, ql = q - (l == 1 ? 0 : l == 2 ? Q1 : Q1 + Q2);
         // (a layer the model does not have loads in-bounds garbage that is never used)
-        const unsigned so = l < a.NH ? w_h1 + ((l - 1) * lh_nf + ql) * CADM_XDL_FRAG_BYTES : wbase;
+        const unsigned so = l < XNH ? w_h1 + ((l - 1) * lh_nf + ql) * CADM_XDL_FRAG_BYTES : wbase;
         xres_load(resH[q][0], rsrc, lane * 16, so);
         xres_load(resH[q][1], rsrc, lane * 16 + 1024, so);
     });
@@ -495,7 +553,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     if constexpr (NRESH > 0 || RESO) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     XRing<G> ring;
     {
-        const int first = next_streamed(a.NH);
+        const int first = next_streamed(XNH);
         const unsigned fo = lay_off(first);
         const int fn = lay_nf(first);
         static_for(std::make_integer_sequence<int, R>{}, [&](auto sc) {
@@ -522,6 +580,15 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         else ctx_off = (ep * a.m + mi) * C;                              // Q1: encoder j % E
 
         float po[NPI][2], areg[NAI];
+        if constexpr (ONED) {
+            po[0][0] = feat ? (a.obs_rows ? a.obs_rows[(size_t)lr * D + sd] : a.obs[mi * D + sd]) : 0.0f;      // :432
+            po[0][1] = 0.0f;
+            areg[0] = sd < A ? a.actions[abase + sd] : 0.0f;
+            if constexpr (C > 0) {
+                for (int f = P + A + sd; f < K0; f += 32) put_x(xin_off(f), a.ctx_vec[ctx_off + f - P - A]);      // static: context (:433-439)
+            }
+            for (int t = sd; t < H; t += 32) ctrl_s[arow * H + t] = ctrl_term<ENV>(a.actions + abase + t * A, A);
+        } else {
 #pragma unroll
         for (int pi = 0; pi < NPI; ++pi)
 #pragma unroll
@@ -541,10 +608,11 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
             }
             for (int t = fg; t < H; t += 16) ctrl_s[arow * H + t] = ctrl_term<ENV>(a.actions + abase + t * A, A);
         }
+        }
         auto gen_noise = [&](int t) {
 #pragma unroll
             for (int pi = 0; pi < NPI; ++pi) {
-                const int dp = fg + 16 * pi;
+                const int dp = ONED ? sd - (32 - NP) : fg + 16 * pi;      // (ONED: called by the noise threads only)
                 if (dp >= NP) continue;                   // (wave-uniform for whole waves of unused pair slots)
                 float2 z;
                 if constexpr (NOISE == CADM_NOISE_INJECT) {
@@ -557,7 +625,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                     philox_rounds<0, 10>(pc, pk);
                     box_muller(u01(pc[0]), u01(pc[1]), z.x, z.y);
                 }
-                zb[((t & 1) * NPI + pi) * 256 + fg * 16 + arow] = z;
+                zb[((t & 1) * NPI + pi) * 256 + (dp & 15) * 16 + arow] = z;
             }
         };
         __syncthreads();
@@ -565,7 +633,61 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
 
         for (int t = 0; t <= H; ++t) {
             // ===== state update from step t-1's head (:348-365,463-466) + reward (:469-471) + input assembly (:442-460) =====
-            if (feat) {
+            if constexpr (ONED) {
+                // one observation dim per thread: thread (arow, sd) owns dim sd of its row; its pair partner is 16 lanes up
+                const int dp = sd >> 1, hh = sd & 1;
+                if (feat) {
+                    floatx4 tq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) tq[q] = *reinterpret_cast<const floatx4*>(tab + sd * G::TABD + 4 * q);
+                    auto tv = [&](int w) { return tq[w >> 2][w & 3]; };
+                    auto ti_ = [&](int w) { const float fv = tq[w >> 2][w & 3]; return __float_as_int(fv); };
+                    if (t > 0) {
+                        const int jt = dp >> 2, lt = (dp & 3) * 16 + arow;
+                        const float* vp = ofull + (jt * 64 + lt) * 4;                            // (mu0, mu1, lv0, lv1) of the pair
+                        float delta = vp[hh] * tv(1) + tv(0);                                    // denormalize, :349
+                        if constexpr (NOISE != CADM_NOISE_NONE) {
+                            const float z = reinterpret_cast<const float*>(zb + ((t - 1) & 1) * 256 + dp * 16 + arow)[hh];
+                            float lv = tv(3) - softplus_fast(tv(3) - vp[2 + hh]);               // :356
+                            lv = tv(4) + softplus_fast(lv - tv(4));                              // :357
+                            const float sdv = __expf((lv + tv(2)) * 0.5f);                       // :360-363
+                            delta = delta + z * sdv;                                             // :365
+                        }
+                        po[0][0] = postproc<ENV>(sd, po[0][0], delta);                           // :466
+                        if (a.traj && valid) a.traj[((size_t)(t - 1) * a.m * a.n_local * a.p + lr) * D + sd] = po[0][0];
+                    }
+                    if (t < H) {
+                        float sn = 0.0f, cs = 0.0f;
+                        if constexpr (ENV == CADM_ENV_HALFCHEETAH) {                             // the one trig pair (obs dim 2)
+                            if (ti_(11) != 0) sincos_cw(po[0][0], &sn, &cs);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const int off = ti_(9 + i), op = ti_(11 + i);
+                            if (off >= 0) {
+                                const float pv = op == 1 ? sn : op == 2 ? cs : po[0][0];
+                                put_x(off + arow16, (pv - tv(5 + i)) * tv(7 + i));               // :450-451
+                            }
+                        }
+                        if (sd < A) {
+                            float v = areg[0];
+                            if (a.norm_actions) v = (v - stats[G::ST_ACT_MEAN + sd]) * stats[G::ST_ACT_DEN + sd];   // :443
+                            put_x(xin_off(P + sd), v);
+                            if (t + 1 < H) areg[0] = a.actions[abase + (t + 1) * A + sd];
+                        }
+                    }
+                }
+                // reward of the pair (dims 2dp, 2dp+1): the even dim's thread adds it, reading its partner's dim 16 lanes up
+                // (every lane of the wave takes part in the exchange; an env whose reward reads one dim compiles it away)
+                const float o1 = __shfl_down(po[0][0], 16);
+                if (feat && hh == 0) {
+                    if constexpr (ENV == CADM_ENV_CARTPOLE) {
+                        if (t > 0) ret += reward_part<ENV>(dp, po[0][0], o1, 0.0f);              // reads NEXT obs
+                    } else {
+                        if (t < H) ret += reward_part<ENV>(dp, po[0][0], o1, ctrl_s[arow * H + t]);
+                    }
+                }
+            } else if (feat) {
 #pragma unroll
             for (int pi = 0; pi < NPI; ++pi) {
                 const int dp = fg + 16 * pi;
@@ -641,7 +763,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
             // the state.  Two row tiles: every thread owns state and makes its own noise, but not here, where it would
             // lengthen the state phase that everything waits for -- see the hidden layers / the head below.
             if constexpr (NOISE != CADM_NOISE_NONE && MT == 1) {
-                if (!feat) gen_noise(t);
+                if (ONED ? nzt : !feat) gen_noise(t);
             }
             TS(0)
             __syncthreads();
@@ -679,20 +801,20 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                     TS(5)
                 };
                 using IC0 = std::integral_constant<int, 0>;
-                if (1 < a.NH) hidden(1, std::integral_constant<int, Q1>{}, IC0{});
-                if (2 < a.NH) hidden(2, std::integral_constant<int, Q2>{}, std::integral_constant<int, Q1>{});
-                if (3 < a.NH) hidden(3, std::integral_constant<int, Q3>{}, std::integral_constant<int, Q1 + Q2>{});
-                for (int l = 4; l < a.NH; ++l) hidden(l, IC0{}, IC0{});
+                if (1 < XNH) hidden(1, std::integral_constant<int, Q1>{}, IC0{});
+                if (2 < XNH) hidden(2, std::integral_constant<int, Q2>{}, std::integral_constant<int, Q1>{});
+                if (3 < XNH) hidden(3, std::integral_constant<int, Q3>{}, std::integral_constant<int, Q1 + Q2>{});
+                for (int l = 4; l < XNH; ++l) hidden(l, IC0{}, IC0{});
                 act_in = act_out;
                 // two row tiles: the waves without a head tile make their noise while the others run the head
                 if constexpr (NOISE != CADM_NOISE_NONE && MT > 1) {
-                    if (!nhead || a.NH < 2) gen_noise(t);
+                    if (!nhead || XNH < 2) gen_noise(t);
                 }
                 // ================= output head tile (mu | logvar of 8 dims) =================
                 if (nhead) {
-                    const int nx = next_streamed(a.NH);
-                    xdl_sweep<G, 1, NCH, RESO ? NCH : 0, 1, false>(ring, resO, rsrc, lay_off(a.NH), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
-                                                         XHeadEpi<G>{xsmem, xb, bias_off, a.NH * G::NT + ht, ht, lane} TS_ARGS);
+                    const int nx = next_streamed(XNH);
+                    xdl_sweep<G, 1, NCH, RESO ? NCH : 0, 1, false>(ring, resO, rsrc, lay_off(XNH), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
+                                                         XHeadEpi<G>{xsmem, xb, bias_off, XNH * G::NT + ht, ht, lane} TS_ARGS);
                 }
             }
             TS(6)
@@ -702,16 +824,30 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         TS_DUMP
 
         // ---- a row's return = sum of its threads' reward parts, in fixed slot order ----
-        float* ret_s = ofull;                      // (this row tile's head buffer, free between tiles)
         __syncthreads();
-        if (feat) ret_s[arow * 16 + fg] = ret;
-        ret = 0.0f;
-        __syncthreads();
-        if (feat && fg == 0 && valid) {
-            float r = 0.0f;
+        if constexpr (ONED) {
+            // 32 dim slots per row; pair slot i = (2i, 2i+1): the same 16 partial sums, added in the same order, as the pair layout
+            float* ret_s = reinterpret_cast<float*>(xsmem + G::ACTA);      // (activation buffer, free between tiles)
+            ret_s[arow * 32 + sd] = ret;
+            ret = 0.0f;
+            __syncthreads();
+            if (sd == 0 && valid) {
+                float r = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) r += ret_s[arow * 16 + i];
-            a.returns_rows[lr] = r;
+                for (int i = 0; i < 16; ++i) r += ret_s[arow * 32 + 2 * i] + ret_s[arow * 32 + 2 * i + 1];
+                a.returns_rows[lr] = r;
+            }
+        } else {
+            float* ret_s = ofull;                      // (this row tile's head buffer, free between tiles)
+            if (feat) ret_s[arow * 16 + fg] = ret;
+            ret = 0.0f;
+            __syncthreads();
+            if (feat && fg == 0 && valid) {
+                float r = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) r += ret_s[arow * 16 + i];
+                a.returns_rows[lr] = r;
+            }
         }
         __syncthreads();
     }
@@ -747,10 +883,10 @@ int xdl_launch_noise(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, h
     if (per_member < 1) per_member = 1;
     args.wgs_per_member = tiles < per_member ? tiles : per_member;
     args.rows_per_member = rows_per_member;
-    const size_t lds = G::lds_bytes(a.H, a.NH);
+    const size_t lds = G::lds_bytes(a.H);
     args.bias_lds = G::BIAS_LDS;
     if (lds > 160 * 1024) {
-        cadm_set_error("rollout: horizon %d with %d hidden layers needs %zu B of LDS (> 160 KiB)", a.H, a.NH, lds);
+        cadm_set_error("rollout: horizon %d with %d hidden layers of %d units needs %zu B of LDS (> 160 KiB)", a.H, G::NHC, G::HID, lds);
         return CADM_EINVAL;
     }
     const void* fn = reinterpret_cast<const void*>(&rollout_xdl_kernel<G, NOISE>);
@@ -758,24 +894,35 @@ int xdl_launch_noise(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, h
         CADM_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->attr_done.insert(fn);
     }
+    if (a.dry_run) return CADM_OK;            // cadm_rollout_check: geometry / LDS validation only
     hipLaunchKernelGGL((rollout_xdl_kernel<G, NOISE>), dim3(args.wgs_per_member * ctx->E), dim3(G::NTHR), lds, s, args);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
 }
 
-template <class G>
+// NOISE < 0: all three noise modes of the geometry (the library's compiled-in set); else only that one (a JIT module is built
+// per noise mode, in parallel / on first use: rollout_jit.hip)
+template <class G, int NOISE>
 int xdl_launch_mt(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipStream_t s) {
-    if (a.deterministic) return xdl_launch_noise<G, CADM_NOISE_NONE>(ctx, a, rows_per_member, s);
-    if (a.eps) return xdl_launch_noise<G, CADM_NOISE_INJECT>(ctx, a, rows_per_member, s);
-    return xdl_launch_noise<G, CADM_NOISE_PHILOX>(ctx, a, rows_per_member, s);
+    const int mode = a.deterministic ? CADM_NOISE_NONE : a.eps ? CADM_NOISE_INJECT : CADM_NOISE_PHILOX;
+    if constexpr (NOISE >= 0) {
+        if (mode != NOISE) { cadm_set_error("rollout: this module holds noise mode %d, the launch needs %d", NOISE, mode); return CADM_EINVAL; }
+        return xdl_launch_noise<G, NOISE>(ctx, a, rows_per_member, s);
+    } else {
+        if (mode == CADM_NOISE_NONE) return xdl_launch_noise<G, CADM_NOISE_NONE>(ctx, a, rows_per_member, s);
+        if (mode == CADM_NOISE_INJECT) return xdl_launch_noise<G, CADM_NOISE_INJECT>(ctx, a, rows_per_member, s);
+        return xdl_launch_noise<G, CADM_NOISE_PHILOX>(ctx, a, rows_per_member, s);
+    }
 }
 
 // Two row tiles per workgroup once every workgroup has at least two tiles to walk over.  The member's tiles are then cut
 // in two launches so that no workgroup idles through a whole two-tile round: the first takes as many FULL rounds of tile
 // pairs as there are (every workgroup the same number), the second the remainder -- as single tiles (one-tile flavour) if
 // they fit one round, else as one more round of pairs.  Rows are independent, so the cut does not change any result.
-template <int ENV, int C, int HID>
+template <int ENV, int C, int HID, int NH, int ACT, int NOISE = -1>
 int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a0, int rows_per_member, hipStream_t s) {
+    using G1 = XC<ENV, C, HID, 1, NH, ACT>;
+    using G2 = XC<ENV, C, HID, 2, NH, ACT>;
     RolloutArgs a = a0;
     const int tiles = (rows_per_member + 15) / 16;
     int per_member = ctx->n_cus / ctx->E;
@@ -785,17 +932,17 @@ int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a0, int rows_per_member, hipStr
     int flavour = tiles >= 2 * per_member ? 2 : 1;
     if (ctx->dev_force_mt) flavour = ctx->dev_force_mt == 2 ? -2 : -1;       // developer library only (dev/dev_api.hip): one launch, forced flavour
     // (wide layers / long horizons: two tiles' activation buffers do not fit the 160 KiB of LDS -- one tile per workgroup then)
-    if (XC<ENV, C, HID, 2>::lds_bytes(a0.H, a0.NH) > 160 * 1024) flavour = flavour < 0 ? -1 : 1;
-    if (flavour == 1 || flavour == -1) return xdl_launch_mt<XC<ENV, C, HID, 1>>(ctx, a, rows_per_member, s);
-    if (flavour == -2) return xdl_launch_mt<XC<ENV, C, HID, 2>>(ctx, a, rows_per_member, s);
+    if (G2::lds_bytes(a0.H) > 160 * 1024) flavour = flavour < 0 ? -1 : 1;
+    if (flavour == 1 || flavour == -1) return xdl_launch_mt<G1, NOISE>(ctx, a, rows_per_member, s);
+    if (flavour == -2) return xdl_launch_mt<G2, NOISE>(ctx, a, rows_per_member, s);
     const int full = (tiles / (2 * per_member)) * 2 * per_member;         // tiles in full rounds of pairs
     a.tile_count = full;
-    int rc = xdl_launch_mt<XC<ENV, C, HID, 2>>(ctx, a, rows_per_member, s);
+    int rc = xdl_launch_mt<G2, NOISE>(ctx, a, rows_per_member, s);
     if (rc || full == tiles) return rc;
     a.tile0 = full;
     a.tile_count = tiles - full;
-    return a.tile_count <= per_member ? xdl_launch_mt<XC<ENV, C, HID, 1>>(ctx, a, rows_per_member, s)
-                                      : xdl_launch_mt<XC<ENV, C, HID, 2>>(ctx, a, rows_per_member, s);
+    return a.tile_count <= per_member ? xdl_launch_mt<G1, NOISE>(ctx, a, rows_per_member, s)
+                                      : xdl_launch_mt<G2, NOISE>(ctx, a, rows_per_member, s);
 }
 
 }  // namespace

@@ -25,7 +25,7 @@
 
 namespace {
 
-enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
+enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_TANH = 3, ACT_SIGMOID = 4 };      // stage-table codes (see dyn_act)
 
 // Branch-free on the activation kind (uniform selects): v_exp_f32 / v_rcp_f32 sigmoid like the planner's swish_f.
 __device__ __forceinline__ float sigmoid_fast(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
@@ -39,6 +39,17 @@ __device__ __forceinline__ float act_bwd(int act, float z) {   // d act / d z
     const float sw = sg * (1.0f + z * (1.0f - sg));
     const float r = act == ACT_RELU ? (z > 0.0f ? 1.0f : 0.0f) : 1.0f;
     return act == ACT_SWISH ? sw : r;
+}
+
+// hidden nonlinearity of the dynamics nets (cadm_config.hidden_act, CADM_ACT_*) as a stage-table code
+static int dyn_act(const cadm_ctx* ctx) {
+    switch (ctx->cfg.hidden_act) {
+        case CADM_ACT_RELU: return ACT_RELU;
+        case CADM_ACT_TANH: return ACT_TANH;
+        case CADM_ACT_SIGMOID: return ACT_SIGMOID;
+        case CADM_ACT_NONE: return ACT_NONE;
+        default: return ACT_SWISH;
+    }
 }
 
 __device__ __forceinline__ void adam_update(float& w, float& m, float& v, float g, float lr_t, float b1, float b2,
@@ -344,6 +355,16 @@ __device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, i
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v0[j][r] = zp[j][r] > 0.0f ? v0[j][r] : 0.0f;
+        } else if (act_d == ACT_TANH) {          // 1 - tanh(z)^2 = 4 s (1 - s), s = sigmoid(2z)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float sg = sigmoid_fast(2.0f * zp[j][r]); v0[j][r] *= 4.0f * sg * (1.0f - sg); }
+        } else if (act_d == ACT_SIGMOID) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float sg = sigmoid_fast(zp[j][r]); v0[j][r] *= sg * (1.0f - sg); }
         }
     }
     if (act_o == ACT_SWISH) {
@@ -356,6 +377,20 @@ __device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, i
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v1[j][r] = fmaxf(v0[j][r], 0.0f);
+    } else if (act_o == ACT_TANH) {              // as the planner: 2 sigmoid(2z) - 1, odd series near 0 where that cancels
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = v0[j][r], x2 = x * x;
+                const float ser = x * fmaf(x2, fmaf(x2, fmaf(x2, -0.05396825396825397f, 0.13333333333333333f), -0.3333333333333333f), 1.0f);
+                v1[j][r] = fabsf(x) < 0.1f ? ser : fmaf(2.0f, sigmoid_fast(2.0f * x), -1.0f);
+            }
+    } else if (act_o == ACT_SIGMOID) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v1[j][r] = sigmoid_fast(v0[j][r]);
     } else {
 #pragma unroll
         for (int j = 0; j < NT; ++j) v1[j] = v0[j];
@@ -1116,7 +1151,7 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
         for (int l = 0; l < NH; ++l) {
             ChainStage g{};
             g.kind = ST_GEMM; g.N = HID; g.nparts = 1; g.part[0] = part_of(net[l], 0, 0, net[l].din, cur);
-            g.bias = net[l].b; g.act_o = ACT_SWISH; g.out0 = nb.z[l]; g.out1 = nb.h[l]; g.ldo = HID; g.dst = cur ^ 1;
+            g.bias = net[l].b; g.act_o = dyn_act(ctx); g.out0 = nb.z[l]; g.out1 = nb.h[l]; g.ldo = HID; g.dst = cur ^ 1;
             push_gemm(g);
             cur ^= 1;
         }
@@ -1135,14 +1170,14 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
             g.kind = ST_GEMM; g.N = HID; g.nparts = dLv ? 2 : 1;
             g.part[0] = part_of(net[NH], 1, 0, D, 0);
             if (dLv) g.part[1] = part_of(net[NH + 1], 1, 0, D, 1);
-            g.zprev = nb.z[NH - 1]; g.ldz = HID; g.act_d = ACT_SWISH; g.out1 = nb.dz[NH - 1]; g.ldo = HID; g.dst = 2;
+            g.zprev = nb.z[NH - 1]; g.ldz = HID; g.act_d = dyn_act(ctx); g.out1 = nb.dz[NH - 1]; g.ldo = HID; g.dst = 2;
             push_gemm(g);
         }
         int cur = 2;
         for (int l = NH - 1; l >= 1; --l) {
             ChainStage g{};
             g.kind = ST_GEMM; g.N = net[l].din; g.nparts = 1; g.part[0] = part_of(net[l], 1, 0, net[l].dout, cur);
-            g.zprev = nb.z[l - 1]; g.ldz = HID; g.act_d = ACT_SWISH; g.out1 = nb.dz[l - 1]; g.ldo = HID; g.dst = (cur + 1) % 3;
+            g.zprev = nb.z[l - 1]; g.ldz = HID; g.act_d = dyn_act(ctx); g.out1 = nb.dz[l - 1]; g.ldo = HID; g.dst = (cur + 1) % 3;
             push_gemm(g);
             cur = (cur + 1) % 3;
         }

@@ -147,10 +147,10 @@ class MLPEnsembleCEMDynamicsModel(object):
 
         if hidden_nonlinearity not in _ACTIVATIONS or output_nonlinearity not in _ACTIVATIONS:
             raise KeyError("unknown nonlinearity %r / %r" % (hidden_nonlinearity, output_nonlinearity))
-        if hidden_nonlinearity != "swish" or output_nonlinearity is not None:
+        if hidden_nonlinearity == "softmax" or output_nonlinearity is not None:
             raise NotImplementedError(
-                "the HIP kernels fuse hidden_nonlinearity='swish' and output_nonlinearity=None "
-                "(the only setting run_cadm_pets.py / run_pets.py use); got %r / %r"
+                "the HIP kernels implement hidden_nonlinearity in (swish, relu, tanh, sigmoid, None) and "
+                "output_nonlinearity=None (run_cadm_pets.py / run_pets.py pass swish / None); got %r / %r"
                 % (hidden_nonlinearity, output_nonlinearity))
         # context_hidden_nonlinearity is accepted and ignored exactly like the reference
         # (always ReLU: dynamics.py:49 vs :141-156, layers.py:34).
@@ -201,12 +201,17 @@ class MLPEnsembleCEMDynamicsModel(object):
                                 deterministic=deterministic, discrete=self.discrete,
                                 reference_quirks=reference_quirks, history_length=history_length,
                                 cp_hidden_sizes=cp_hidden_sizes, back_model=back_coeff > 0.0, device=device,
+                                hidden_nonlinearity=hidden_nonlinearity,
                                 lib=engine_lib)      # engine_lib: developer builds only (tools/ab.sh); None = the product library
         # tf.global_variables_initializer() equivalent (mb_trainer.py:164)
         self.engine.init_weights(np.random.default_rng(self.seed))
         self._train_ready = False
         self._stats_dirty = True
         self._dist_failed = False
+        # The rollout kernel is compiled per geometry: the reference defaults are in the library, anything else
+        # (`--hidden_size`, `--context_out_dim`, depth, nonlinearity) is built now (cadm_amd.jit, ~30 s once, then cached),
+        # and a launch that cannot fit the hardware (LDS for this horizon) raises here -- not at the first get_action.
+        self.engine.ensure_rollout(None, 1, max(1, n_candidates))
 
     # ------------------------------------------------------------------ planning
     def _push_stats(self):

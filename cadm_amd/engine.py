@@ -41,7 +41,8 @@ def ctx_param_names(n_cp_hidden):
 class HipEngine:
     def __init__(self, env_kind, E, p, D, A, P, C, hidden_sizes, H, deterministic=False, discrete=False,
                  reference_quirks=True, history_length=10, cp_hidden_sizes=(256, 128, 64), back_model=False,
-                 num_elites=50, num_cem_iters=5, alpha=0.1, lower_bound=-1.0, upper_bound=1.0, device=None, lib=None):
+                 num_elites=50, num_cem_iters=5, alpha=0.1, lower_bound=-1.0, upper_bound=1.0, device=None, lib=None,
+                 hidden_nonlinearity="swish"):
         if not torch.cuda.is_available():
             raise _lib.CadmError("no HIP device visible: the CaDM planner runs only on the GPU "
                                  "(libcadm_hip.so); there is no CPU fallback")
@@ -59,6 +60,10 @@ class HipEngine:
         self.deterministic, self.discrete = bool(deterministic), bool(discrete)
         self.back_model = bool(back_model)
         self.K0 = P + A + C
+        if hidden_nonlinearity not in _lib.ACT_KINDS:
+            raise NotImplementedError("hidden_nonlinearity %r: the kernels implement swish / relu / tanh / sigmoid / None" % (hidden_nonlinearity,))
+        self.hidden_nonlinearity, self.hidden_act = hidden_nonlinearity, _lib.ACT_KINDS[hidden_nonlinearity]
+        self._rollout_ready = set()
         cfg = Config()
         cfg.abi_version = _lib.ABI_VERSION
         cfg.env_kind = _lib.ENV_KINDS[env_kind]
@@ -74,6 +79,7 @@ class HipEngine:
         cfg.num_elites, cfg.num_cem_iters, cfg.alpha = num_elites, num_cem_iters, alpha
         cfg.lower_bound, cfg.upper_bound = lower_bound, upper_bound
         cfg.back_model = int(self.back_model)
+        cfg.hidden_act = self.hidden_act
         self.cfg = cfg
         self.num_elites, self.num_cem_iters = num_elites, num_cem_iters
         self._ctx = C_void_p()
@@ -243,6 +249,19 @@ class HipEngine:
         ptrs = (ct.c_void_p * 12)(*[a.ctypes.data_as(ct.c_void_p) for a in arrs])
         self._check(self.lib.cadm_set_norm_stats(self._ctx, ptrs, self.stream), "cadm_set_norm_stats")
 
+    # ------------------------------------------------------------------ rollout kernel for this geometry
+    def ensure_rollout(self, noise=None, m=1, n_local=1):
+        """The rollout kernel is compile-time specialised per geometry: make sure one exists for this engine (compiled in, or
+        built on demand by cadm_amd.jit -- ~30 s the first time, cached) and that a launch fits the hardware (LDS for this
+        horizon), so that a problem shows at construction, not at the first `get_action`."""
+        from . import jit
+        if noise is None:
+            noise = _lib.NOISE_NONE if self.deterministic else _lib.NOISE_PHILOX
+        if noise not in self._rollout_ready:
+            jit.ensure(self, noise)
+            self._check(self.lib.cadm_rollout_check(self._ctx, noise, int(m), int(n_local)), "cadm_rollout_check")
+            self._rollout_ready.add(noise)
+
     # ------------------------------------------------------------------ planner primitives
     def context_forward(self, cp_obs, cp_act, bs=False):
         cp_obs, cp_act = self._t(cp_obs), self._t(cp_act)
@@ -276,6 +295,7 @@ class HipEngine:
         ctx_vec = None if ctx_vec is None else self._t(ctx_vec)
         eps = None if eps is None else self._t(eps)
         obs_rows = None if obs_rows is None else self._t(obs_rows)
+        self.ensure_rollout(_lib.NOISE_NONE if self.deterministic else _lib.NOISE_INJECT if eps is not None else _lib.NOISE_PHILOX, m, n_local)
         rows = torch.empty((m, n_local, self.p), dtype=torch.float32, device=self.device)
         traj = (torch.empty((self.H, m, n_local, self.p, self.D), dtype=torch.float32, device=self.device)
                 if want_traj else None)
@@ -331,6 +351,7 @@ class HipEngine:
         cp_obs = None if cp_obs is None else self._t(cp_obs)
         cp_act = None if cp_act is None else self._t(cp_act)
         m = obs.shape[0]
+        self.ensure_rollout(None, m, max(1, n // self.dist_world))
         ws = self._workspace(m, n)
         if out is None:
             out = torch.empty((m, self.H, self.A), dtype=torch.float32, device=self.device)
@@ -343,6 +364,7 @@ class HipEngine:
         cp_obs = None if cp_obs is None else self._t(cp_obs)
         cp_act = None if cp_act is None else self._t(cp_act)
         m = obs.shape[0]
+        self.ensure_rollout(None, m, max(1, n // self.dist_world))
         ws = self._workspace(m, n)
         out = torch.empty((m, self.A), dtype=torch.float32, device=self.device)
         raw = torch.empty((m,), dtype=torch.int32, device=self.device) if self.discrete else None

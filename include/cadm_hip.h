@@ -34,6 +34,14 @@ extern "C" {
 #define CADM_ENOMEM (-2)      /* device allocation failed */
 #define CADM_EHIP (-3)        /* HIP runtime error (see cadm_last_error) */
 #define CADM_ESTATE (-4)      /* weights / stats not set */
+#define CADM_ENOTBUILT (-5)   /* no rollout kernel for this geometry in this build (cadm_amd.jit builds one: cadm_register_rollout) */
+
+/* hidden nonlinearity (the reference's `_activations` table, dynamics.py:17-24; ctor default relu :30, the scripts pass swish) */
+#define CADM_ACT_SWISH 0
+#define CADM_ACT_RELU 1
+#define CADM_ACT_TANH 2
+#define CADM_ACT_SIGMOID 3
+#define CADM_ACT_NONE 4
 
 /* env kinds: the closures obs_preproc / obs_postproc / tf_reward_fn that the reference
  * compiles into its graph (cadm/envs/<env>.py) are compiled into the kernels */
@@ -77,7 +85,8 @@ typedef struct cadm_config {
     float lower_bound;         /* -1  (core/utils.py:395) */
     float upper_bound;         /* +1  (core/utils.py:396) */
     int32_t back_model;        /* 1: backward model present (back_coeff > 0, dynamics.py:212) */
-    int32_t reserved[7];
+    int32_t hidden_act;        /* CADM_ACT_*: hidden_nonlinearity of both dynamics nets (dynamics.py:104; 0 = swish) */
+    int32_t reserved[6];
 } cadm_config;
 
 const char* cadm_last_error(void);
@@ -141,6 +150,18 @@ int cadm_rollout_returns(cadm_ctx* ctx, const float* obs, const float* obs_rows,
                          uint32_t seed, uint32_t call, int it,
                          int cand_offset, int n_global, int m, int n_local,
                          float* returns_rows, float* traj_out, void* stream);
+
+/* Rollout kernels are compile-time specialised per (env kind, hidden width, number of hidden layers, context width,
+ * nonlinearity).  The library carries the reference's defaults (4 x {128,200,256,512} swish, context 0 / 10); for anything else
+ * (`--hidden_size`, `--context_out_dim`, run_cadm_pets.py:122-135) the caller builds cadm_amd/csrc/rollout_jit.hip with hipcc
+ * (cadm_amd/jit.py does) and registers the module's entry point for a noise mode (0 device Philox, 1 injected eps, 2 deterministic).
+ *   cadm_rollout_builtin   1 if the ctx's geometry is compiled in, else 0
+ *   cadm_register_rollout  fn = the module's `cadm_jit_rollout`; describe = its `cadm_jit_describe` output (checked against the ctx)
+ *   cadm_rollout_check     validates that a rollout of m x n_local candidates can be launched (kernel present, LDS fits the
+ *                          horizon) WITHOUT launching -- construction-time instead of first-get_action failure */
+int cadm_rollout_builtin(cadm_ctx* ctx);
+int cadm_register_rollout(cadm_ctx* ctx, int noise_mode, void* fn, const int describe[8]);
+int cadm_rollout_check(cadm_ctx* ctx, int noise_mode, int m, int n_local);
 
 /* Mean over particles (core/utils.py:474): returns_rows [m,n_local,p] -> cand_returns [m,n_local]. */
 int cadm_particle_mean(cadm_ctx* ctx, const float* returns_rows, int m, int n_local,

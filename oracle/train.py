@@ -37,9 +37,12 @@ def _swish(x):
     return x * torch.sigmoid(x)
 
 
-def _mlp(p, x, n_hidden):
+_ACTS = {"swish": _swish, "relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, None: lambda x: x}   # dynamics.py:17-24
+
+
+def _mlp(p, x, n_hidden, act=_swish):
     for i in range(n_hidden):
-        x = _swish(torch.matmul(x, p["hidden_%d_weight" % i]) + p["hidden_%d_bias" % i])
+        x = act(torch.matmul(x, p["hidden_%d_weight" % i]) + p["hidden_%d_bias" % i])
     mu = torch.matmul(x, p["output_mu_weight"]) + p["output_mu_bias"]
     lv = torch.matmul(x, p["output_logvar_weight"]) + p["output_logvar_bias"]
     return mu, lv
@@ -105,7 +108,8 @@ def train_losses(env_name, ff, back, cp, st, batch, cfg):
             x = torch.relu(torch.matmul(x, cp["cp_hidden_%d_weight" % i]) + cp["cp_hidden_%d_bias" % i])
         ctx = torch.matmul(x, cp["cp_output_weight"]) + cp["cp_output_bias"]
         feats.append(ctx)
-    mu, lv = _mlp(ff, torch.cat(feats, -1), nh)
+    act = _ACTS[cfg.get("hidden_nonlinearity", "swish")]
+    mu, lv = _mlp(ff, torch.cat(feats, -1), nh, act)
     targ = _norm(batch["delta"], st["delta_mean"], st["delta_std"])
 
     def red(x):  # reduce_sum_e(reduce_mean_b(reduce_mean_d(.)))  dynamics.py:273-274
@@ -122,7 +126,7 @@ def train_losses(env_name, ff, back, cp, st, batch, cfg):
                   _norm(batch["act"], st["act_mean"], st["act_std"])]
         if ctx is not None:
             bfeats.append(ctx)
-        bmu, _ = _mlp(back, torch.cat(bfeats, -1), nh)
+        bmu, _ = _mlp(back, torch.cat(bfeats, -1), nh, act)
         btarg = _norm(batch["back_delta"], st["back_delta_mean"], st["back_delta_std"])
         back_mse = red((bmu - btarg) ** 2)                                   # :280-281
         l2 = l2 + _l2(back, dyn_weight_decays(cfg["weight_decays"], nh), dyn_l2_names(nh))  # :283,293

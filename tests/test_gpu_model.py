@@ -100,8 +100,10 @@ def test_cadm_random_shooting_and_errors(gpu):
     # empty batch of environments (m = 0): empty result, like the reference's dynamic-m graph
     assert model.get_action(o[:0], np.zeros((0, 180)), np.zeros((0, 60))).shape == (0, 6)
     assert model.get_action(o[:0], np.zeros((0, 180)), np.zeros((0, 60)), np.zeros((0, 8, 6)), np.zeros((0, 8, 6))).shape == (0, 8, 6)
+    with pytest.raises(NotImplementedError):       # a cross-feature nonlinearity / an output nonlinearity: not in the kernels
+        CaDMModel(**_cadm_kwargs(hidden_nonlinearity="softmax"))
     with pytest.raises(NotImplementedError):
-        CaDMModel(**_cadm_kwargs(hidden_nonlinearity="relu"))
+        CaDMModel(**_cadm_kwargs(output_nonlinearity="tanh"))
     with pytest.raises(ValueError):
         CaDMModel(**_cadm_kwargs(n_particles=7))
     class UnknownEnv:                      # right duck type, but no compiled-in closures for this class

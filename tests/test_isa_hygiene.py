@@ -67,7 +67,7 @@ def test_resident_fragments_never_leave_agprs():
     for img in images:
         for sym, ins in _kernels(img).items():
             # XC<ENV, C, HID>: geometries with HID <= 256 use the asm MFMA path with AGPR-resident fragments
-            m = re.search(r"2XCILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEE", sym)        # XC<ENV, C, HID, MT>
+            m = re.search(r"2XCILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi\d+ELi\d+EEE", sym)        # XC<ENV, C, HID, MT, NH, ACT>
             assert m, sym
             hid = int(m.group(3))
             n_mfma = sum(1 for x in ins if x.startswith("v_mfma_f32_16x16x32_f16"))

@@ -14,7 +14,7 @@ path = sys.argv[1] if len(sys.argv) > 1 else t.LIB
 for img in t._code_objects(path):
     for sym, ins in t._kernels(img).items():
         ops = collections.Counter(x.split()[0] for x in ins if x and not x.startswith(("//", ";")))
-        m = re.search(r"2XCILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)EEELi(\d+)", sym)
+        m = re.search(r"2XCILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi\d+ELi\d+EEELi(\d+)", sym)
         key = ("env%s C%s HID%s MT%s noise%s" % m.groups()) if m else sym
         pick = {k: ops[k] for k in ("v_mfma_f32_16x16x32_f16", "v_accvgpr_write_b32", "v_accvgpr_read_b32", "v_writelane_b32",
                                     "v_readlane_b32", "scratch_load_dwordx4", "scratch_store_dwordx4", "buffer_load_dwordx4",
