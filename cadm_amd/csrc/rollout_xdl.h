@@ -31,6 +31,7 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 
 #ifndef CADM_XDL_RING
 #define CADM_XDL_RING 4
@@ -195,7 +196,7 @@ __device__ __forceinline__ void xsplit(float v, _Float16& hi, _Float16& lo) {
 template <class G>
 struct XHiddenEpi {
     static constexpr int NSTAGE = 6;
-    struct State { floatx4 v, s; f16x4 h1, h2; };
+    struct State { floatx2 v[2], s[2]; f16x4 h1, h2; };
     unsigned char* xsmem;
     const float* xb;
     int bias_off;
@@ -206,42 +207,71 @@ struct XHiddenEpi {
         if constexpr (G::BIAS_LDS) return *reinterpret_cast<const floatx4*>(xsmem + bias_off + bt * 16);
         else return *reinterpret_cast<const floatx4*>(xb + bt * 4);
     }
+    // The arithmetic is written on PAIRS (floatx2) so that it compiles to packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 /
+    // v_pk_add_f32: two values per 4-cycle issue); the low f16 part comes from v_fma_mixlo/hi_f16 (f16 source, f32 addend, f16
+    // result: one instruction instead of convert, fma, convert).  VALU instructions of the two waves of a SIMD do not overlap
+    // with its MFMAs on gfx950 (tools/micro/coexec_bench.hip), so every instruction saved here is time saved per layer.
+    static __device__ __forceinline__ floatx2 lo2(const floatx4& x) { return __builtin_shufflevector(x, x, 0, 1); }
+    static __device__ __forceinline__ floatx2 hi2(const floatx4& x) { return __builtin_shufflevector(x, x, 2, 3); }
     template <int S>
     __device__ __forceinline__ void stage(int ti, int hh, const floatx4& hi, const floatx4& lo, const floatx4& ll, State& st) const {
         if constexpr (S == 0) {            // pre-activation (hi + 2^-11 lo), f16-range clamp, exp2 argument
+            const floatx2 c11 = {4.8828125e-4f, 4.8828125e-4f}, c22 = {2.384185791015625e-7f, 2.384185791015625e-7f};
+            constexpr float KE = G::ACT == CADM_ACT_TANH ? -2.0f * 1.4426950408889634f : -1.4426950408889634f;
+            const floatx2 ke = {KE, KE};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float pre = fmaf(lo[r], 4.8828125e-4f, hi[r]);
-                if constexpr (G::NPROD == 4) pre = fmaf(ll[r], 2.384185791015625e-7f, pre);
-                st.v[r] = fminf(pre, 60000.0f);
-                st.s[r] = st.v[r] * (G::ACT == CADM_ACT_TANH ? -2.0f * 1.4426950408889634f : -1.4426950408889634f);
+            for (int q = 0; q < 2; ++q) {
+                floatx2 pre = __builtin_elementwise_fma(q ? hi2(lo) : lo2(lo), c11, q ? hi2(hi) : lo2(hi));
+                if constexpr (G::NPROD == 4) pre = __builtin_elementwise_fma(q ? hi2(ll) : lo2(ll), c22, pre);
+                pre[0] = fminf(pre[0], 60000.0f);
+                pre[1] = fminf(pre[1], 60000.0f);
+                st.v[q] = pre;
+                st.s[q] = pre * ke;
             }
         } else if constexpr (S == 1) {
             if constexpr (G::ACT != CADM_ACT_RELU && G::ACT != CADM_ACT_NONE) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st.s[r] = __builtin_amdgcn_exp2f(st.s[r]);
+                for (int q = 0; q < 2; ++q) { st.s[q][0] = __builtin_amdgcn_exp2f(st.s[q][0]); st.s[q][1] = __builtin_amdgcn_exp2f(st.s[q][1]); }
             }
         } else if constexpr (S == 2) {
             if constexpr (G::ACT != CADM_ACT_RELU && G::ACT != CADM_ACT_NONE) {
+                const floatx2 one = {1.0f, 1.0f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st.s[r] = __builtin_amdgcn_rcpf(1.0f + st.s[r]);
+                for (int q = 0; q < 2; ++q) {
+                    st.s[q] = st.s[q] + one;
+                    st.s[q][0] = __builtin_amdgcn_rcpf(st.s[q][0]);
+                    st.s[q][1] = __builtin_amdgcn_rcpf(st.s[q][1]);
+                }
             }
         } else if constexpr (S == 3) {     // the nonlinearity (dynamics.py:17-24) and the high f16 part
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if constexpr (G::ACT == CADM_ACT_SWISH) st.v[r] = st.v[r] * st.s[r];                 // x * sigmoid(x), :23
-                else if constexpr (G::ACT == CADM_ACT_SIGMOID) st.v[r] = st.s[r];                    // 1 / (1 + e^-x)
+            for (int q = 0; q < 2; ++q) {
+                if constexpr (G::ACT == CADM_ACT_SWISH) st.v[q] = st.v[q] * st.s[q];                 // x * sigmoid(x), :23
+                else if constexpr (G::ACT == CADM_ACT_SIGMOID) st.v[q] = st.s[q];                    // 1 / (1 + e^-x)
                 else if constexpr (G::ACT == CADM_ACT_TANH) {      // 2 sigmoid(2x) - 1 (s was built from 2x); odd series near 0, where that cancels
-                    const float x = st.v[r], x2 = x * x;
-                    const float ser = x * fmaf(x2, fmaf(x2, fmaf(x2, -0.05396825396825397f, 0.13333333333333333f), -0.3333333333333333f), 1.0f);
-                    st.v[r] = fabsf(x) < 0.1f ? ser : fmaf(2.0f, st.s[r], -1.0f);
-                } else if constexpr (G::ACT == CADM_ACT_RELU) st.v[r] = fmaxf(st.v[r], 0.0f);
-                else if constexpr (G::ACT == CADM_ACT_NONE) st.v[r] = fmaxf(st.v[r], -60000.0f);       // f16 range, both sides
-                st.h1[r] = (_Float16)st.v[r];
-            }
-        } else if constexpr (S == 4) {     // low part: (h - hi) * 2^11, exact in fp32
 #pragma unroll
-            for (int r = 0; r < 4; ++r) st.h2[r] = (_Float16)fmaf((float)st.h1[r], -2048.0f, st.v[r] * 2048.0f);
+                    for (int r = 0; r < 2; ++r) {
+                        const float x = st.v[q][r], x2 = x * x;
+                        const float ser = x * fmaf(x2, fmaf(x2, fmaf(x2, -0.05396825396825397f, 0.13333333333333333f), -0.3333333333333333f), 1.0f);
+                        st.v[q][r] = fabsf(x) < 0.1f ? ser : fmaf(2.0f, st.s[q][r], -1.0f);
+                    }
+                } else if constexpr (G::ACT == CADM_ACT_RELU) { st.v[q][0] = fmaxf(st.v[q][0], 0.0f); st.v[q][1] = fmaxf(st.v[q][1], 0.0f); }
+                else if constexpr (G::ACT == CADM_ACT_NONE) { st.v[q][0] = fmaxf(st.v[q][0], -60000.0f); st.v[q][1] = fmaxf(st.v[q][1], -60000.0f); }   // f16 range, both sides
+                st.h1[2 * q] = (_Float16)st.v[q][0];
+                st.h1[2 * q + 1] = (_Float16)st.v[q][1];
+            }
+        } else if constexpr (S == 4) {     // low part: (h - hi) * 2^11 = fma(hi, -2^11, h * 2^11), exact in fp32, rounded once to f16
+            const floatx2 k11 = {2048.0f, 2048.0f};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const floatx2 t = st.v[q] * k11;
+                const f16x2 hp = {st.h1[2 * q], st.h1[2 * q + 1]};
+                f16x2 lp;
+                asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                    : "=&v"(lp) : "v"(hp), "s"(-2048.0f), "v"(t[0]), "v"(t[1]));
+                st.h2[2 * q] = lp[0];
+                st.h2[2 * q + 1] = lp[1];
+            }
         } else {
             const int Tg = tstart + ti;
             unsigned char* dst = xsmem + out + hh * G::ACT_T + ((Tg >> 1) * 64 + lane) * 16 + (Tg & 1) * 8;
