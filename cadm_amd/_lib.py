@@ -77,6 +77,7 @@ SIGNATURES = {
     "cadm_rs_select": (_i, [_P, _P, _i, _i, _P, _i, _P, _P, _P]),
     "cadm_plan_workspace_bytes": (C.c_size_t, [_P, _i, _i]),
     "cadm_cem_plan": (_i, [_P, _P, _P, _P, _P, _P, _i, _i, _u32, _u32, _P, _P, _P]),
+    "cadm_cem_plan_staged": (_i, [_P, _P, _P, C.POINTER(C.c_int32), _i, _i, _i, _u32, _u32, _P, _P, _i, _P]),
     "cadm_rs_plan": (_i, [_P, _P, _P, _P, _i, _i, _u32, _u32, _P, _P, _P, _P]),
     "cadm_train_configure": (_i, [_P, C.POINTER(TrainHParams), _i]),
     "cadm_train_step": (_i, [_P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _P, _P]),

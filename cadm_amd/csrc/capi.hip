@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "common.h"
 
@@ -362,6 +363,65 @@ extern "C" int cadm_cem_plan(cadm_ctx* ctx, const float* obs, const float* cp_ob
         } else {       // single rank: the particle mean is taken inside the refit kernel
             if ((rc = cadm_launch_refit(ctx, nullptr, w.rows, 1, nl, w.actions, m, mean_in, var_in, w.mean, w.var, nullptr, plan, s))) return rc;
         }
+    }
+    return CADM_OK;
+}
+
+// Per-call inputs of a small planner call travel as KERNEL ARGUMENTS: the runtime writes them into the kernarg segment with
+// the launch packet, a one-workgroup kernel unpacks them into the device block.  Same queue as the planner kernels: no copy
+// engine, no cross-engine dependency (hipMemcpyAsync of 2.5 KB cost ~10 us more per call; a kernel READING the pinned block
+// over PCIe was 10x slower still).
+#define CADM_INGEST_MAX 960
+struct IngestBlock { float v[CADM_INGEST_MAX]; };
+__global__ void ingest_kernel(const IngestBlock blk, float* __restrict__ dev_block, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dev_block[i] = blk.v[i];
+}
+
+// The class API's call (dynamics.py:344-367: numpy in -> numpy out) as ONE library call: the caller has packed the five
+// per-call inputs into a pinned host block; one async H2D copy of that block, the whole planner, the plan written straight
+// into the caller's pinned host buffer by the last refit kernel, and (optionally) the stream synchronisation.
+extern "C" int cadm_cem_plan_staged(cadm_ctx* ctx, const float* host_block, float* dev_block, const int32_t off[5], int nfloats,
+                                    int m, int n, uint32_t seed, uint32_t call, void* workspace, float* plan_out_host, int sync,
+                                    void* stream) {
+    CADM_REQUIRE(ctx && host_block && dev_block && off && nfloats > 0 && plan_out_host, "cadm_cem_plan_staged: bad arguments");
+    CADM_ON_DEVICE(ctx);
+    hipStream_t s = (hipStream_t)stream;
+    if (nfloats <= CADM_INGEST_MAX) {
+        IngestBlock blk;
+        memcpy(blk.v, host_block, (size_t)nfloats * sizeof(float));
+        hipLaunchKernelGGL(ingest_kernel, dim3(1), dim3(256), 0, s, blk, dev_block, nfloats);
+        CADM_CHECK_HIP(hipGetLastError());
+    } else {
+        CADM_CHECK_HIP(hipMemcpyAsync(dev_block, host_block, (size_t)nfloats * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+    auto at = [&](int i) -> const float* { return off[i] < 0 ? nullptr : dev_block + off[i]; };      // obs, cp_obs, cp_act, mean, var
+    // completion: [m] flag words behind the plan in the caller's pinned buffer, released by the last refit kernel with this
+    // call's id; the host polls them (a sleeping hipStreamSynchronize wakes up ~10 us late on a 1 ms call)
+    unsigned* flags = reinterpret_cast<unsigned*>(plan_out_host + (size_t)m * ctx->H * ctx->A);
+    const unsigned val = call ^ 0x5ca1ab1eu;
+    if (sync) { for (int i = 0; i < m; ++i) flags[i] = ~val; }
+    ctx->plan_done = sync ? flags : nullptr;
+    ctx->plan_done_val = val;
+    const int rc = cadm_cem_plan(ctx, at(0), at(1), at(2), at(3), at(4), m, n, seed, call, workspace, plan_out_host, stream);
+    ctx->plan_done = nullptr;
+    if (rc) return rc;
+    if (sync) {
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        volatile unsigned* vf = flags;
+        bool ok = false;
+        for (unsigned long spins = 0; !ok; ++spins) {
+            ok = true;
+            for (int i = 0; i < m; ++i) ok = ok && vf[i] == val;
+            if (ok) break;
+            __builtin_ia32_pause();
+            if ((spins & 4095) == 4095) {           // a kernel that faulted never raises the flag: fall back to the runtime's verdict
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) > 0.25) break;
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (!ok) CADM_CHECK_HIP(hipStreamSynchronize(s));
     }
     return CADM_OK;
 }

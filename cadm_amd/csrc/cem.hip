@@ -117,7 +117,8 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
                                  const float* __restrict__ actions,
                                  int m, int H, int A, int K, float alpha, int npow2, const float* mean_in,
                                  const float* var_in, float* mean_out, float* var_out, int32_t* __restrict__ elites_out,
-                                 float* __restrict__ plan_out, float lo, float hi, int do_clip, int part_off) {
+                                 float* __restrict__ plan_out, float lo, float hi, int do_clip, int part_off,
+                                 unsigned* done_flag, unsigned done_val) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);
     const int mi = blockIdx.x;
@@ -276,6 +277,13 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
             if (plan_out) plan_out[o] = do_clip ? fminf(fmaxf(mo, lo), hi) : mo;
         }
     }
+    // completion flag of the staged planner call (cadm_cem_plan_staged): the host polls it in pinned memory instead of
+    // sleeping in hipStreamSynchronize.  Every thread's plan stores are fenced to system scope before the flag is released.
+    if (done_flag) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(done_flag + mi, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // RS: first maximum over candidates (tf.argmax), gather the first action (:555-561)
@@ -388,7 +396,8 @@ int cadm_launch_refit(cadm_ctx* ctx, const float* cand_returns, const float* row
     }
     hipLaunchKernelGGL(cem_refit_kernel, dim3(m), dim3(1024), lds, stream, cand_returns, rows, ctx->p, G, n_local, actions,
                        m, ctx->H, ctx->A, ctx->cfg.num_elites, ctx->cfg.alpha, npow2, mean_in, var_in, mean_out, var_out,
-                       elites_out, plan_out, ctx->cfg.lower_bound, ctx->cfg.upper_bound, ctx->cfg.discrete ? 0 : 1, (int)lds_keys);
+                       elites_out, plan_out, ctx->cfg.lower_bound, ctx->cfg.upper_bound, ctx->cfg.discrete ? 0 : 1, (int)lds_keys,
+                       plan_out ? ctx->plan_done : nullptr, ctx->plan_done_val);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
 }

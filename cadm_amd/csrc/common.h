@@ -141,6 +141,9 @@ struct cadm_ctx {
     std::vector<hipEvent_t> prof_ag;   // start/stop pairs around the per-iteration ncclAllGather (sharded planner)
     size_t prof_ag_used = 0;
     unsigned long long* tbuf = nullptr;   // cadm_dev_set_timing_buffer (developer library only)
+    // completion flags of a staged planner call (cadm_cem_plan_staged): [m] words in pinned host memory, released by the last refit
+    unsigned* plan_done = nullptr;
+    unsigned plan_done_val = 0;
     // RCCL communicator for candidate-sharded planning (dist.hip)
     void* comm = nullptr;
     int nranks = 1, rank = 0;

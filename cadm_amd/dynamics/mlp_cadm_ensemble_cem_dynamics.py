@@ -195,6 +195,7 @@ class MLPEnsembleCEMDynamicsModel(object):
         self.seed = int(seed)
         self._call = 0
         self._group = process_group
+        self._shard1 = None
         self._check_replicated_left = int(check_replicated_calls)   # sharded get_action calls that still verify replicated inputs
         self.engine = HipEngine(self.env_kind, ensemble_size, n_particles, obs_space_dims, self.action_space_dims,
                                 self.proc_obs_space_dims, context_out_dim, hidden_sizes, n_forwards,
@@ -244,6 +245,10 @@ class MLPEnsembleCEMDynamicsModel(object):
 
     def _sharding(self):
         """Candidate shard of this rank + whether the in-library RCCL path is usable on EVERY rank of the group."""
+        if self._group is None:         # never sharded (the default): nothing to negotiate
+            if self._shard1 is None or self._shard1.n != self.n_candidates:
+                self._shard1 = _planner.Shard(self.n_candidates)
+            return self._shard1, True
         shard = _planner.Shard.from_group(self.n_candidates, self._group)
         if shard.world > 1 and self.engine.dist_world == 1 and not self._dist_failed:
             import torch.distributed as dist
@@ -271,10 +276,19 @@ class MLPEnsembleCEMDynamicsModel(object):
             if cem_init_mean is not None:
                 return np.zeros((0, self.n_forwards, self.action_space_dims), np.float32)
             return np.zeros((0,), np.int32) if self.discrete else np.zeros((0, self.action_space_dims), np.float32)
-        self._check_planner_inputs(obs, cp_obs, cp_act, cem_init_mean, cem_init_var)
+        host_in = not any(isinstance(x, torch.Tensor) for x in (obs, cp_obs, cp_act, cem_init_mean, cem_init_var))
+        # shape checks once per shape set (the reference would raise a TF shape error; raw device pointers would not)
+        sig = tuple(None if x is None else tuple(np.shape(x)) for x in (obs, cp_obs, cp_act, cem_init_mean, cem_init_var))
+        if sig != getattr(self, "_checked_sig", None):
+            self._check_planner_inputs(obs, cp_obs, cp_act, cem_init_mean, cem_init_var)
+            self._checked_sig = sig
         call = self._next_call()
         shard, fused = self._sharding()
-        if not any(isinstance(x, torch.Tensor) for x in (obs, cp_obs, cp_act, cem_init_mean, cem_init_var)):
+        if fused and host_in and cem_init_mean is not None and not (shard.world > 1 and self._check_replicated_left > 0):
+            # the hot path of the samplers' loop: one library call from host arrays to the host plan (clipped in the last kernel)
+            return self.engine.cem_plan_host((obs, cp_obs, cp_act, cem_init_mean, cem_init_var), self.n_candidates, seed=self.seed, call=call,
+                                             shapes=sig)
+        if host_in:
             obs, cp_obs, cp_act, cem_init_mean, cem_init_var = self.engine.stage((obs, cp_obs, cp_act, cem_init_mean, cem_init_var))
         if shard.world > 1 and self._check_replicated_left > 0:      # first calls only: two blocking collectives + a host sync
             self._check_replicated_left -= 1

@@ -88,6 +88,7 @@ class HipEngine:
         self.nets = OrderedDict()   # net name -> OrderedDict(param name -> tensor)
         self._ws = None
         self._ws_key = None
+        self._host_plan = None
         self._train_B = 0
         self.dist_world, self.dist_rank = 1, 0
 
@@ -335,6 +336,7 @@ class HipEngine:
             nbytes = self.lib.cadm_plan_workspace_bytes(self._ctx, m, n)
             self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
             self._ws_key = key
+            self._host_plan = None          # (holds a pointer into the workspace)
         return self._ws
 
     def host_out(self, shape):
@@ -358,6 +360,39 @@ class HipEngine:
         self._check(self.lib.cadm_cem_plan(self._ctx, ptr(obs), ptr(cp_obs), ptr(cp_act), ptr(init_mean), ptr(init_var), m, n,
                                      seed, call, ptr(ws), ptr(out), self.stream), "cadm_cem_plan")
         return out
+
+    def cem_plan_host(self, arrays, n, seed=0, call=0, shapes=None):
+        """The class API's fast path: `arrays` = (obs, cp_obs, cp_act, init_mean, init_var) as host arrays (None = absent) ->
+        the plan [m,H,A] as a fresh numpy array.  Everything between is ONE library call (`cadm_cem_plan_staged`): the inputs
+        go through a persistent pinned block, the plan comes back through another; the block layout is cached per shape set."""
+        if shapes is None:
+            shapes = tuple(None if a is None else tuple(np.shape(a)) for a in arrays)
+        st = self._host_plan
+        if st is None or st["shapes"] != shapes or st["n"] != n:
+            offs, views, pos = [], [], 0
+            sizes = [0 if sh is None else int(np.prod(sh)) for sh in shapes]
+            total = max(sum(sizes), 1)
+            host = torch.empty(total, dtype=torch.float32).pin_memory()
+            hv = host.numpy()
+            for sh, sz in zip(shapes, sizes):
+                offs.append(-1 if sh is None else pos)
+                views.append(None if sh is None else hv[pos:pos + sz].reshape(sh))
+                pos += sz
+            m = shapes[0][0]
+            out = torch.zeros(m * self.H * self.A + m, dtype=torch.float32).pin_memory()       # plan + m completion flags
+            st = self._host_plan = dict(shapes=shapes, n=n, ws=ptr(self._workspace(m, n)), host=host, views=views, dev=torch.empty(total, dtype=torch.float32, device=self.device),
+                                        off=(ct.c_int32 * 5)(*offs), total=total, out=out, out_np=out.numpy()[:m * self.H * self.A].reshape(m, self.H, self.A), m=m,
+                                        hp=ct.c_void_p(host.data_ptr()), op=ct.c_void_p(out.data_ptr()))
+            st["dp"] = ct.c_void_p(st["dev"].data_ptr())
+            self.ensure_rollout(None, m, max(1, n // self.dist_world))
+        for v, a in zip(st["views"], arrays):
+            if v is not None:
+                np.copyto(v, a, casting="unsafe")
+        rc = self.lib.cadm_cem_plan_staged(self._ctx, st["hp"], st["dp"], st["off"], st["total"], st["m"], n, seed, call,
+                                           st["ws"], st["op"], 1, self.stream)
+        if rc:
+            self._check(rc, "cadm_cem_plan_staged")
+        return st["out_np"].copy()
 
     def rs_plan(self, obs, cp_obs, cp_act, n, seed=0, call=0):
         obs = self._t(obs)

@@ -190,6 +190,14 @@ size_t cadm_plan_workspace_bytes(cadm_ctx* ctx, int m, int n);
 int cadm_cem_plan(cadm_ctx* ctx, const float* obs, const float* cp_obs, const float* cp_act,
                   const float* init_mean, const float* init_var, int m, int n,
                   uint32_t seed, uint32_t call, void* workspace, float* plan_out, void* stream);
+/* The same planner fed from the HOST, as the class's get_action is (numpy in -> numpy out, dynamics.py:344-367): `host_block`
+ * is a pinned host buffer of `nfloats` floats holding obs / cp_obs / cp_act / init_mean / init_var at float offsets off[0..4]
+ * (-1 = absent); it is copied to `dev_block` (device, >= nfloats floats) with one async copy on `stream`, the planner runs, and
+ * the last refit kernel writes the plan into `plan_out_host` (pinned, device-visible host memory: [m,H,A] floats followed by m
+ * 32-bit completion flags).  sync != 0: returns when plan_out_host is readable (the flags are polled; no sleep in the runtime). */
+int cadm_cem_plan_staged(cadm_ctx* ctx, const float* host_block, float* dev_block, const int32_t off[5], int nfloats,
+                         int m, int n, uint32_t seed, uint32_t call, void* workspace, float* plan_out_host, int sync,
+                         void* stream);
 /* Random-shooting planner (core/utils.py:490-561): out [m,A] (continuous) or raw_best_out [m] ints. */
 int cadm_rs_plan(cadm_ctx* ctx, const float* obs, const float* cp_obs, const float* cp_act,
                  int m, int n, uint32_t seed, uint32_t call, void* workspace,
