@@ -23,6 +23,11 @@ def main():
                 cnt[name] = cnt.get(name, 0) + 1
     out = {k: acc[k] / cnt[k] for k in sorted(acc)}
     out["_dispatches"] = max(cnt.values()) if cnt else 0
+    # share of SIMD-cycles of a launch in which the matrix pipe was busy: SQ_VALU_MFMA_BUSY_CYCLES is summed over all SIMDs;
+    # GRBM_GUI_ACTIVE is the launch's duration in GPU clocks summed over the 8 XCDs (both per dispatch); 4 SIMDs x 256 CUs
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in out and out.get("GRBM_GUI_ACTIVE"):
+        out["launch_cycles"] = out["GRBM_GUI_ACTIVE"] / 8.0
+        out["mfma_busy_frac"] = out["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * 256.0 * out["launch_cycles"])
     print(json.dumps(out, indent=1))
 
 

@@ -6,7 +6,7 @@ TAG=${1:-r2}; shift || true
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --no-cpu-baseline --legs none --steps 20 --warmup 3 $*"
+BENCH="python $PWD/bench.py --no-extras --steps 20 --warmup 3 $*"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 DB=$(find $OUT/trace -name "*.db" | head -1)
