@@ -101,24 +101,26 @@ struct XC {
     // (tests/test_isa_hygiene.py checks the ISA for AGPR<->VGPR shuffles of resident fragments, which would also be an
     // undetected MFMA operand hazard).
 #ifndef CADM_XDL_RES_FRAGS
-#define CADM_XDL_RES_FRAGS 13       // waves with BASE hidden tiles
+#define CADM_XDL_RES_FRAGS 16       // waves with one hidden tile (+ a head tile)
 #endif
 #ifndef CADM_XDL_RES_MT2_LESS
-#define CADM_XDL_RES_MT2_LESS 3     // two row tiles: twice the accumulators, operand registers and rollout state
+#define CADM_XDL_RES_MT2_LESS 6     // two row tiles: twice the accumulators, operand registers and rollout state
 #endif
 #ifndef CADM_XDL_RES_FRAGS_X
-#define CADM_XDL_RES_FRAGS_X 11     // waves with BASE + 1 hidden tiles (more accumulators / epilogue state live)
+#define CADM_XDL_RES_FRAGS_X 14     // waves with two or more hidden tiles (more accumulators / epilogue state live)
 #endif
     static constexpr bool ASM_MFMA = CADM_XDL_RES && NCH <= 8;     // asm MFMAs (AGPR-resident operands) vs builtins
     static constexpr int res_frags(int ntw) {      // (wide observations keep two pair slots of rollout state per thread)
         return (!CADM_XDL_RES || NCH > 8) ? 0
                : MT > 1 ? (ntw >= 2 ? CADM_XDL_RES_FRAGS_X : CADM_XDL_RES_FRAGS) - (NPI > 1 ? 2 : 0) - CADM_XDL_RES_MT2_LESS - (NT >= 15 ? 1 : 0)
-                        : (ntw == BASE ? CADM_XDL_RES_FRAGS : CADM_XDL_RES_FRAGS_X) - (NPI > 1 ? 2 : 0);
+                        : (ntw >= 2 ? CADM_XDL_RES_FRAGS_X : CADM_XDL_RES_FRAGS) - (NPI > 1 ? 2 : 0) - (NT >= 15 ? 2 : 0);
     }
     static constexpr int MAX_NH_LDS = NH_;
     static constexpr int BIAS_BYTES = (MAX_NH_LDS * NT + NTO) * 1024;
     static constexpr bool BIAS_LDS = CTRL + MT * 16 * 64 * 4 + BIAS_BYTES <= 154 * 1024;
-    static constexpr int XDEPTH = MT > 1 ? 2 : 3;          // B-operand chunks in registers (lookahead XDEPTH - 1)
+    // (one row tile: a lookahead of 2 chunks bought nothing measurable, and its 8 registers are worth one more resident
+    //  fragment: every streamed fragment costs ~0.6 us per launch at cfg2 -- the L2 -> CU weight stream is what the one-tile kernel waits for)
+    static constexpr int XDEPTH = 2;                       // B-operand chunks in registers (lookahead XDEPTH - 1)
     static size_t lds_bytes(int H) {                       // dynamic LDS of a launch
         return (size_t)CTRL + (size_t)rup(MT * 16 * H * 4, 16) + (BIAS_LDS ? (size_t)(NHC * NT + NTO) * 1024 : 0);
     }
