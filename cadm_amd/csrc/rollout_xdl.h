@@ -116,13 +116,25 @@ struct XC {
                         : (ntw >= 2 ? CADM_XDL_RES_FRAGS_X : CADM_XDL_RES_FRAGS) - (NPI > 1 ? 2 : 0) - (NT >= 15 ? 2 : 0);
     }
     static constexpr int MAX_NH_LDS = NH_;
-    static constexpr int BIAS_BYTES = (MAX_NH_LDS * NT + NTO) * 1024;
+    // (a bias tile in D layout repeats each of its 16 values over the tile's 16 data rows: LDS keeps one copy, 64 B per tile)
+    static constexpr int BIAS_TILE_B = 64;
+    static constexpr int BIAS_BYTES = (MAX_NH_LDS * NT + NTO) * BIAS_TILE_B;
     static constexpr bool BIAS_LDS = CTRL + MT * 16 * 64 * 4 + BIAS_BYTES <= 154 * 1024;
     // (one row tile: a lookahead of 2 chunks bought nothing measurable, and its 8 registers are worth one more resident
     //  fragment: every streamed fragment costs ~0.6 us per launch at cfg2 -- the L2 -> CU weight stream is what the one-tile kernel waits for)
     static constexpr int XDEPTH = 2;                       // B-operand chunks in registers (lookahead XDEPTH - 1)
+    // LDS-resident weight fragments: what is left of the 160 KiB (at horizons <= 128; one row tile per workgroup) holds the LAST
+    // LQ_SLOTS fragments of hidden layers 1..3 of every wave with two or more tiles -- the waves a layer waits for.  The one-tile
+    // kernel is bound by the L2 -> CU weight stream (every streamed fragment costs ~0.6 us per launch at cfg2).
+#ifndef CADM_XDL_LQ_MAX
+#define CADM_XDL_LQ_MAX 2       // (a third slot measured +-0: the stream is no longer what the layer waits for)
+#endif
+    static constexpr int NEL = BASE >= 2 ? NW : EXTRA;                 // waves with >= 2 tiles (waves 0 .. NEL-1)
+    static constexpr int LQ_FREE = 160 * 1024 - (CTRL + rup(MT * 16 * 128 * 4, 16) + (BIAS_LDS ? BIAS_BYTES : 0));
+    static constexpr int LQ_SLOTS = (MT > 1 || NEL == 0 || !ASM_MFMA || LQ_FREE <= 0) ? 0 : cmin(CADM_XDL_LQ_MAX, LQ_FREE / (NEL * 3 * CADM_XDL_FRAG_BYTES));
+    static constexpr int LQ_BYTES = NEL * 3 * LQ_SLOTS * CADM_XDL_FRAG_BYTES;
     static size_t lds_bytes(int H) {                       // dynamic LDS of a launch
-        return (size_t)CTRL + (size_t)rup(MT * 16 * H * 4, 16) + (BIAS_LDS ? (size_t)(NHC * NT + NTO) * 1024 : 0);
+        return (size_t)CTRL + (size_t)rup(MT * 16 * H * 4, 16) + (BIAS_LDS ? (size_t)BIAS_BYTES : 0) + LQ_BYTES;
     }
 };
 
@@ -204,9 +216,10 @@ struct XHiddenEpi {
     int bias_off;
     int layer, out, tstart, lane;
     __device__ __forceinline__ floatx4 init(int ti) const {       // bias tile (fp32, D layout) of local tile ti
-        const int bt = (layer * G::NT + tstart + ti) * 64 + lane;
+        const int tile = layer * G::NT + tstart + ti;
+        const int bt = tile * 64 + lane;
         // (a select between an LDS and a global POINTER would become a flat load with a full vmcnt/lgkmcnt drain)
-        if constexpr (G::BIAS_LDS) return *reinterpret_cast<const floatx4*>(xsmem + bias_off + bt * 16);
+        if constexpr (G::BIAS_LDS) return *reinterpret_cast<const floatx4*>(xsmem + bias_off + tile * G::BIAS_TILE_B + (lane >> 4) * 16);
         else return *reinterpret_cast<const floatx4*>(xb + bt * 4);
     }
     // The arithmetic is written on PAIRS (floatx2) so that it compiles to packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 /
@@ -293,7 +306,7 @@ struct XHeadEpi {
     int bias_off, bias_tile, ht, lane;
     __device__ __forceinline__ floatx4 init(int) const {
         const int bt = bias_tile * 64 + lane;
-        if constexpr (G::BIAS_LDS) return *reinterpret_cast<const floatx4*>(xsmem + bias_off + bt * 16);
+        if constexpr (G::BIAS_LDS) return *reinterpret_cast<const floatx4*>(xsmem + bias_off + bias_tile * G::BIAS_TILE_B + (lane >> 4) * 16);
         else return *reinterpret_cast<const floatx4*>(xb + bt * 4);
     }
     template <int S>
@@ -316,11 +329,15 @@ struct XHeadEpi {
 //   The B operand (the 16 rows' activations) is read from LDS chunk by chunk, XD-1 chunks ahead of its use.
 //   The epilogue of a tile group runs stage by stage between the MFMAs of the NEXT group (f16 MFMAs hide independent
 //   VALU work of the same wave); the last group's epilogue overlaps with the SIMD's other wave.
-template <class G, int NTW, int NCHL, int NRES, int GS, bool SIDE, class Epi>
+//   NLDS: the LAST NLDS fragments of the layer (consumption order) are LDS-resident (lq: this wave's copy, made once per workgroup):
+//   they go through the ring like streamed ones, from LDS instead of L2.  The first R ring fragments stay streamed.
+template <class G, int NTW, int NCHL, int NRES, int GS, bool SIDE, int NLDS, class Epi>
 __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2], __amdgpu_buffer_rsrc_t rsrc, unsigned wcur,
-                                          unsigned wnext, int nx_nf, const unsigned char* lds_in, int lane, const Epi& epi TS_PARAMS) {
+                                          unsigned wnext, int nx_nf, const unsigned char* lds_in, int lane, const Epi& epi,
+                                          const unsigned char* lq TS_PARAMS) {
     constexpr int R = G::R, NF = NTW * NCHL, NFS = NF - NRES, NFSPAD = rup(NFS, R);
     static_assert(NRES >= 0 && NRES <= NF, "bad resident fragment count");
+    static_assert(NLDS == 0 || NFS - NLDS >= R, "the first R ring fragments of a layer are streamed");
     constexpr int MT = G::MT, XD = NCHL < G::XDEPTH ? NCHL : G::XDEPTH;
     constexpr int IN_T = 2 * NCHL * 1024;                  // bytes of one row tile's operand block
     f16x8 X1[XD][MT], X2[XD][MT];
@@ -335,8 +352,12 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
     auto prefetch = [&](auto jsc) {      // after streamed time slot js: refill its ring slot
         constexpr int js = decltype(jsc)::value;
         constexpr int jj = js + R;
-        if constexpr (jj < NFS) {
+        if constexpr (jj < NFS - NLDS) {
             xring_load<js % R>(ring, rsrc, wcur + jj * CADM_XDL_FRAG_BYTES, lane);
+        } else if constexpr (jj < NFS) {
+            const unsigned char* p = lq + (jj - (NFS - NLDS)) * CADM_XDL_FRAG_BYTES + lane * 16;
+            ring.w[js % R][0] = *reinterpret_cast<const uintx4*>(p);
+            ring.w[js % R][1] = *reinterpret_cast<const uintx4*>(p + 1024);
         } else if constexpr (jj >= NFSPAD) {
             if (jj - NFSPAD < nx_nf) xring_load<js % R>(ring, rsrc, wnext + (jj - NFSPAD) * CADM_XDL_FRAG_BYTES, lane);
         }
@@ -457,7 +478,8 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     for (int i = tid; i < (G::OFULL - G::XIN) / 16; i += G::NTHR) reinterpret_cast<uintx4*>(xsmem + G::XIN)[i] = uintx4{0u, 0u, 0u, 0u};
     if (bias_lds) {
         const uintx4* src = reinterpret_cast<const uintx4*>(a.xb + (size_t)(blockIdx.x / a.wgs_per_member) * a.xb_member);
-        for (int i = tid; i < (XNH * G::NT + NTO) * 64; i += G::NTHR) reinterpret_cast<uintx4*>(xsmem + bias_off)[i] = src[i];
+        // one float4 per (tile, lane group): the copy of data row 0
+        for (int i = tid; i < (XNH * G::NT + NTO) * 4; i += G::NTHR) reinterpret_cast<uintx4*>(xsmem + bias_off)[i] = src[(i >> 2) * 64 + (i & 3) * 16];
     }
 
     // byte offset (part 0) of input feature f of row 0 inside x_in; row arow adds arow * 16
@@ -564,6 +586,21 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         }
         return l;                         // (nothing streamed at all: a layer with lay_nf = 0, no loads are issued for it)
     };
+    // LDS-resident tail of hidden layers 1..3 (XC::LQ_SLOTS): as many as leave the first R ring fragments of every layer streamed
+    constexpr int LQ = (NTW >= 2 && G::LQ_SLOTS > 0) ? cmax(0, cmin(G::LQ_SLOTS, NFH - cmax(Q1, cmax(Q2, Q3)) - R)) : 0;
+    const int lq_off = bias_off + (G::BIAS_LDS ? G::BIAS_BYTES : 0) + wave * 3 * G::LQ_SLOTS * CADM_XDL_FRAG_BYTES;
+    if constexpr (LQ > 0) {      // once per workgroup: L2 -> LDS (a wave-private region: no barrier)
+#pragma unroll
+        for (int l = 1; l < (XNH < 4 ? XNH : 4); ++l)
+#pragma unroll
+            for (int i = 0; i < LQ; ++i)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+                    const uintx4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16 + part * 1024,
+                                                                           w_h1 + ((l - 1) * lh_nf + NFH - LQ + i) * CADM_XDL_FRAG_BYTES, 0);
+                    *reinterpret_cast<uintx4*>(xsmem + lq_off + ((l - 1) * LQ + i) * CADM_XDL_FRAG_BYTES + part * 1024 + lane * 16) = v;
+                }
+    }
     uintx4 resH[NRESH > 0 ? NRESH : 1][2], resO[RESO ? NCH : 1][2];
     static_for(std::make_integer_sequence<int, NRESH>{}, [&](auto qc) {
         constexpr int q = decltype(qc)::value;
@@ -809,20 +846,22 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                 // layer 0
                 {
                     const int nx = next_streamed(0);
-                    xdl_sweep<G, NTW, NC0, 0, GSZ, !SEQ>(ring, nullptr, rsrc, w_l0, lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
-                                              hidden_epi(0, act_out) TS_ARGS);
+                    xdl_sweep<G, NTW, NC0, 0, GSZ, !SEQ, 0>(ring, nullptr, rsrc, w_l0, lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
+                                              hidden_epi(0, act_out), nullptr TS_ARGS);
                 }
                 TS(2)
                 __syncthreads();
                 TS(3)
                 // hidden layers 1 .. NH-1: the first three are unrolled (distinct resident registers), the rest loop
-                auto hidden = [&](int l, auto res_c, auto base_c) {
+                auto hidden = [&](int l, auto res_c, auto base_c, auto lq_c) {
                     constexpr int NRES = decltype(res_c)::value, RBASE = decltype(base_c)::value;
                     act_in = act_out;
                     act_out = (act_in == G::ACTA) ? G::ACTB : G::ACTA;
                     const int nx = next_streamed(l);
-                    xdl_sweep<G, NTW, NCH, NRES, GSZ, !SEQ>(ring, resH + RBASE, rsrc, lay_off(l), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
-                                                 hidden_epi(l, act_out) TS_ARGS);
+                    // (layers 1..3: distinct instantiations with their LDS-resident tail; deeper layers stream everything)
+                    constexpr int NL = decltype(lq_c)::value ? LQ : 0;
+                    xdl_sweep<G, NTW, NCH, NRES, GSZ, !SEQ, NL>(ring, resH + RBASE, rsrc, lay_off(l), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
+                                                 hidden_epi(l, act_out), xsmem + lq_off + (l - 1) * LQ * CADM_XDL_FRAG_BYTES TS_ARGS);
                     // two row tiles: the waves that have a head tile (and one hidden tile less than the others: they would
                     // wait at this barrier anyway) make their noise now
                     if constexpr (NOISE != CADM_NOISE_NONE && MT > 1) {
@@ -833,10 +872,11 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                     TS(5)
                 };
                 using IC0 = std::integral_constant<int, 0>;
-                if (1 < XNH) hidden(1, std::integral_constant<int, Q1>{}, IC0{});
-                if (2 < XNH) hidden(2, std::integral_constant<int, Q2>{}, std::integral_constant<int, Q1>{});
-                if (3 < XNH) hidden(3, std::integral_constant<int, Q3>{}, std::integral_constant<int, Q1 + Q2>{});
-                for (int l = 4; l < XNH; ++l) hidden(l, IC0{}, IC0{});
+                using IC1 = std::integral_constant<int, 1>;
+                if (1 < XNH) hidden(1, std::integral_constant<int, Q1>{}, IC0{}, IC1{});
+                if (2 < XNH) hidden(2, std::integral_constant<int, Q2>{}, std::integral_constant<int, Q1>{}, IC1{});
+                if (3 < XNH) hidden(3, std::integral_constant<int, Q3>{}, std::integral_constant<int, Q1 + Q2>{}, IC1{});
+                for (int l = 4; l < XNH; ++l) hidden(l, IC0{}, IC0{}, IC0{});
                 act_in = act_out;
                 // two row tiles: the waves without a head tile make their noise while the others run the head
                 if constexpr (NOISE != CADM_NOISE_NONE && MT > 1) {
@@ -845,8 +885,8 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                 // ================= output head tile (mu | logvar of 8 dims) =================
                 if (nhead) {
                     const int nx = next_streamed(XNH);
-                    xdl_sweep<G, 1, NCH, RESO ? NCH : 0, 1, false>(ring, resO, rsrc, lay_off(XNH), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
-                                                         XHeadEpi<G>{xsmem, xb, bias_off, XNH * G::NT + ht, ht, lane} TS_ARGS);
+                    xdl_sweep<G, 1, NCH, RESO ? NCH : 0, 1, false, 0>(ring, resO, rsrc, lay_off(XNH), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
+                                                         XHeadEpi<G>{xsmem, xb, bias_off, XNH * G::NT + ht, ht, lane}, nullptr TS_ARGS);
                 }
             }
             TS(6)
