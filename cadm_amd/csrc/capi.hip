@@ -11,6 +11,11 @@ int cadm_launch_refit(cadm_ctx* ctx, const float* cand_returns, const float* row
                       int m, const float* mean_in, const float* var_in, float* mean_out, float* var_out, int32_t* elites_out,
                       float* plan_out, hipStream_t stream);
 
+int cadm_launch_refit_sample(cadm_ctx* ctx, const float* cand_returns, const float* rows, int G, int n_local, float* actions, int m,
+                             const float* mean_in, const float* var_in, float* mean_out, float* var_out, uint32_t seed, uint32_t call,
+                             int next_it, hipStream_t stream);
+bool cadm_refit_sample_ok(const cadm_ctx* ctx, int n);
+
 static thread_local char g_err[1024] = "";
 
 void cadm_set_error(const char* fmt, ...) {
@@ -347,21 +352,34 @@ extern "C" int cadm_cem_plan(cadm_ctx* ctx, const float* obs, const float* cp_ob
     CADM_REQUIRE(n % G == 0, "cadm_cem_plan: n_candidates %d not divisible by %d ranks", n, G);
     const int nl = n / G, off = (ctx->comm ? ctx->rank : 0) * nl;
     const int iters = ctx->cfg.num_cem_iters;
+    // Small candidate sets (rank-by-counting regime): the refit of iteration it and the sampling of iteration it + 1 are ONE
+    // launch parallel over the plan's (t, a) elements (cem_refit_sample_kernel) -- sample(0), then rollout + fused step per
+    // iteration, the last refit alone (it writes the clipped plan).  Larger sets: sample / rollout / refit per iteration.
+    const bool fuse = cadm_refit_sample_ok(ctx, n);
     for (int it = 0; it < iters; ++it) {
+        const bool first = it == 0, last = it + 1 == iters;
         // iteration 0 reads the caller's mean / var directly; the last refit also writes the clipped plan (dynamics.py:365-366)
-        const float* mean_in = it == 0 ? init_mean : w.mean;
-        const float* var_in = it == 0 ? init_var : w.var;
-        float* plan = it + 1 == iters ? plan_out : nullptr;
+        const float* mean_in = first ? init_mean : w.mean;
+        const float* var_in = first ? init_var : w.var;
+        float* plan = last ? plan_out : nullptr;
         // every rank draws ALL n candidates (counter-based RNG keyed by global candidate id): elites need no exchange
-        if ((rc = cadm_sample_actions(ctx, mean_in, var_in, nullptr, seed, call, it, m, n, w.actions, stream))) return rc;
+        if (first || !fuse) {
+            if ((rc = cadm_sample_actions(ctx, mean_in, var_in, nullptr, seed, call, it, m, n, w.actions, stream))) return rc;
+        }
         if ((rc = cadm_rollout_returns(ctx, obs, nullptr, ctx->C > 0 ? w.ctxv : nullptr, w.actions, nullptr, 1, seed,
                                        call, it, off, n, m, nl, w.rows, nullptr, stream))) return rc;
+        const float* cand = nullptr;
+        const float* rows = w.rows;
         if (G > 1) {   // the one collective of the path: [m, n/G] per rank -> [G, m, n/G] everywhere
             if ((rc = cadm_particle_mean(ctx, w.rows, m, nl, w.cand, stream))) return rc;
             if ((rc = allgather_timed(ctx, w.cand, w.gath, (size_t)m * nl, s))) return rc;
-            if ((rc = cadm_launch_refit(ctx, w.gath, nullptr, G, nl, w.actions, m, mean_in, var_in, w.mean, w.var, nullptr, plan, s))) return rc;
-        } else {       // single rank: the particle mean is taken inside the refit kernel
-            if ((rc = cadm_launch_refit(ctx, nullptr, w.rows, 1, nl, w.actions, m, mean_in, var_in, w.mean, w.var, nullptr, plan, s))) return rc;
+            cand = w.gath;
+            rows = nullptr;
+        }              // (single rank: the particle mean is taken inside the refit kernels)
+        if (fuse && !last) {
+            if ((rc = cadm_launch_refit_sample(ctx, cand, rows, G, nl, w.actions, m, mean_in, var_in, w.mean, w.var, seed, call, it + 1, s))) return rc;
+        } else {
+            if ((rc = cadm_launch_refit(ctx, cand, rows, G, nl, w.actions, m, mean_in, var_in, w.mean, w.var, nullptr, plan, s))) return rc;
         }
     }
     return CADM_OK;

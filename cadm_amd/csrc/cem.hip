@@ -5,6 +5,34 @@
 // ---------------------------------------------------------------------------------------------
 // action sampling
 // ---------------------------------------------------------------------------------------------
+// one candidate action element L = ((mi * n + c) * H + t) * A + a from the CEM distribution (mu, var) of its (t, a)
+__device__ __forceinline__ float sample_action(float mu, float var, const float* __restrict__ z, size_t L, uint32_t seed, uint32_t call,
+                                               int it, float lb, float ub) {
+    const float lbd = mu - lb, ubd = ub - mu;                                  // :425
+    const float a1 = lbd / 2.0f, a2 = ubd / 2.0f;
+    const float cv = fminf(fminf(a1 * a1, a2 * a2), var);                      // :426
+    float zz;
+    if (z) {
+        zz = z[L];
+    } else {
+        // TF TruncatedNormalDistribution: reject |x| >= 2 (kTruncateValue)
+        zz = 0.0f;
+        for (uint32_t attempt = 0; attempt < 64; ++attempt) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)(L & 0xFFFFFFFFull), attempt, (uint32_t)(L >> 32),
+                          CADM_STREAM_ACT | ((uint32_t)it << 8), seed, call, r);
+            float c0, c1, c2, c3;
+            box_muller(u01(r[0]), u01(r[1]), c0, c1);
+            box_muller(u01(r[2]), u01(r[3]), c2, c3);
+            if (fabsf(c0) < 2.0f) { zz = c0; break; }
+            if (fabsf(c1) < 2.0f) { zz = c1; break; }
+            if (fabsf(c2) < 2.0f) { zz = c2; break; }
+            if (fabsf(c3) < 2.0f) { zz = c3; break; }
+        }
+    }
+    return mu + sqrtf(cv) * zz;                                                // :429
+}
+
 __global__ void sample_actions_kernel(const float* __restrict__ mean, const float* __restrict__ var,
                                       const float* __restrict__ z, uint32_t seed, uint32_t call, int it,
                                       int m, int n, int H, int A, float lb, float ub,
@@ -14,30 +42,7 @@ __global__ void sample_actions_kernel(const float* __restrict__ mean, const floa
     for (size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x; L < total; L += (size_t)gridDim.x * blockDim.x) {
         const int ta = (int)(L % HA);
         const int mi = (int)(L / ((size_t)n * HA));
-        const float mu = mean[(size_t)mi * HA + ta];
-        const float lbd = mu - lb, ubd = ub - mu;                                  // :425
-        const float a1 = lbd / 2.0f, a2 = ubd / 2.0f;
-        const float cv = fminf(fminf(a1 * a1, a2 * a2), var[(size_t)mi * HA + ta]);  // :426
-        float zz;
-        if (z) {
-            zz = z[L];
-        } else {
-            // TF TruncatedNormalDistribution: reject |x| >= 2 (kTruncateValue)
-            zz = 0.0f;
-            for (uint32_t attempt = 0; attempt < 64; ++attempt) {
-                uint32_t r[4];
-                philox4x32_10((uint32_t)(L & 0xFFFFFFFFull), attempt, (uint32_t)(L >> 32),
-                              CADM_STREAM_ACT | ((uint32_t)it << 8), seed, call, r);
-                float c0, c1, c2, c3;
-                box_muller(u01(r[0]), u01(r[1]), c0, c1);
-                box_muller(u01(r[2]), u01(r[3]), c2, c3);
-                if (fabsf(c0) < 2.0f) { zz = c0; break; }
-                if (fabsf(c1) < 2.0f) { zz = c1; break; }
-                if (fabsf(c2) < 2.0f) { zz = c2; break; }
-                if (fabsf(c3) < 2.0f) { zz = c3; break; }
-            }
-        }
-        out[L] = mu + sqrtf(cv) * zz;                                              // :429
+        out[L] = sample_action(mean[(size_t)mi * HA + ta], var[(size_t)mi * HA + ta], z, L, seed, call, it, lb, ub);
     }
 }
 
@@ -285,6 +290,133 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
         if (threadIdx.x == 0) __hip_atomic_store(done_flag + mi, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Fused planner step for small candidate sets (n <= 256): elite refit of iteration `it` AND the sampling of iteration it + 1,
+// parallel over the (t, a) elements of the plan.  Workgroup (mi, s) ranks the n candidates itself (cheap, deterministic: every
+// workgroup finds the same elites), then owns EPW consecutive elements: their elite statistics, the EMA update of mean / var
+// (every element is read and written by its owner only: mean_in may alias mean_out) and the next iteration's n candidates of these elements (in place in
+// `actions`: the elites' values of these elements were read before).  Arithmetic = cem_refit_kernel + sample_actions_kernel
+// (same summation order, same Philox counters): the fused planner equals the stepwise composition bit for bit.
+// ---------------------------------------------------------------------------------------------
+#define CADM_FUSED_EPW 8
+__global__ __launch_bounds__(1024) void cem_refit_sample_kernel(const float* __restrict__ cand, const float* __restrict__ rows, int p, int G,
+                                                               int n_local, float* __restrict__ actions, int m, int H, int A, int K, float alpha,
+                                                               const float* mean_in, const float* var_in, float* mean_out, float* var_out, float lb,
+                                                               float ub, uint32_t seed, uint32_t call, int next_it) {
+    __shared__ uint64_t raw[256];
+    __shared__ uint64_t keys[256];
+    __shared__ int rank_s[256];
+    __shared__ float vals[64 * CADM_FUSED_EPW];      // [K <= 64][EPW] elite values of this workgroup's elements
+    __shared__ float part[64 * CADM_FUSED_EPW];      // [KG <= K <= 64][EPW]
+    __shared__ float nd[2 * CADM_FUSED_EPW], nmean[CADM_FUSED_EPW];
+    const int HA = H * A, n = G * n_local, tid = threadIdx.x;
+    const int NS = (HA + CADM_FUSED_EPW - 1) / CADM_FUSED_EPW;
+    const int mi = blockIdx.x / NS, ta0 = (blockIdx.x % NS) * CADM_FUSED_EPW;
+    const int ne = HA - ta0 < CADM_FUSED_EPW ? HA - ta0 : CADM_FUSED_EPW;
+    // ---- elites: rank by counting (keys are unique: candidate index in the low word), as cem_refit_kernel's small-n path;
+    //      the n x n comparisons are cut in 4 column quarters (1024 threads), partial ranks meet in integer LDS atomics
+    if (tid < 256) rank_s[tid] = 0;
+    if (tid < n) raw[tid] = make_key(cand_value(cand, rows, p, G, n_local, m, mi, tid), (uint32_t)tid);
+    __syncthreads();
+    {
+        const int i = tid & 255, quarter = tid >> 8;
+        if (i < n) {
+            const uint64_t ki = raw[i];
+            const int qn = (n + 3) >> 2, j0 = quarter * qn, j1 = j0 + qn < n ? j0 + qn : n;
+            int cnt = 0;
+            for (int j = j0; j < j1; ++j) cnt += raw[j] < ki ? 1 : 0;
+            if (cnt) atomicAdd(&rank_s[i], cnt);
+        }
+    }
+    __syncthreads();
+    if (tid < n && rank_s[tid] < K) keys[rank_s[tid]] = raw[tid];
+    __syncthreads();
+    // ---- elite values of the owned elements
+    float* act_m = actions + (size_t)mi * n * HA;
+    for (int q = tid; q < K * ne; q += blockDim.x) {
+        const int k = q / ne, e = q % ne;
+        vals[k * CADM_FUSED_EPW + e] = act_m[(size_t)(keys[k] & 0xFFFFFFFFu) * HA + ta0 + e];
+    }
+    __syncthreads();
+    // ---- mean / biased variance over the elites in cem_refit_kernel's summation order: KG interleaved groups of up to 16
+    //      elites whose partial sums are added in group order ("par"), or one sequential sum when that split does not cover K
+    constexpr int MAXE = 16;
+    const int KG0 = 1024 / HA > 0 ? 1024 / HA : 1;
+    const int KG = KG0 < K ? KG0 : K;
+    const bool par = KG * MAXE >= K;
+    if (par) {
+        for (int q = tid; q < KG * ne; q += blockDim.x) {
+            const int kg = q / ne, e = q % ne;
+            float sum = 0.0f;
+            for (int i = 0; i < MAXE; ++i) { const int k = kg + i * KG; sum += k < K ? vals[k * CADM_FUSED_EPW + e] : 0.0f; }
+            part[kg * CADM_FUSED_EPW + e] = sum;
+        }
+        __syncthreads();
+        if (tid < ne) {
+            float nm = 0.0f;
+            for (int g = 0; g < KG; ++g) nm += part[g * CADM_FUSED_EPW + tid];
+            nmean[tid] = nm / (float)K;                                            // :482
+        }
+        __syncthreads();
+        for (int q = tid; q < KG * ne; q += blockDim.x) {
+            const int kg = q / ne, e = q % ne;
+            const float nm = nmean[e];
+            float qq = 0.0f;
+            for (int i = 0; i < MAXE; ++i) {
+                const int k = kg + i * KG;
+                const float d = (k < K ? vals[k * CADM_FUSED_EPW + e] : 0.0f) - nm;
+                qq += k < K ? d * d : 0.0f;
+            }
+            part[kg * CADM_FUSED_EPW + e] = qq;
+        }
+        __syncthreads();
+        if (tid < ne) {
+            float nv = 0.0f;
+            for (int g = 0; g < KG; ++g) nv += part[g * CADM_FUSED_EPW + tid];
+            nv = nv / (float)K;                                                    // :483
+            const size_t o = (size_t)mi * HA + ta0 + tid;
+            const float mo = mean_in[o] * alpha + (1.0f - alpha) * nmean[tid];     // :485
+            const float vo = var_in[o] * alpha + (1.0f - alpha) * nv;              // :486
+            mean_out[o] = mo; var_out[o] = vo;
+            nd[tid] = mo; nd[CADM_FUSED_EPW + tid] = vo;
+        }
+    } else {
+        if (tid < ne) {
+            float sum = 0.0f;
+            for (int k = 0; k < K; ++k) sum += vals[k * CADM_FUSED_EPW + tid];
+            const float nm = sum / (float)K;
+            float v = 0.0f;
+            for (int k = 0; k < K; ++k) { const float d = vals[k * CADM_FUSED_EPW + tid] - nm; v += d * d; }
+            const float nv = v / (float)K;
+            const size_t o = (size_t)mi * HA + ta0 + tid;
+            const float mo = mean_in[o] * alpha + (1.0f - alpha) * nm;
+            const float vo = var_in[o] * alpha + (1.0f - alpha) * nv;
+            mean_out[o] = mo; var_out[o] = vo;
+            nd[tid] = mo; nd[CADM_FUSED_EPW + tid] = vo;
+        }
+    }
+    __syncthreads();
+    // ---- the next iteration's candidates of the owned elements (in place: the elites above were read before the barrier)
+    for (int q = tid; q < n * ne; q += blockDim.x) {
+        const int c = q / ne, e = q % ne;
+        const size_t L = ((size_t)mi * n + c) * HA + ta0 + e;
+        actions[L] = sample_action(nd[e], nd[CADM_FUSED_EPW + e], nullptr, L, seed, call, next_it, lb, ub);
+    }
+}
+
+int cadm_launch_refit_sample(cadm_ctx* ctx, const float* cand_returns, const float* rows, int G, int n_local, float* actions, int m,
+                             const float* mean_in, const float* var_in, float* mean_out, float* var_out, uint32_t seed, uint32_t call,
+                             int next_it, hipStream_t stream) {
+    const int HA = ctx->H * ctx->A, NS = (HA + CADM_FUSED_EPW - 1) / CADM_FUSED_EPW;
+    hipLaunchKernelGGL(cem_refit_sample_kernel, dim3(m * NS), dim3(1024), 0, stream, cand_returns, rows, ctx->p, G, n_local, actions, m,
+                       ctx->H, ctx->A, ctx->cfg.num_elites, ctx->cfg.alpha, mean_in, var_in, mean_out, var_out, ctx->cfg.lower_bound,
+                       ctx->cfg.upper_bound, seed, call, next_it);
+    CADM_CHECK_HIP(hipGetLastError());
+    return CADM_OK;
+}
+// the fused step covers the rank-by-counting regime of the refit and elite sets that fit its LDS arrays
+bool cadm_refit_sample_ok(const cadm_ctx* ctx, int n) { return n <= 256 && n >= ctx->cfg.num_elites && ctx->cfg.num_elites <= 64; }
 
 // RS: first maximum over candidates (tf.argmax), gather the first action (:555-561)
 __global__ void rs_select_kernel(const float* __restrict__ cand, int G, int n_local, const float* __restrict__ actions,
