@@ -113,6 +113,7 @@ extern "C" int cadm_set_weights(cadm_ctx* ctx, int net, int layer, float* W, flo
     CADM_REQUIRE(layer >= 0 && layer < (int)v->size(), "cadm_set_weights: layer %d out of range for net %d", layer, net);
     DenseRef& d = (*v)[layer];
     d.W = W; d.b = b;
+    ctx->train_packs_stale = true;
     if (net == CADM_NET_CTX) {
         const int ncp = ctx->cfg.n_cp_hidden;
         d.din = layer == 0 ? (ctx->D + ctx->A) * ctx->cfg.history_length : ctx->cfg.cp_hidden[layer - 1];
@@ -151,6 +152,7 @@ int cadm_pack_streams(cadm_ctx* ctx, hipStream_t s) {
 extern "C" int cadm_repack(cadm_ctx* ctx, void* stream) {
     CADM_REQUIRE(ctx, "cadm_repack: null ctx");
     CADM_ON_DEVICE(ctx);
+    ctx->train_packs_stale = true;     // the caller announces new master weights: the training chains' copies follow at the next step
     return cadm_pack_streams(ctx, (hipStream_t)stream);
 }
 

@@ -108,6 +108,7 @@ struct cadm_ctx {
     std::vector<DenseRef> ff, back, cp;   // ff/back: NH hidden + mu + logvar; cp: n_cp_hidden + out
     float *ff_maxlv = nullptr, *ff_minlv = nullptr, *back_maxlv = nullptr, *back_minlv = nullptr;
     bool packed = false;
+    bool train_packs_stale = true;  // the training chains' packed operand streams (train.hip) must be rebuilt from the master weights
     // planner weight stream (ff net only): split-f16 fragments of the rollout kernel (xdl_geo.h)
     XdlGeo xg;
     unsigned short* xw = nullptr;   // [E][member_frags] fragments of 2 KB

@@ -61,9 +61,44 @@ __device__ __forceinline__ void adam_update(float& w, float& m, float& v, float 
 }
 
 // ---------------------------------------------------------------------------------------------
+// packed operand streams of the chain kernel (layout: ChainSeg)
+// ---------------------------------------------------------------------------------------------
+struct PackDst {          // where element (m, n) of a layer W [M][N] lives in one stream (tr: 0 forward, 1 transposed)
+    float* P; long sP;    // stream base, member stride (floats); P == null: no stream
+    int KB, kb0;          // k-blocks of the whole stream; this layer's first one (streams concatenated along k)
+    int row0, ncols;      // forward: Bop(k, n') = W[k][n'];  transposed: Bop(k, n') = W[row0 + n'][k];  n' < ncols
+    int nt, pad;          // tiles of the stream (even)
+};
+__device__ __forceinline__ long pack_index(const PackDst& d, int k, int np) {    // float index inside a member's stream
+    return (((long)(d.kb0 + (k >> 4)) * d.nt + (np >> 4)) * 64 + ((k >> 2) & 3) * 16 + (np & 15)) * 4 + (k & 3);
+}
+
+struct PackJob {
+    const float* W; int M, N;        // [E][M][N]
+    PackDst d; int tr, nk, ntile;    // nk: valid k; ntile: tiles of the stream (even)
+};
+// Full (re)build of one layer's part of a stream, zero padding included: one float4 per thread.
+__global__ void train_pack_kernel(const PackJob j, int E) {
+    const int KBl = (j.nk + 15) >> 4;
+    const long per = (long)j.ntile * KBl * 64, idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= per * E) return;
+    const int e = (int)(idx / per);
+    const long r = idx - e * per;
+    const int lane = (int)(r & 63), t = (int)((r >> 6) % KBl), tile = (int)((r >> 6) / KBl);
+    const int c = lane & 15, kq = lane >> 4, np = 16 * tile + c;
+    const float* W = j.W + (long)e * j.M * j.N;
+    floatx4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = 16 * t + 4 * kq + i;
+        v[i] = (k < j.nk && np < j.d.ncols) ? (j.tr ? W[(long)(j.d.row0 + np) * j.N + k] : W[(long)k * j.N + np]) : 0.0f;
+    }
+    *reinterpret_cast<floatx4*>(j.d.P + (long)e * j.d.sP + (((long)(j.d.kb0 + t) * j.d.nt + tile) * 64 + lane) * 4) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
 // chain kernel: a list of LOAD / GEMM stages over a 16-row batch tile held in LDS
 // ---------------------------------------------------------------------------------------------
-enum { ST_LOAD = 0, ST_GEMM = 1 };
 // Pointers read out of a stage table are generic to the compiler (flat_load: slower, and it ties the vector-memory
 // counter to the LDS one); they all point to device memory, so say so.
 typedef __attribute__((address_space(1))) const float* gcptr;
@@ -72,35 +107,45 @@ __device__ __forceinline__ gcptr as_global(const float* p) { return (gcptr)p; }
 __device__ __forceinline__ gptr as_global(float* p) { return (gptr)p; }
 #define CH_ROWS 16
 #define CH_THREADS 512        // 8 waves: two per SIMD, so one wave's LDS / load / scalar work overlaps the other's MFMAs
-#define CH_GW 32              // output columns per wave and pass (NT <= 2 MFMA tiles)
-#define CH_AD 3            // A fragments are read from LDS this many k-steps ahead
+#define CH_WAVES 8
+#define CH_RING 8             // operand blocks (16 k x 2 tiles) of a wave's ring; CH_RING - 1 are in flight
 #define CH_MAXSTAGE 20
+#define CH_BLK_FLOATS 256     // one operand block of one tile: 64 lanes x float4
 
-struct ChainPart {         // one product term of a GEMM stage: acc += src[16 x K] * Bop[K x N]
-    const float* W;        // [E][.][ldw]
-    long sWe;              // member stride (elements)
-    int ldw;               // row stride of W
-    int wt;                // 0: Bop(k,n) = W[k][n]   1: Bop(k,n) = W[row0 + n][k]  (backward: dZ W^T)
-    int row0, K, src, pad;
+// A GEMM stage computes acc[16 rows x N] = src[16 x K] * Bop[K x N] for up to two column SEGMENTS (e.g. the mu and
+// logvar heads side by side), each with its own operand stream, bias and outputs.  The operand stream is a packed copy
+// of the layer (train_pack_kernel; kept current by dw_adam_kernel's epilogue): per member [k-block][tile][lane] float4,
+// tile = 16 output columns, k-block = 16 k, lane (c, kq) holds Bop(16 t + 4 kq + i, 16 tile + c), i = 0..3 -- exactly
+// the A operand of four v_mfma_f32_16x16x4_f32 k-steps, zero-padded in both directions.  A wave reads the 2 KB of its
+// tile pair per k-block; the workgroup's waves -- and the member's other workgroups, which walk the same stages at the
+// same time -- together read one contiguous window of the stream per k-block (all of the L2's channels, not the few
+// that per-tile streams a fixed stride apart would hit).  The same load shape in every stage of every chain, forward
+// or transposed.
+struct ChainSeg {
+    const float* P;        // packed operand [E][KB][tiles (even)][64][4]
+    long sP;               // member stride (floats)
+    const float *bias, *zprev;                           // bias [E][N]; zprev [E][B][ldz]: pre-activation whose act' scales the result
+    float *out0, *out1;                                  // [E][B][ldo]: value before act_o / after
+    int N, ldo, ldz, vec;                                // vec: N, ldo, ldz, dk0 all multiples of 4 -> 16-byte accesses
+    int nt, pad[3];                                      // tiles of the stream
 };
 struct ChainStage {
-    int kind, N, nparts, act_d, act_o, dst, dk0, K;      // K, ld_in: LOAD only
-    ChainPart part[2];
-    const float *bias, *zprev, *g0, *g1;                 // g0 (+ g1): LOAD sources [E][B][ld_in]
-    float *out0, *out1, *gsum;                           // out0: value before act_o, out1: after; gsum: LOAD echo
-    int ldz, ldo, ld_in;
-    int zpad;                                            // rows to zero behind the written range of dst: the consumer's k loops run
-                                                         // whole 32-deep blocks without masking A (host: round32(width) - width)
+    int KB, src, dst, dk0, act_d, act_o, ntp, tp1;       // KB: k-blocks; ntp: tile pairs (all segments); tp1: first pair of segment 1
+    int zfill, pad[7];                                   // zfill: columns N .. of the last tile are written as zeros
+    ChainSeg seg[2];
 };
-#define CH_MAXPF 24
+struct ChainLoad {        // input tile -> LDS: K columns of g0 (+ g1) [E][B][ld_in] become rows dk0 .. dk0 + K - 1 of buffer dst,
+    const float *g0, *g1; // zeros up to row zero_to (the consumer's k loop runs whole 16-row blocks without masking)
+    float* gsum;          // echo of the sum [E][B][ldg]
+    int ld_in, ldg, K, dst, dk0, zero_to;
+};
 struct ChainArgs {
     const ChainStage* prog;
     int first[2], count[2];                              // stage range per chain (y)
+    ChainLoad pre[2][2]; int npre[2];                    // the chain's inputs (kernel arguments: they are requested before the table is)
     int B, bufsz;                                        // rows per member, floats per LDS activation buffer
     int E, ny, ntiles, G, ips;                           // work decomposition, see chain_kernel
-    int npf;                                             // weight tensors to pull into this XCD's L2 up front
-    const float* pf_ptr[CH_MAXPF]; int pf_n[CH_MAXPF];   // base, floats per member
-    unsigned long long* tbuf;                            // cadm_debug_set_timing_buffer: clocks of member 0's first work item:
+    unsigned long long* tbuf;                            // cadm_dev_set_timing_buffer: clocks of member 0's first work item:
                                                          // [0..63] stage boundaries, [64 + 4 si ..] wave 0: group start, k loop end,
                                                          // epilogue end, barrier reached
 };
@@ -109,39 +154,28 @@ typedef __attribute__((address_space(1))) const char* gcbytes;
 typedef __attribute__((address_space(1))) const floatx4* gcptr4;
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 
-// acc[j] += src(16 x K) * Bop(K x 16) for NT column tiles of this wave.  A comes from the LDS activation buffer
-// (k-major, lds[k * 16 + m]), B straight from global memory through a register ring PF k-steps deep, addressed as
-// (uniform base of the k-step) + (per-lane byte offset).  Three load shapes:
-//   MODE 0  dword per (tile, k-step); tile j <-> column nb + 16 j + c; any N, K, either weight orientation
-//   MODE 1  forward (Bop(k,n) = W[k][n]), N % 2 == 0: one b64 per k-step holds the 2 tiles, tile j <-> column nb + 2 c + j
-//   MODE 2  transposed (Bop(k,n) = W[n][k]), K % 4 == 0: one b128 per (tile, 4 k-steps), k-step 4 t + i <-> k = 16 t + 4 kq + i
-// The k loop is a compact rolled loop (this kernel runs each piece of code once per stage, so long unrolled
-// stretches turn into instruction-cache misses that cost more than the MFMAs: ~300 cycles per k-step were measured
-// with 32-step straight-line blocks).  B lives in four register blocks of PF k-steps that rotate: while block b is
-// consumed, blocks b+1, b+2 and b+3 are in flight, which covers the ~2000-cycle L2 latency seen when a member's 32
-// workgroups stream the same weights.
-// hipcc cannot express that pipeline: its s_waitcnt placement gives up across the loop back edge and waits for
-// every outstanding load at the first use, i.e. a lookahead of at most one block.  The weight loads are therefore
-// issued from inline asm (invisible to the compiler's counters) and ordered with explicit `s_waitcnt vmcnt(n)`:
-// loads return in issue order, so "at most n younger loads outstanding" is exact; older compiler-issued accesses
-// (epilogue operands, stores of the previous stage) only make a wait conservative.  Every wait is followed by a
-// sched_barrier so that no consumer can move above it, and nothing is left in flight when the function returns.
-// A block that reaches past K is padded, never predicated: k-step indices are clamped to the last one, whose lanes
-// beyond K use offsets clamped into the matrix, and A is zeroed for k >= K.
-// (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset): no vector address arithmetic per load
-__device__ __forceinline__ void async_load(float& dst, gcbytes base, unsigned off) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
-}
-__device__ __forceinline__ void async_load(floatx2& dst, gcbytes base, unsigned off) {
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
-}
-__device__ __forceinline__ void async_load(floatx4& dst, gcbytes base, unsigned off) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(off), "s"(base) : "memory");
-}
+// The operand ring lives in a[0:63], named literally: slot s holds block i (i % 8 == s) of the wave's two tiles in
+// a[8 s : 8 s + 3] and a[8 s + 4 : 8 s + 7].  Loads and MFMAs on it are inline asm, for two reasons:
+//  * hipcc cannot pipeline loads across a loop back edge (its s_waitcnt placement waits for every outstanding load at the
+//    first use behind it), let alone across a stage boundary; asm loads are invisible to its counters and are ordered
+//    with explicit `s_waitcnt vmcnt(n)`: vector-memory operations of a wave complete in issue order, so "at most n
+//    younger operations outstanding" is exact when the n youngest are ring loads and conservative when compiler-issued
+//    accesses (epilogue operands, z / h stores) sit between them;
+//  * a ring held in compiler-allocated registers gets MOVED at control-flow merges (the stage loop, the conditional
+//    refills): a copy of a register with a load in flight reads stale data, the hardware does not interlock that.
+//    Registers the compiler never sees cannot be moved.  (It has no reason to touch AGPRs in this kernel -- the ISA
+//    hygiene test checks that it does not.)
+// Wait states the hazard recognizer cannot place inside asm (cdna_hip_programming.md 5.7): `s_nop 4` between a
+// readfirstlane'd base and the load that reads it, `s_nop 1` between a VALU-written operand and the MFMA (ring_begin), 12 states between
+// the last MFMA and the first reader of its accumulator (ring_done).
+#define CH_RING_REGS                                                                                                                   \
+    "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19",   \
+        "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37",  \
+        "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55",  \
+        "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
 }
 // Values read out of the LDS stage table are wave-uniform, but the compiler cannot know: make them scalar.
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -150,236 +184,229 @@ __device__ __forceinline__ gcbytes uni(gcbytes p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
     return (gcbytes)(((unsigned long long)hi << 32) | lo);
 }
+__device__ __forceinline__ gcbytes uni_ptr(const float* p) { return uni((gcbytes)as_global(p)); }
 
-template <int NT, int MODE>
-__device__ __forceinline__ void chain_kloop(floatx4 (&acc)[NT], const ChainPart& pt, const float* src, int e, int nb, int N,
-                                            int lane) {
-    constexpr int PF = 8;                                  // k-steps per block
-    constexpr int NR0 = MODE == 0 ? PF : 1, NR1 = MODE == 1 ? PF : 1, NR2 = MODE == 2 ? PF / 4 : 1;
-    constexpr int LPB = MODE == 0 ? PF * NT : MODE == 1 ? PF : (PF / 4) * NT;      // loads per block
-    const int c = lane & 15, kq = lane >> 4;
-    const int K = uni(pt.K), ldw = uni(pt.ldw), wt = uni(pt.wt), prow0 = uni(pt.row0);
-    const int nsteps = MODE == 2 ? ((K + 15) >> 4) * 4 : (K + 3) >> 2, last = nsteps - 1;
-    const int nblk = (nsteps + PF - 1) / PF;
-    gcbytes Wm = uni((gcbytes)(as_global(pt.W) + (long)e * pt.sWe));
-    long step_bytes;                                        // per k-step (MODE 0/1) or per 4 k-steps (MODE 2)
-    unsigned boff[NT], boffl[NT];                           // per-lane byte offsets: regular / last (clamped) step
-    if (MODE == 0) {
-        const int ks = wt ? 1 : ldw, ns = wt ? ldw : 1;
-        const int kql = 4 * last + kq < K ? kq : K - 1 - 4 * last;
-        step_bytes = 16L * ks;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            int n = nb + 16 * j + c;
-            n = n < N ? n : N - 1;
-            boff[j] = 4u * (unsigned)((prow0 + n) * ns + kq * ks);
-            boffl[j] = 4u * (unsigned)((prow0 + n) * ns + kql * ks);
-        }
-    } else if (MODE == 1) {
-        int n2 = nb + 2 * c;
-        n2 = n2 < N ? n2 : N - 2;
-        const int kql = 4 * last + kq < K ? kq : K - 1 - 4 * last;
-        step_bytes = 16L * ldw;
-        boff[0] = 4u * (unsigned)(n2 + kq * ldw);
-        boffl[0] = 4u * (unsigned)(n2 + kql * ldw);
-    } else {
-        const int lastq = last >> 2;
-        const int k4l = 16 * lastq + 4 * kq <= K - 4 ? 4 * kq : K - 4 - 16 * lastq;
-        step_bytes = 64L;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            int n = nb + 16 * j + c;
-            n = n < N ? n : N - 1;
-            boff[j] = 4u * (unsigned)((prow0 + n) * ldw + 4 * kq);
-            boffl[j] = 4u * (unsigned)((prow0 + n) * ldw + k4l);
-        }
+// LDS activation tile: element (k, row m) at ((k >> 2) * 16 + m) * 4 + (k & 3): the B operand of a k-block is one
+// lane-linear ds_read_b128 (lane (m, kq) <- k = 16 t + 4 kq + 0..3), and a D fragment of the transposed product
+// (lane (m, q) holds columns 4 q + 0..3 of its tile) is written back as one lane-linear ds_write_b128.
+__device__ __forceinline__ int lds_at(int k, int m) { return ((k >> 2) * CH_ROWS + m) * 4 + (k & 3); }
+
+struct ChainGroup {       // one wave's work in one stage: a tile pair
+    int si, tp;           // stage, pair index (si < 0: none)
+    int KB;
+    gcbytes w0;           // block 0 of the pair (tile 1 right behind tile 0)
+    int bstep;            // bytes from one k-block to the next
+};
+
+// block i of the group -> ring slot S (both tiles); (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset)
+template <int S>
+__device__ __forceinline__ void ring_issue(const ChainGroup& g, int i, unsigned loff) {
+    gcbytes p0 = g.w0 + (long)i * g.bstep;
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 a[%2*8:%2*8+3], %0, %1\n\tglobal_load_dwordx4 a[%2*8+4:%2*8+7], %0, %1 offset:1024"
+                 :: "v"(loff), "s"(p0), "n"(S) : "memory", CH_RING_REGS);
+}
+// the first CH_RING - 1 blocks of a group: issued one stage ahead (before the previous group's stores and the barrier)
+template <int S>
+__device__ __forceinline__ void ring_prologue_from(const ChainGroup& g, unsigned loff) {
+    if (S < g.KB) {
+        ring_issue<S>(g, S, loff);
+        if constexpr (S + 1 < CH_RING - 1) ring_prologue_from<S + 1>(g, loff);
     }
-    struct Blk {
-        float r0[NR0][NT];
-        floatx2 r1[NR1];
-        floatx4 r2[NR2][NT];
-    };
-    Blk b0, b1, b2, b3;
-    float ar[4];
-    // loads of block bi (its PF k-steps) into a register block.  Blocks that end before the last k-step take the
-    // fast path: a scalar base walks the k-steps, the per-lane offsets never change.
-    auto issue_block = [&](Blk& blk, int bi) {
-        const int s0 = bi * PF;
-        constexpr int SPL = MODE == 2 ? 4 : 1;              // k-steps per load group
-        const int lim = MODE == 2 ? last >> 2 : last;
-        const int i0 = s0 / SPL;                            // first load-group index of the block
-        if (i0 + PF / SPL - 1 < lim) {
-            gcbytes base = Wm + i0 * step_bytes;
+}
+__device__ __forceinline__ void ring_prologue(const ChainGroup& g, unsigned loff) {
+    if (g.si >= 0) ring_prologue_from<0>(g, loff);
+}
+// tail of a group (nothing left to issue): at most `rem` younger blocks may still be outstanding.  Three levels instead of
+// seven: a taken scalar branch costs more than the MFMA it delays, and the blocks a coarser wait adds were issued at least
+// four block times ago.
+__device__ __forceinline__ void wait_blocks(int rem) {
+    if (rem >= 4) wait_vmcnt<8>();
+    else if (rem >= 2) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+}
+static_assert(CH_RING == 8, "wait_blocks, the ring's register names and the slot arithmetic assume a ring of 8");
+// acc += (weights of ring slot S, tile J, k-step U) x (activation column x): weights are the A operand, so a lane (m, q)
+// of D holds columns 4 q + 0..3 of the tile for batch row m
+template <int S, int J, int U>
+__device__ __forceinline__ void ring_mfma(floatx4& acc, float x) {
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, a[%2], %1, %0" : "+v"(acc) : "v"(x), "n"(S * 8 + J * 4 + U));
+}
+// consume block i (slot S): refill the slot freed by block i - 1, wait for block i, 8 MFMAs
+template <int S>
+__device__ __forceinline__ void ring_step(const ChainGroup& g, int i, unsigned loff, const float* abase, floatx4 (&xa)[4],
+                                          floatx4 (&acc)[2]) {
+    const int rem = g.KB - 1 - i;
+    if (rem >= CH_RING - 1) {
+        ring_issue<(S + CH_RING - 1) % CH_RING>(g, i + CH_RING - 1, loff);
+        wait_vmcnt<2 * (CH_RING - 1)>();
+    } else {
+        wait_blocks(rem);
+    }
+    const int ia = i + 2 < g.KB ? i + 2 : g.KB - 1;
+    xa[(S + 2) & 3] = *reinterpret_cast<const floatx4*>(abase + CH_BLK_FLOATS * ia);
+    __builtin_amdgcn_sched_barrier(0);     // keep the LDS read two blocks ahead of its use
+    const floatx4 x = xa[S & 3];
+    ring_mfma<S, 0, 0>(acc[0], x[0]); ring_mfma<S, 1, 0>(acc[1], x[0]);
+    ring_mfma<S, 0, 1>(acc[0], x[1]); ring_mfma<S, 1, 1>(acc[1], x[1]);
+    ring_mfma<S, 0, 2>(acc[0], x[2]); ring_mfma<S, 1, 2>(acc[1], x[2]);
+    ring_mfma<S, 0, 3>(acc[0], x[3]); ring_mfma<S, 1, 3>(acc[1], x[3]);
+}
+template <int S>
+__device__ __forceinline__ void ring_steps(const ChainGroup& g, int i0, unsigned loff, const float* abase, floatx4 (&xa)[4],
+                                           floatx4 (&acc)[2]) {
+    if (S == 0 || i0 + S < g.KB) {
+        ring_step<S>(g, i0 + S, loff, abase, xa, acc);
+        if constexpr (S + 1 < CH_RING) ring_steps<S + 1>(g, i0, loff, abase, xa, acc);
+    }
+}
+// VALU-written accumulators (the zeroing moves) -> first MFMA.  The MFMAs' other operands never come out of a VALU
+// instruction: weights are written by the ring's loads, activations by ds_read_b128 (tests/test_isa_hygiene.py checks the
+// instruction in front of every MFMA of this kernel).
+__device__ __forceinline__ void ring_begin(floatx4 (&acc)[2]) { asm volatile("s_nop 1" : "+v"(acc[0]), "+v"(acc[1])); }
+__device__ __forceinline__ void ring_done(floatx4 (&acc)[2]) {   // last MFMA -> first VALU read of its accumulator (8-pass op)
+    asm volatile("s_nop 11" : "+v"(acc[0]), "+v"(acc[1]));
+}
+
+__device__ __forceinline__ ChainGroup group_of(const ChainStage* stg, int si, int tp, int e) {
+    const ChainStage& st = stg[si];
+    const int tp1 = uni(st.tp1);
+    const int sg = tp >= tp1 ? 1 : 0;
+    const ChainSeg& seg = st.seg[sg];
+    ChainGroup g;
+    g.si = si; g.tp = tp; g.KB = uni(st.KB);
+    g.w0 = uni((gcbytes)(as_global(seg.P) + (long)e * seg.sP + (long)(2 * (tp - (sg ? tp1 : 0))) * CH_BLK_FLOATS));
+    g.bstep = uni(seg.nt) * (CH_BLK_FLOATS * 4);
+    return g;
+}
+// the wave's next tile pair behind (si, tp): the next pass of the same stage, else its pair in the next GEMM stage
+__device__ __forceinline__ ChainGroup next_group(const ChainStage* stg, int nst, int si, int tp, int wave, int e) {
+    if (si >= 0 && tp + CH_WAVES < uni(stg[si].ntp)) return group_of(stg, si, tp + CH_WAVES, e);
+    for (int sj = si + 1; sj < nst; ++sj)
+        if (wave < uni(stg[sj].ntp)) return group_of(stg, sj, wave, e);
+    ChainGroup g;
+    g.si = -1; g.tp = 0; g.KB = 0; g.w0 = nullptr; g.bstep = 0;
+    return g;
+}
+
+// Epilogue operands of a group (bias, act'(z) source): lane (m, q) needs columns 4 q + 0..3 of both tiles for row m.
+// Requested one stage ahead, right before the group's first ring blocks -- so that, in issue order, nothing but ring
+// loads follows a ring load and the k loop's vmcnt counts are exact (clamped, never predicated).
+struct ChainOps { floatx4 bv[2], zp[2]; };
+__device__ __forceinline__ void load_ops(const ChainStage* stg, const ChainGroup& g, int e, int B, int row0, int lane, ChainOps& o) {
+    if (g.si < 0) return;
+    const ChainStage& st = stg[g.si];
+    const int m = lane & 15, q = lane >> 4;
+    const int tp1 = uni(st.tp1);
+    const int sg = g.tp >= tp1 ? 1 : 0;
+    const ChainSeg& seg = st.seg[sg];
+    const int nb = 32 * (g.tp - (sg ? tp1 : 0));
+    const int N = uni(seg.N), ldz = uni(seg.ldz);
+    const bool VEC = uni(seg.vec) != 0;
+    gcbytes p_bias = uni_ptr(seg.bias), p_z = uni_ptr(seg.zprev);
+    const bool has_z = p_z != nullptr, has_b = p_bias != nullptr;
+    const long mrow = (long)e * B;
+    const int row = row0 + m, rowc = row < B ? row : B - 1;
 #pragma unroll
-            for (int u = 0; u < PF; u += SPL) {
-                if (MODE == 0) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) async_load(blk.r0[u][j], base, boff[j]);
-                } else if (MODE == 1) {
-                    async_load(blk.r1[u], base, boff[0]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) async_load(blk.r2[u >> 2][j], base, boff[j]);
-                }
-                base += step_bytes;
-            }
+    for (int j = 0; j < 2; ++j) {
+        const int n0 = nb + 16 * j + 4 * q;
+        if (VEC) {
+            const int nc = n0 < N ? n0 : 0;
+            gcbytes bb = has_b ? p_bias + ((long)e * N + nc) * 4 : g.w0;
+            gcbytes zb = has_z ? p_z + ((mrow + rowc) * ldz + nc) * 4 : g.w0;
+            o.bv[j] = *reinterpret_cast<gcptr4>(bb);
+            o.zp[j] = *reinterpret_cast<gcptr4>(zb);
         } else {
 #pragma unroll
-            for (int u = 0; u < PF; u += SPL) {
-                const int sidx = i0 + u / SPL;
-                const int sc = sidx < lim ? sidx : lim;
-                gcbytes base = Wm + sc * step_bytes;
-                const bool tail = sidx >= lim;
-                if (MODE == 0) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) async_load(blk.r0[u][j], base, tail ? boffl[j] : boff[j]);
-                } else if (MODE == 1) {
-                    async_load(blk.r1[u], base, tail ? boffl[0] : boff[0]);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) async_load(blk.r2[u >> 2][j], base, tail ? boffl[j] : boff[j]);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + r, nc = n < N ? n : N - 1;
+                gcbytes bb = has_b ? p_bias + ((long)e * N + nc) * 4 : g.w0;
+                gcbytes zb = has_z ? p_z + ((mrow + rowc) * ldz + nc) * 4 : g.w0;
+                o.bv[j][r] = *reinterpret_cast<gcptr>(bb);
+                o.zp[j][r] = *reinterpret_cast<gcptr>(zb);
             }
         }
-    };
-    // A fragment of k-step sidx: MODE 0/1 lds[(4 sidx + kq) * 16 + c] = lds[64 sidx + lane]; MODE 2 (sidx = 4 t + i)
-    // lds[(16 t + 4 kq + i) * 16 + c].  Neither clamped nor masked: the producing stage zeroed rows K .. round32(K)
-    // (ChainStage::zpad), and anything a lookahead read fetches beyond that is never used.  (A per-step
-    // compare + select feeding the MFMA costs ~30 cycles per k-step that do not overlap with the matrix pipe.)
-    const float* abase = MODE == 2 ? src + 64 * kq + c : src + lane;
-    auto read_a = [&](int sidx) { return MODE == 2 ? abase[256 * (sidx >> 2) + 16 * (sidx & 3)] : abase[64 * sidx]; };
-    auto compute_block = [&](const Blk& blk, int bi) {
-        const int s0 = bi * PF;
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            float b[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) b[j] = MODE == 0 ? blk.r0[u][j] : MODE == 1 ? blk.r1[u][j] : blk.r2[u >> 2][j][u & 3];
-            const float av = ar[u & 3];
-            ar[(u + CH_AD) & 3] = read_a(s0 + u + CH_AD);
-            __builtin_amdgcn_sched_barrier(0);     // keep the LDS read CH_AD steps ahead of its use
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[j], acc[j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    // consume block bi from `cur`; `nxt` is the register block that was consumed last (free) and receives block bi + 3
-    auto step = [&](Blk& cur, Blk& nxt, int bi) {
-        const int rem = nblk - 1 - bi;             // blocks after this one
-        if (rem >= 3) { issue_block(nxt, bi + 3); wait_vmcnt<3 * LPB>(); }
-        else if (rem == 2) wait_vmcnt<2 * LPB>();
-        else if (rem == 1) wait_vmcnt<LPB>();
-        else wait_vmcnt<0>();
-        compute_block(cur, bi);
-    };
-    __builtin_amdgcn_sched_barrier(0);
-    issue_block(b0, 0);
-    if (nblk > 1) issue_block(b1, 1);
-    if (nblk > 2) issue_block(b2, 2);
-#pragma unroll
-    for (int u = 0; u < CH_AD; ++u) ar[u] = read_a(u);
-#pragma unroll 1
-    for (int bi = 0; bi < nblk; bi += 4) {
-        step(b0, b3, bi);
-        if (bi + 1 < nblk) step(b1, b0, bi + 1);
-        if (bi + 2 < nblk) step(b2, b1, bi + 2);
-        if (bi + 3 < nblk) step(b3, b2, bi + 3);
     }
 }
 
-// One GEMM stage for NT column tiles of this wave (VECN: tile j <-> column nb + 2 c + j, else nb + 16 j + c): all parts,
-// then the epilogue.
-__device__ __forceinline__ gcbytes uni_ptr(const float* p) { return uni((gcbytes)as_global(p)); }
-
-template <int NT, bool VECN>
-__device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, int bufsz, int e, int B, int row0, int nb,
-                                            int lane, unsigned long long* dbg) {
+// One tile pair of a GEMM stage: k loop over the ring, epilogue.  At the end of the epilogue -- behind this group's
+// stores -- the NEXT group's operands and first ring blocks are requested: by the time the stage-end barrier has been
+// passed they have landed, so a stage starts with MFMAs instead of an L2 round trip.
+__device__ __forceinline__ void chain_group(const ChainStage* stg, const ChainGroup& g, const ChainGroup& nxt, ChainOps& ops,
+                                            float* bufs, int bufsz, int e, int B, int row0, int lane, unsigned long long* dbg) {
     if (dbg) dbg[0] = __builtin_readcyclecounter();
-    const int c = lane & 15, q = lane >> 4;
+    const ChainStage& st = stg[g.si];
+    const int m = lane & 15, q = lane >> 4;
+    const unsigned loff = 16u * (unsigned)lane;
+    const int tp1 = uni(st.tp1);
+    const int sg = g.tp >= tp1 ? 1 : 0;
+    const ChainSeg& seg = st.seg[sg];
+    const int nb = 32 * (g.tp - (sg ? tp1 : 0));          // first column of the pair inside its segment
     // stage constants -> SGPRs (they come out of LDS): scalar address bases, uniform branches on the activation kinds
-    const int N = uni(st.N), ldo = uni(st.ldo), ldz = uni(st.ldz), dk0 = uni(st.dk0), dsti = uni(st.dst);
-    const int act_d = uni(st.act_d), act_o = uni(st.act_o), nparts = uni(st.nparts);
-    gcbytes p_bias = uni_ptr(st.bias), p_z = uni_ptr(st.zprev), p_o0 = uni_ptr(st.out0), p_o1 = uni_ptr(st.out1);
-    const bool has_z = p_z != nullptr, has_b = p_bias != nullptr, s0 = p_o0 != nullptr, s1 = p_o1 != nullptr;
+    const int N = uni(seg.N), ldo = uni(seg.ldo), dk0 = uni(st.dk0), dsti = uni(st.dst);
+    const int act_d = uni(st.act_d), act_o = uni(st.act_o), zfill = uni(st.zfill);
+    const bool VEC = uni(seg.vec) != 0;
+    gcbytes p_o0 = uni_ptr(seg.out0), p_o1 = uni_ptr(seg.out1);
+    const bool has_z = uni_ptr(seg.zprev) != nullptr, has_b = uni_ptr(seg.bias) != nullptr, s0 = p_o0 != nullptr, s1 = p_o1 != nullptr;
     const long mrow = (long)e * B;                        // first row of this member in the [E][B][.] tensors
-    floatx4 acc[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    // epilogue operands requested before the k loop so that their latency hides under it (clamped, never predicated)
-    float zp[NT][4], bv[NT];
-    int ncl[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int n = VECN ? nb + 2 * c + j : nb + 16 * j + c;
-        ncl[j] = n < N ? n : N - 1;
-    }
-    {
-        gcbytes bb = has_b ? p_bias + (long)e * N * 4 : (gcbytes)as_global(st.part[0].W);
-        gcbytes zb = has_z ? p_z + mrow * ldz * 4 : (gcbytes)as_global(st.part[0].W);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            bv[j] = *reinterpret_cast<gcptr>(bb + (has_b ? 4u * (unsigned)ncl[j] : 0u));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int row = row0 + 4 * q + r;
-                row = row < B ? row : B - 1;
-                zp[j][r] = *reinterpret_cast<gcptr>(zb + (has_z ? 4u * (unsigned)(row * ldz + ncl[j]) : 0u));
-            }
-        }
-    }
-    for (int pi = 0; pi < nparts; ++pi) {
-        const ChainPart& pt = st.part[pi];
-        const float* src = bufs + pt.src * bufsz;
-        if (VECN) chain_kloop<NT, 1>(acc, pt, src, e, nb, N, lane);
-        else if (pt.wt && (pt.K & 3) == 0 && (pt.ldw & 3) == 0) chain_kloop<NT, 2>(acc, pt, src, e, nb, N, lane);
-        else chain_kloop<NT, 0>(acc, pt, src, e, nb, N, lane);
+    const int row = row0 + m;
+    const floatx4 bv[2] = {ops.bv[0], ops.bv[1]}, zp[2] = {ops.zp[0], ops.zp[1]};
+    const int n0[2] = {nb + 4 * q, nb + 16 + 4 * q};
+    floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+    {   // ---- k loop: block i of the pair sits in ring slot i % 8; its loads were issued 7 blocks earlier ----
+        const float* abase = bufs + uni(st.src) * bufsz + 4 * lane;       // activation block i: + 256 i floats
+        floatx4 xa[4];
+        xa[0] = *reinterpret_cast<const floatx4*>(abase);
+        xa[1] = *reinterpret_cast<const floatx4*>(abase + CH_BLK_FLOATS * (g.KB > 1 ? 1 : 0));
+        ring_begin(acc);
+#pragma unroll 1
+        for (int i0 = 0; i0 < g.KB; i0 += CH_RING) ring_steps<0>(g, i0, loff, abase, xa, acc);
+        ring_done(acc);
     }
     if (dbg) dbg[1] = __builtin_readcyclecounter();
-    // D layout: col = lane & 15 -> column slot c, row = (lane >> 4) * 4 + r -> batch row
-    floatx4 v0[NT], v1[NT];                       // [tile][r]: before / after the output activation
+    floatx4 v0[2], v1[2];                         // [tile][r]: before / after the output activation
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v0[j][r] = acc[j][r] + (has_b ? bv[j] : 0.0f);
+        for (int r = 0; r < 4; ++r) v0[j][r] = acc[j][r] + (has_b ? bv[j][r] : 0.0f);
     if (has_z) {
         if (act_d == ACT_SWISH) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float z = zp[j][r], sg = sigmoid_fast(z);
-                    v0[j][r] *= sg * (1.0f + z * (1.0f - sg));
+                    const float z = zp[j][r], sg_ = sigmoid_fast(z);
+                    v0[j][r] *= sg_ * (1.0f + z * (1.0f - sg_));
                 }
         } else if (act_d == ACT_RELU) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v0[j][r] = zp[j][r] > 0.0f ? v0[j][r] : 0.0f;
         } else if (act_d == ACT_TANH) {          // 1 - tanh(z)^2 = 4 s (1 - s), s = sigmoid(2z)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float sg = sigmoid_fast(2.0f * zp[j][r]); v0[j][r] *= 4.0f * sg * (1.0f - sg); }
+                for (int r = 0; r < 4; ++r) { const float sg_ = sigmoid_fast(2.0f * zp[j][r]); v0[j][r] *= 4.0f * sg_ * (1.0f - sg_); }
         } else if (act_d == ACT_SIGMOID) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float sg = sigmoid_fast(zp[j][r]); v0[j][r] *= sg * (1.0f - sg); }
+                for (int r = 0; r < 4; ++r) { const float sg_ = sigmoid_fast(zp[j][r]); v0[j][r] *= sg_ * (1.0f - sg_); }
         }
     }
     if (act_o == ACT_SWISH) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v1[j][r] = v0[j][r] * sigmoid_fast(v0[j][r]);
     } else if (act_o == ACT_RELU) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v1[j][r] = fmaxf(v0[j][r], 0.0f);
     } else if (act_o == ACT_TANH) {              // as the planner: 2 sigmoid(2z) - 1, odd series near 0 where that cancels
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float x = v0[j][r], x2 = x * x;
@@ -388,63 +415,92 @@ __device__ __forceinline__ void chain_group(const ChainStage& st, float* bufs, i
             }
     } else if (act_o == ACT_SIGMOID) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v1[j][r] = sigmoid_fast(v0[j][r]);
     } else {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) v1[j] = v0[j];
+        for (int j = 0; j < 2; ++j) v1[j] = v0[j];
     }
     if (dsti >= 0) {
         float* dst = bufs + dsti * bufsz;
+        if (VEC) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = VECN ? nb + 2 * c + j : nb + 16 * j + c;
-            if (n < N) *reinterpret_cast<floatx4*>(dst + (dk0 + n) * CH_ROWS + 4 * q) = v1[j];
+            for (int j = 0; j < 2; ++j)
+                *reinterpret_cast<floatx4*>(dst + lds_at(dk0 + n0[j], m)) = n0[j] < N ? v1[j] : floatx4{0.f, 0.f, 0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0[j] + r;
+                    if (n < N || zfill) dst[lds_at(dk0 + n, m)] = n < N ? v1[j][r] : 0.0f;
+                }
         }
     }
-    // global stores: (uniform base of this member) + 32-bit byte offset (host checks E * B * ldo * 4 < 2^32)
+    // global stores: (uniform base of this member) + 32-bit byte offset (host checks B * ldo * 4 < 2^32)
     gcbytes b0 = p_o0 + mrow * ldo * 4, b1 = p_o1 + mrow * ldo * 4;
     typedef __attribute__((address_space(1))) float* gfp;
-    typedef __attribute__((address_space(1))) floatx2* gf2p;
-    if (VECN && (ldo & 1) == 0) {                 // a lane's 2 tiles are 2 adjacent columns: b64 stores
-        const int n = nb + 2 * c;
-        if (n < N) {
-            // every store's data pair is built in ITS OWN registers before the first store is issued: a store reads its
-            // data registers asynchronously, so re-using a pair makes hipcc wait (vmcnt) for the previous store to complete
-            // -- eight full store round trips, ~2.6 k cycles per stage, were measured that way
-            floatx2 p0[4], p1[4];
+    typedef __attribute__((address_space(1))) floatx4* gf4p;
+    if (row < B) {
+        if (VEC) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                p0[r] = floatx2{v0[0][r], v0[1 % NT][r]};
-                p1[r] = floatx2{v1[0][r], v1[1 % NT][r]};
+            for (int j = 0; j < 2; ++j) {
+                if (n0[j] >= N) continue;
+                const unsigned o = 4u * (unsigned)(row * ldo + n0[j]);
+                if (s0) *(gf4p)(b0 + o) = v0[j];
+                if (s1) *(gf4p)(b1 + o) = v1[j];
             }
-            asm volatile("" : "+v"(p0[0]), "+v"(p0[1]), "+v"(p0[2]), "+v"(p0[3]), "+v"(p1[0]), "+v"(p1[1]), "+v"(p1[2]), "+v"(p1[3]));
+        } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 4 * q + r;
-                if (row >= B) continue;
-                const unsigned o = 4u * (unsigned)(row * ldo + n);
-                if (s0) *(gf2p)(b0 + o) = p0[r];
-                if (s1) *(gf2p)(b1 + o) = p1[r];
-            }
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0[j] + r;
+                    if (n >= N) continue;
+                    const unsigned o = 4u * (unsigned)(row * ldo + n);
+                    if (s0) *(gfp)(b0 + o) = v0[j][r];
+                    if (s1) *(gfp)(b1 + o) = v1[j][r];
+                }
         }
-    } else {
+    }
+    load_ops(stg, nxt, e, B, row0, lane, ops);
+    ring_prologue(nxt, loff);
+    if (dbg) dbg[2] = __builtin_readcyclecounter();
+}
+
+// The chain's input tiles.  Thread idx of a tile's index space owns LDS dword idx of the destination range (lane-linear,
+// conflict-free): (k & 3) fastest, then the row, then the k quad.  Loads are issued four deep before the first is used.
+__device__ __forceinline__ void chain_input(const ChainLoad& d, float* bufs, int bufsz, int e, int B, int row0, int tid) {
+    float* dst = bufs + d.dst * bufsz + (d.dk0 >> 2) * (4 * CH_ROWS);
+    const int total = ((d.zero_to - d.dk0) >> 2) * (4 * CH_ROWS);
+    gcptr g0 = as_global(d.g0), g1 = as_global(d.g1);
+    const bool two = d.g1 != nullptr;
+#pragma unroll 1
+    for (int base = 0; base < total; base += 4 * CH_THREADS) {
+        float v[4], w[4];
+        bool ok[4];
+        long off[4];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = VECN ? nb + 2 * c + j : nb + 16 * j + c;
-            if (n >= N) continue;
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * CH_THREADS + tid;
+            const int k = (idx >> 6) * 4 + (idx & 3), m = (idx >> 2) & 15, row = row0 + m;
+            ok[u] = idx < total && k < d.K && row < B;
+            off[u] = ok[u] ? ((long)e * B + row) * d.ld_in + k : 0;
+            v[u] = g0[off[u]];
+            w[u] = two ? g1[off[u]] : 0.0f;
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = row0 + 4 * q + r;
-                if (row >= B) continue;
-                const unsigned o = 4u * (unsigned)(row * ldo + n);
-                if (s0) *(gfp)(b0 + o) = v0[j][r];
-                if (s1) *(gfp)(b1 + o) = v1[j][r];
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * CH_THREADS + tid;
+            const float x = ok[u] ? v[u] + w[u] : 0.0f;
+            if (idx < total) dst[idx] = x;
+            if (ok[u] && d.gsum) {
+                const int k = (idx >> 6) * 4 + (idx & 3), m = (idx >> 2) & 15;
+                as_global(d.gsum)[((long)e * B + row0 + m) * d.ldg + k] = x;
             }
         }
     }
-    if (dbg) dbg[2] = __builtin_readcyclecounter();
 }
 
 // Work decomposition.  Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8), and every XCD has
@@ -462,88 +518,47 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float chain_smem[];
     ChainStage* const stg = reinterpret_cast<ChainStage*>(chain_smem);
     float* const bufs = chain_smem + (CH_MAXSTAGE * sizeof(ChainStage)) / sizeof(float);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
     int e, item;
     const int per = a.ntiles * a.ny;
     if (!xcd_affine_item(a.E, a.G, a.ips, per, e, item)) return;
     const int y = item / a.ntiles, row0 = (item - y * a.ntiles) * CH_ROWS, B = a.B;
     const int nst = a.count[y];
-    {   // stage table of this chain -> LDS (one memory latency instead of one per stage)
+    // stage table of this chain -> LDS (one memory latency instead of one per stage); requested first, stored behind the
+    // input tiles, which are described by kernel arguments and so are on their way before the table has arrived
+    constexpr int TW = (CH_MAXSTAGE * (int)(sizeof(ChainStage) / sizeof(int)) + CH_THREADS - 1) / CH_THREADS;
+    int tv[TW];
+    const int nw = nst * (int)(sizeof(ChainStage) / sizeof(int));
+    {
         const int* g = reinterpret_cast<const int*>(a.prog + a.first[y]);
-        int* l = reinterpret_cast<int*>(stg);
-        const int nw = nst * (int)(sizeof(ChainStage) / sizeof(int));
-        for (int i = tid; i < nw; i += CH_THREADS) l[i] = g[i];
-    }
-    // Pull this member's weights into the XCD's L2 now (one 128-byte line per load, spread over the member's
-    // workgroups) so that the stages below start from L2, not from HBM.  The loads are fire-and-forget: inline
-    // asm keeps them out of the compiler's vmcnt bookkeeping (older loads only make its waits conservative), and
-    // `pf` stays live until the closing s_waitcnt so the destination register cannot be reused early.
-    float pf = 0.0f;
-    for (int i = 0; i < a.npf; ++i) {
-        gcptr base = as_global(a.pf_ptr[i]) + (long)e * a.pf_n[i];
-        const int nlines = (a.pf_n[i] + 31) >> 5;
-        for (int line = (item / a.G) * CH_THREADS + tid; line < nlines; line += a.ips * CH_THREADS) {
-            gcptr q = base + line * 32;
-            asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(q) : "memory");
+#pragma unroll
+        for (int u = 0; u < TW; ++u) {
+            const int i = tid + u * CH_THREADS;
+            tv[u] = g[i < nw ? i : 0];
         }
     }
+    for (int i = 0; i < a.npre[y]; ++i) chain_input(a.pre[y][i], bufs, a.bufsz, e, B, row0, tid);
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+        if (tid + u * CH_THREADS < nw) reinterpret_cast<int*>(stg)[tid + u * CH_THREADS] = tv[u];
     __syncthreads();
     const bool timed = a.tbuf && item == 0 && e == 0 && tid == 0;
     if (timed) a.tbuf[0] = __builtin_readcyclecounter();
+    ChainOps ops;
+    ChainGroup cur = next_group(stg, nst, -1, 0, wave, e);
+    load_ops(stg, cur, e, B, row0, lane, ops);
+    ring_prologue(cur, 16u * (unsigned)lane);
     for (int si = 0; si < nst; ++si) {
-        const ChainStage& st = stg[si];
-        if (st.zpad > 0) {      // nobody reads dst during this stage, its readers wait for the stage-end barrier
-            float* zb = bufs + st.dst * a.bufsz + (st.dk0 + (st.kind == ST_LOAD ? st.K : st.N)) * CH_ROWS;
-            for (int i = tid; i < st.zpad * CH_ROWS / 4; i += CH_THREADS) reinterpret_cast<floatx4*>(zb)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (st.kind == ST_LOAD) {
-            float* dst = bufs + st.dst * a.bufsz;
-            const int K = st.K;
-            if (((K | st.ld_in | st.ldo) & 3) == 0) {          // b128 path: every thread's loads are in flight together
-                const int K4 = K >> 2;
-                for (int idx = tid; idx < CH_ROWS * K4; idx += CH_THREADS) {
-                    const int m = idx / K4, k = (idx - m * K4) * 4;
-                    const int row = row0 + m;
-                    floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
-                    if (row < B) {
-                        const long o = ((long)e * B + row) * st.ld_in + k;
-                        v = *reinterpret_cast<gcptr4>(as_global(st.g0) + o);
-                        if (st.g1) v += *reinterpret_cast<gcptr4>(as_global(st.g1) + o);
-                        if (st.gsum) *reinterpret_cast<__attribute__((address_space(1))) floatx4*>(as_global(st.gsum) + ((long)e * B + row) * st.ldo + k) = v;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) dst[(st.dk0 + k + i) * CH_ROWS + m] = v[i];
-                }
-            } else {
-                for (int idx = tid; idx < CH_ROWS * K; idx += CH_THREADS) {
-                    const int m = idx / K, k = idx - m * K;
-                    const int row = row0 + m;
-                    float v = 0.0f;
-                    if (row < B) {
-                        const long o = ((long)e * B + row) * st.ld_in + k;
-                        v = as_global(st.g0)[o];
-                        if (st.g1) v += as_global(st.g1)[o];
-                        if (st.gsum) as_global(st.gsum)[((long)e * B + row) * st.ldo + k] = v;
-                    }
-                    dst[(st.dk0 + k) * CH_ROWS + m] = v;
-                }
-            }
-        } else {
-            const int N = st.N;
-            for (int nb = wave * CH_GW; nb < N; nb += CH_GW * (CH_THREADS / 64)) {
-                const int nt = (N - nb + 15) >> 4;
-                const ChainPart& p0 = st.part[0];
-                unsigned long long* dbg = timed ? a.tbuf + 64 + si * 4 : nullptr;
-                if (st.nparts == 1 && !p0.wt && (N & 1) == 0 && (p0.ldw & 1) == 0) chain_group<2, true>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
-                else if (nt >= 2) chain_group<2, false>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
-                else chain_group<1, false>(st, bufs, a.bufsz, e, B, row0, nb, lane, dbg);
-            }
+        while (cur.si == si) {
+            const ChainGroup nxt = next_group(stg, nst, si, cur.tp, wave, e);
+            unsigned long long* dbg = timed ? a.tbuf + 64 + si * 4 : nullptr;
+            chain_group(stg, cur, nxt, ops, bufs, a.bufsz, e, B, row0, lane, dbg);
+            cur = nxt;
         }
         if (timed) a.tbuf[64 + si * 4 + 3] = __builtin_readcyclecounter();
         __syncthreads();
         if (timed) a.tbuf[si + 1] = __builtin_readcyclecounter();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::"v"(pf) : "memory");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -555,6 +570,7 @@ struct DwJob {                       // W[e] (M x N) <- Adam(W, X[e]^T dZ[e] + w
     int ldx, M, N, tile0;            // tile0: first workgroup (blockIdx.x) of this job
     float wdc;
     int tn;                          // column tiles
+    PackDst pf, pb;                  // the chain kernel's packed copies of W (forward / transposed operand), kept current here
 };
 #define DW_MAXJOBS 20
 struct DwArgs {
@@ -562,6 +578,7 @@ struct DwArgs {
     int njobs, B, tiles, E;          // tiles: work items per member
     float lr_t, b1, b2, eps;
 };
+static_assert(sizeof(DwArgs) <= 4096, "kernel argument block");
 
 #define TN 64
 #define TM 48
@@ -697,6 +714,17 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
             *reinterpret_cast<floatx4*>(jb.W + o) = w;
             *reinterpret_cast<floatx4*>(jb.Mw + o) = mo;
             *reinterpret_cast<floatx4*>(jb.Vw + o) = vo;
+            // packed copies: forward operand (k = m, column n): the 4 columns are 4 lanes of one block; transposed operand
+            // (k = n, column m - row0): the 4 columns are one lane's 4 k
+            if (jb.pf.P) {
+                float* q = jb.pf.P + (long)e * jb.pf.sP + pack_index(jb.pf, m, n);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) q[4 * c] = w[c];
+            }
+            if (jb.pb.P) {
+                const int np = m - jb.pb.row0;
+                if (np >= 0 && np < jb.pb.ncols) *reinterpret_cast<floatx4*>(jb.pb.P + (long)e * jb.pb.sP + pack_index(jb.pb, n, np)) = w;
+            }
         }
     } else {
 #pragma unroll
@@ -710,6 +738,9 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
                 float w = jb.W[o], mo = jb.Mw[o], vo = jb.Vw[o];
                 adam_update(w, mo, vo, acc[i][r] + jb.wdc * w, a.lr_t, a.b1, a.b2, a.eps);
                 jb.W[o] = w; jb.Mw[o] = mo; jb.Vw[o] = vo;
+                if (jb.pf.P) jb.pf.P[(long)e * jb.pf.sP + pack_index(jb.pf, m, n)] = w;
+                const int np = m - jb.pb.row0;
+                if (jb.pb.P && np >= 0 && np < jb.pb.ncols) jb.pb.P[(long)e * jb.pb.sP + pack_index(jb.pb, n, np)] = w;
             }
     }
     if (do_colsum && nb + tid < N) {
@@ -966,10 +997,15 @@ struct TrainState {
     std::vector<AdamSlot> a_ff, a_bk, a_cp;   // 2 per layer
     AdamSlot a_mx, a_mn;
     float* adam_buf = nullptr;
+    // packed operand streams of the chain kernel, per registered layer (forward / transposed); one allocation
+    std::vector<PackDst> pf_ff, pb_ff, pf_bk, pb_bk, pf_cp, pb_cp;
+    std::vector<int> pt_ff, pt_bk, pt_cp, ptb_ff, ptb_bk, ptb_cp;     // tiles (even) of the forward / transposed stream
+    float* pack_buf = nullptr;
     // chain programs: [fwd ff | fwd back | bwd ff | bwd back | bwd context]
     std::vector<ChainStage> prog_host;
     ChainStage* prog_dev = nullptr;
     int prog_first[5] = {0, 0, 0, 0, 0}, prog_count[5] = {0, 0, 0, 0, 0};
+    ChainLoad pre[5][2]; int npre[5] = {0, 0, 0, 0, 0};         // the programs' input tiles (kernel arguments of the launch)
     int chain_bufsz = 0;
 };
 
@@ -978,6 +1014,7 @@ void cadm_train_free(cadm_ctx* ctx) {
     if (ctx->train->ws) (void)hipFree(ctx->train->ws);
     if (ctx->train->adam_buf) (void)hipFree(ctx->train->adam_buf);
     if (ctx->train->prog_dev) (void)hipFree(ctx->train->prog_dev);
+    if (ctx->train->pack_buf) (void)hipFree(ctx->train->pack_buf);
     delete ctx->train;
     ctx->train = nullptr;
 }
@@ -1008,6 +1045,90 @@ static int alloc_adam(cadm_ctx* ctx) {
     t->a_mx.n = t->a_mn.n = ctx->D;
     t->a_mx.m = q; q += ctx->D; t->a_mx.v = q; q += ctx->D;
     t->a_mn.m = q; q += ctx->D; t->a_mn.v = q; q += ctx->D;
+    return CADM_OK;
+}
+
+static inline int kblocks(int k) { return (k + 15) >> 4; }
+static inline int even_tiles(int n) { return 2 * ((((n + 15) >> 4) + 1) / 2); }
+
+// Streams of the chain kernel's stages (geometry only; filled by pack_streams and kept current by dw_adam_kernel):
+//   forward    every layer: Bop(k, n) = W[k][n]
+//   transposed hidden layers l >= 1 and the context net's layers l >= 1: Bop(k, n') = W[n'][k];
+//              layer 0 of a dynamics net: only its context rows (row0 = P + A, C of them) carry a gradient;
+//              the heads mu (| logvar) of a net share ONE stream, concatenated along k: dz = [dMu | dLv] [Wmu | Wlv]^T
+static int alloc_packs(cadm_ctx* ctx) {
+    TrainState* t = ctx->train;
+    const int E = ctx->E, NH = ctx->NH, D = ctx->D, C = ctx->C, PA = ctx->P + ctx->A;
+    const bool has_back = ctx->cfg.back_model != 0, has_cp = C > 0, det = ctx->cfg.deterministic != 0;
+    size_t total = 0;
+    auto region = [&](PackDst& d, int ntile) { d.nt = ntile; d.sP = (long)ntile * d.KB * CH_BLK_FLOATS; d.P = reinterpret_cast<float*>(total + 1); total += (size_t)E * d.sP; };
+    auto net = [&](const std::vector<DenseRef>& L, bool dyn, bool with_lv, std::vector<PackDst>& pf, std::vector<PackDst>& pb,
+                   std::vector<int>& pt, std::vector<int>& ptb) {
+        const int n = (int)L.size();
+        pf.assign(n, PackDst{}); pb.assign(n, PackDst{}); pt.assign(n, 0); ptb.assign(n, 0);
+        for (int l = 0; l < n; ++l) {
+            if (dyn && l == NH + 1 && !with_lv) continue;          // logvar head outside the data path
+            PackDst& f = pf[l];
+            f.KB = kblocks(L[l].din); f.kb0 = 0; f.row0 = 0; f.ncols = L[l].dout;
+            pt[l] = even_tiles(L[l].dout);
+            region(f, pt[l]);
+            PackDst& b = pb[l];
+            if (dyn && l == 0) {
+                if (!has_cp) continue;
+                b.KB = kblocks(L[0].dout); b.kb0 = 0; b.row0 = PA; b.ncols = C;
+                ptb[0] = even_tiles(C);
+                region(b, ptb[0]);
+            } else if (dyn && l >= NH) {
+                const int KBd = kblocks(D);
+                b.KB = KBd * (with_lv ? 2 : 1); b.kb0 = (l - NH) * KBd; b.row0 = 0; b.ncols = L[l].din;
+                ptb[l] = even_tiles(L[l].din);
+                if (l == NH) region(b, ptb[l]);
+                else { b.P = pb[NH].P; b.sP = pb[NH].sP; b.nt = pb[NH].nt; }
+            } else if (l >= 1) {
+                b.KB = kblocks(L[l].dout); b.kb0 = 0; b.row0 = 0; b.ncols = L[l].din;
+                ptb[l] = even_tiles(L[l].din);
+                region(b, ptb[l]);
+            }
+        }
+    };
+    net(ctx->ff, true, !det, t->pf_ff, t->pb_ff, t->pt_ff, t->ptb_ff);
+    if (has_back) net(ctx->back, true, false, t->pf_bk, t->pb_bk, t->pt_bk, t->ptb_bk);
+    if (has_cp) net(ctx->cp, false, false, t->pf_cp, t->pb_cp, t->pt_cp, t->ptb_cp);
+    CADM_CHECK_HIP(hipMalloc(&t->pack_buf, total * sizeof(float)));
+    for (auto* v : {&t->pf_ff, &t->pb_ff, &t->pf_bk, &t->pb_bk, &t->pf_cp, &t->pb_cp})
+        for (auto& d : *v)
+            if (d.P) d.P = t->pack_buf + (reinterpret_cast<size_t>(d.P) - 1);
+    ctx->train_packs_stale = true;
+    return CADM_OK;
+}
+
+// (Re)build every stream from the registered master weights: after cadm_set_weights / cadm_repack, i.e. whenever the
+// caller may have written the weights; the training step itself updates them in dw_adam_kernel's epilogue.
+static int pack_streams(cadm_ctx* ctx, hipStream_t s) {
+    TrainState* t = ctx->train;
+    auto one = [&](const DenseRef& L, const PackDst& d, int tr, int nk, int ntile) -> int {
+        if (!d.P) return CADM_OK;
+        PackJob j{};
+        j.W = L.W; j.M = L.din; j.N = L.dout; j.d = d; j.tr = tr; j.nk = nk; j.ntile = ntile;
+        const long n = (long)ctx->E * ntile * kblocks(nk) * 64;
+        hipLaunchKernelGGL(train_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, j, ctx->E);
+        CADM_CHECK_HIP(hipGetLastError());
+        return CADM_OK;
+    };
+    auto net = [&](const std::vector<DenseRef>& L, std::vector<PackDst>& pf, std::vector<PackDst>& pb, std::vector<int>& pt,
+                   std::vector<int>& ptb) -> int {
+        int rc;
+        for (size_t l = 0; l < pf.size(); ++l) {
+            if ((rc = one(L[l], pf[l], 0, L[l].din, pt[l]))) return rc;
+            if ((rc = one(L[l], pb[l], 1, L[l].dout, ptb[l]))) return rc;
+        }
+        return CADM_OK;
+    };
+    int rc;
+    if ((rc = net(ctx->ff, t->pf_ff, t->pb_ff, t->pt_ff, t->ptb_ff))) return rc;
+    if (ctx->cfg.back_model && (rc = net(ctx->back, t->pf_bk, t->pb_bk, t->pt_bk, t->ptb_bk))) return rc;
+    if (ctx->C > 0 && (rc = net(ctx->cp, t->pf_cp, t->pb_cp, t->pt_cp, t->ptb_cp))) return rc;
+    ctx->train_packs_stale = false;
     return CADM_OK;
 }
 
@@ -1093,20 +1214,31 @@ namespace {
 
 enum { PROG_FWD_FF = 0, PROG_FWD_BK = 1, PROG_BWD_FF = 2, PROG_BWD_BK = 3, PROG_BWD_CP = 4 };
 
-int pad32(int w) { return ((w + 31) & ~31) - w; }
-
-// `complete`: this stage finishes the buffer (width dk0 + K) -> zero-pad behind it
-ChainStage load_stage(const float* g0, const float* g1, float* gsum, int ld_in, int ldo, int K, int dst, int dk0, bool complete = true) {
-    ChainStage s{};
-    s.kind = ST_LOAD; s.g0 = g0; s.g1 = g1; s.gsum = gsum; s.ld_in = ld_in; s.ldo = ldo; s.K = K; s.dst = dst; s.dk0 = dk0;
-    s.zpad = complete ? pad32(dk0 + K) : 0;
-    return s;
+ChainLoad input_tile(const float* g0, const float* g1, float* gsum, int ld_in, int ldg, int K, int dst, int dk0, int zero_to) {
+    ChainLoad d{};
+    d.g0 = g0; d.g1 = g1; d.gsum = gsum; d.ld_in = ld_in; d.ldg = ldg; d.K = K; d.dst = dst; d.dk0 = dk0; d.zero_to = zero_to;
+    return d;
 }
 
-ChainPart part_of(const DenseRef& L, int wt, int row0, int K, int src) {
-    ChainPart p{};
-    p.W = L.W; p.sWe = (long)L.din * L.dout; p.ldw = L.dout; p.wt = wt; p.row0 = row0; p.K = K; p.src = src;
-    return p;
+ChainStage gemm_stage(int src, int dst, int dk0, int act_d, int act_o) {
+    ChainStage g{};
+    g.src = src; g.dst = dst; g.dk0 = dk0; g.act_d = act_d; g.act_o = act_o; g.zfill = dst >= 0 && dk0 == 0;
+    return g;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+// appends a column segment (its packed operand `d` with `ntile` tiles) to a GEMM stage
+void add_seg(ChainStage& g, const PackDst& d, int ntile, const float* bias, const float* zprev, float* out0, float* out1, int N,
+             int ldo, int ldz) {
+    const int si = g.ntp == 0 ? 0 : 1;
+    ChainSeg& sg = g.seg[si];
+    sg.P = d.P; sg.sP = d.sP; sg.nt = d.nt; sg.bias = bias; sg.zprev = zprev; sg.out0 = out0; sg.out1 = out1; sg.N = N; sg.ldo = ldo; sg.ldz = ldz;
+    sg.vec = (N & 3) == 0 && ((!out0 && !out1) || (ldo & 3) == 0) && (!zprev || (ldz & 3) == 0) && (g.dst < 0 || (g.dk0 & 3) == 0) &&
+             aligned16(bias) && aligned16(zprev) && aligned16(out0) && aligned16(out1);
+    g.KB = d.KB;
+    g.ntp += ntile / 2;
+    if (si == 0) g.tp1 = g.ntp;          // (a second segment starts here)
 }
 
 // Builds the five stage lists for the current pointers and uploads them if anything changed.
@@ -1117,92 +1249,101 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
     const int ncp = has_cp ? ctx->cfg.n_cp_hidden : 0;
     const int cpin = (ctx->D + ctx->A) * ctx->cfg.history_length;
     std::vector<ChainStage> prog;
-    auto push_gemm = [&](ChainStage g) {
-        g.zpad = g.dst >= 0 ? pad32(g.dk0 + g.N) : 0;
+    int first[5], count[5];
+    int maxk = 16;                       // k extent of the widest LDS activation buffer
+    int cur_prog = 0;
+    for (int i = 0; i < 5; ++i) t->npre[i] = 0;
+    auto push = [&](const ChainStage& g) {
+        const int ext = g.dst >= 0 ? g.dk0 + 32 * g.ntp : 0;       // whole tile pairs are written (zeros behind N)
+        maxk = ext > maxk ? ext : maxk;
         prog.push_back(g);
     };
-    int first[5], count[5];
-    int maxk = K0 > HID ? K0 : HID;
-    maxk = D > maxk ? D : maxk;
-    if (has_cp) { maxk = cpin > maxk ? cpin : maxk; for (int l = 0; l < ncp; ++l) maxk = ctx->cfg.cp_hidden[l] > maxk ? ctx->cfg.cp_hidden[l] : maxk; }
+    auto input = [&](const ChainLoad& d) {
+        maxk = d.zero_to > maxk ? d.zero_to : maxk;
+        t->pre[cur_prog][t->npre[cur_prog]++] = d;
+    };
 
-    auto fwd_prog = [&](const std::vector<DenseRef>& net, float* X, NetBufs& nb, bool store_cp, bool want_lv) {
-        int cur = 0;
+    auto fwd_prog = [&](const std::vector<DenseRef>& net, const std::vector<PackDst>& pf, const std::vector<int>& pt, float* X,
+                        NetBufs& nb, bool store_cp, bool want_lv) {
+        int cur;
         if (has_cp) {
-            prog.push_back(load_stage(t->Xcp, nullptr, nullptr, cpin, 0, cpin, 0, 0));
+            // both inputs at once: the context encoder's history in buffer 0, this net's (obs, act) columns in buffer 2,
+            // where the encoder's last stage drops the context vector behind them
+            input(input_tile(t->Xcp, nullptr, nullptr, cpin, 0, cpin, 0, 0, 16 * kblocks(cpin)));
+            input(input_tile(X, nullptr, nullptr, K0, 0, PA, 2, 0, 16 * kblocks(K0)));
+            cur = 0;
             for (int l = 0; l <= ncp; ++l) {
                 const DenseRef& L = ctx->cp[l];
-                ChainStage g{};
-                g.kind = ST_GEMM; g.N = L.dout; g.nparts = 1; g.part[0] = part_of(L, 0, 0, L.din, cur);
-                g.bias = L.b; g.dst = cur ^ 1;
                 if (l < ncp) {
-                    g.act_o = ACT_RELU; g.ldo = L.dout;
-                    if (store_cp) { g.out0 = t->cp.z[l]; g.out1 = t->cp.h[l]; }
+                    ChainStage g = gemm_stage(cur, cur ^ 1, 0, ACT_NONE, ACT_RELU);
+                    add_seg(g, t->pf_cp[l], t->pt_cp[l], L.b, nullptr, store_cp ? t->cp.z[l] : nullptr, store_cp ? t->cp.h[l] : nullptr,
+                            L.dout, L.dout, 0);
+                    push(g);
+                    cur ^= 1;
                 } else {   // context vector -> the ctx columns of this net's input (LDS and global)
-                    g.act_o = ACT_NONE; g.out1 = X + PA; g.ldo = K0; g.dk0 = PA;
+                    ChainStage g = gemm_stage(cur, 2, PA, ACT_NONE, ACT_NONE);
+                    add_seg(g, t->pf_cp[l], t->pt_cp[l], L.b, nullptr, nullptr, X + PA, L.dout, K0, 0);
+                    push(g);
                 }
-                push_gemm(g);
-                cur ^= 1;
             }
-            prog.push_back(load_stage(X, nullptr, nullptr, K0, 0, PA, cur, 0, false));   // [PA, K0) holds the context vector
+            cur = 2;
         } else {
-            prog.push_back(load_stage(X, nullptr, nullptr, K0, 0, K0, 0, 0));
+            input(input_tile(X, nullptr, nullptr, K0, 0, K0, 0, 0, 16 * kblocks(K0)));
+            cur = 0;
         }
         for (int l = 0; l < NH; ++l) {
-            ChainStage g{};
-            g.kind = ST_GEMM; g.N = HID; g.nparts = 1; g.part[0] = part_of(net[l], 0, 0, net[l].din, cur);
-            g.bias = net[l].b; g.act_o = dyn_act(ctx); g.out0 = nb.z[l]; g.out1 = nb.h[l]; g.ldo = HID; g.dst = cur ^ 1;
-            push_gemm(g);
-            cur ^= 1;
+            const int dst = cur == 0 ? 1 : 0;
+            ChainStage g = gemm_stage(cur, dst, 0, ACT_NONE, dyn_act(ctx));
+            add_seg(g, pf[l], pt[l], net[l].b, nullptr, nb.z[l], nb.h[l], HID, HID, 0);
+            push(g);
+            cur = dst;
         }
-        for (int hd = 0; hd < (want_lv ? 2 : 1); ++hd) {
-            ChainStage g{};
-            g.kind = ST_GEMM; g.N = D; g.nparts = 1; g.part[0] = part_of(net[NH + hd], 0, 0, HID, cur);
-            g.bias = net[NH + hd].b; g.act_o = ACT_NONE; g.out1 = hd ? nb.lv : nb.mu; g.ldo = D; g.dst = -1;
-            push_gemm(g);
+        {   // the heads side by side: mu on the first tile pairs, logvar behind them
+            ChainStage g = gemm_stage(cur, -1, 0, ACT_NONE, ACT_NONE);
+            add_seg(g, pf[NH], pt[NH], net[NH].b, nullptr, nullptr, nb.mu, D, D, 0);
+            if (want_lv) add_seg(g, pf[NH + 1], pt[NH + 1], net[NH + 1].b, nullptr, nullptr, nb.lv, D, D, 0);
+            push(g);
         }
     };
-    auto bwd_prog = [&](const std::vector<DenseRef>& net, NetBufs& nb, const float* dMu, const float* dLv) {
-        prog.push_back(load_stage(dMu, nullptr, nullptr, D, 0, D, 0, 0));
-        if (dLv) prog.push_back(load_stage(dLv, nullptr, nullptr, D, 0, D, 1, 0));
-        {   // d z_{NH-1} = (dMu W_mu^T (+ dLv W_lv^T)) * swish'(z_{NH-1})
-            ChainStage g{};
-            g.kind = ST_GEMM; g.N = HID; g.nparts = dLv ? 2 : 1;
-            g.part[0] = part_of(net[NH], 1, 0, D, 0);
-            if (dLv) g.part[1] = part_of(net[NH + 1], 1, 0, D, 1);
-            g.zprev = nb.z[NH - 1]; g.ldz = HID; g.act_d = dyn_act(ctx); g.out1 = nb.dz[NH - 1]; g.ldo = HID; g.dst = 2;
-            push_gemm(g);
+    auto bwd_prog = [&](const std::vector<DenseRef>& net, const std::vector<PackDst>& pb, const std::vector<int>& ptb, NetBufs& nb,
+                        const float* dMu, const float* dLv) {
+        const int KBd = kblocks(D);
+        // [dMu | dLv] side by side along k (the heads' transposed operands are concatenated the same way)
+        input(input_tile(dMu, nullptr, nullptr, D, 0, D, 0, 0, 16 * KBd));
+        if (dLv) input(input_tile(dLv, nullptr, nullptr, D, 0, D, 0, 16 * KBd, 32 * KBd));
+        {   // d z_{NH-1} = (dMu W_mu^T (+ dLv W_lv^T)) * act'(z_{NH-1})
+            ChainStage g = gemm_stage(0, 1, 0, dyn_act(ctx), ACT_NONE);
+            add_seg(g, pb[NH], ptb[NH], nullptr, nb.z[NH - 1], nullptr, nb.dz[NH - 1], HID, HID, HID);
+            push(g);
         }
-        int cur = 2;
+        int cur = 1;
         for (int l = NH - 1; l >= 1; --l) {
-            ChainStage g{};
-            g.kind = ST_GEMM; g.N = net[l].din; g.nparts = 1; g.part[0] = part_of(net[l], 1, 0, net[l].dout, cur);
-            g.zprev = nb.z[l - 1]; g.ldz = HID; g.act_d = dyn_act(ctx); g.out1 = nb.dz[l - 1]; g.ldo = HID; g.dst = (cur + 1) % 3;
-            push_gemm(g);
-            cur = (cur + 1) % 3;
+            const int dst = (cur + 1) % 3;
+            ChainStage g = gemm_stage(cur, dst, 0, dyn_act(ctx), ACT_NONE);
+            add_seg(g, pb[l], ptb[l], nullptr, nb.z[l - 1], nullptr, nb.dz[l - 1], net[l].din, HID, HID);
+            push(g);
+            cur = dst;
         }
         if (has_cp) {   // only the context columns of the input carry a gradient
-            ChainStage g{};
-            g.kind = ST_GEMM; g.N = C; g.nparts = 1; g.part[0] = part_of(net[0], 1, PA, net[0].dout, cur);
-            g.out1 = nb.dctx; g.ldo = C; g.dst = -1;
-            push_gemm(g);
+            ChainStage g = gemm_stage(cur, -1, 0, ACT_NONE, ACT_NONE);
+            add_seg(g, pb[0], ptb[0], nullptr, nullptr, nullptr, nb.dctx, C, C, 0);
+            push(g);
         }
     };
 
-    first[PROG_FWD_FF] = (int)prog.size(); fwd_prog(ctx->ff, t->Xff, t->ff, true, !det); count[PROG_FWD_FF] = (int)prog.size() - first[PROG_FWD_FF];
-    first[PROG_FWD_BK] = (int)prog.size(); if (has_back) fwd_prog(ctx->back, t->Xbk, t->bk, false, false); count[PROG_FWD_BK] = (int)prog.size() - first[PROG_FWD_BK];
-    first[PROG_BWD_FF] = (int)prog.size(); bwd_prog(ctx->ff, t->ff, t->dMu, det ? nullptr : t->dLv); count[PROG_BWD_FF] = (int)prog.size() - first[PROG_BWD_FF];
-    first[PROG_BWD_BK] = (int)prog.size(); if (has_back) bwd_prog(ctx->back, t->bk, t->dBmu, nullptr); count[PROG_BWD_BK] = (int)prog.size() - first[PROG_BWD_BK];
-    first[PROG_BWD_CP] = (int)prog.size();
+    cur_prog = PROG_FWD_FF; first[PROG_FWD_FF] = (int)prog.size(); fwd_prog(ctx->ff, t->pf_ff, t->pt_ff, t->Xff, t->ff, true, !det); count[PROG_FWD_FF] = (int)prog.size() - first[PROG_FWD_FF];
+    cur_prog = PROG_FWD_BK; first[PROG_FWD_BK] = (int)prog.size(); if (has_back) fwd_prog(ctx->back, t->pf_bk, t->pt_bk, t->Xbk, t->bk, false, false); count[PROG_FWD_BK] = (int)prog.size() - first[PROG_FWD_BK];
+    cur_prog = PROG_BWD_FF; first[PROG_BWD_FF] = (int)prog.size(); bwd_prog(ctx->ff, t->pb_ff, t->ptb_ff, t->ff, t->dMu, det ? nullptr : t->dLv); count[PROG_BWD_FF] = (int)prog.size() - first[PROG_BWD_FF];
+    cur_prog = PROG_BWD_BK; first[PROG_BWD_BK] = (int)prog.size(); if (has_back) bwd_prog(ctx->back, t->pb_bk, t->ptb_bk, t->bk, t->dBmu, nullptr); count[PROG_BWD_BK] = (int)prog.size() - first[PROG_BWD_BK];
+    cur_prog = PROG_BWD_CP; first[PROG_BWD_CP] = (int)prog.size();
     if (has_cp) {
-        prog.push_back(load_stage(t->ff.dctx, has_back ? t->bk.dctx : nullptr, t->dCtx, C, C, C, 0, 0));
+        input(input_tile(t->ff.dctx, has_back ? t->bk.dctx : nullptr, t->dCtx, C, C, C, 0, 0, 16 * kblocks(C)));
         int cur = 0;
         for (int l = ncp; l >= 1; --l) {
             const DenseRef& L = ctx->cp[l];
-            ChainStage g{};
-            g.kind = ST_GEMM; g.N = L.din; g.nparts = 1; g.part[0] = part_of(L, 1, 0, L.dout, cur);
-            g.zprev = t->cp.z[l - 1]; g.ldz = L.din; g.act_d = ACT_RELU; g.out1 = t->cp.dz[l - 1]; g.ldo = L.din; g.dst = cur ^ 1;
-            push_gemm(g);
+            ChainStage g = gemm_stage(cur, cur ^ 1, 0, ACT_RELU, ACT_NONE);
+            add_seg(g, t->pb_cp[l], t->ptb_cp[l], nullptr, t->cp.z[l - 1], nullptr, t->cp.dz[l - 1], L.din, L.din, L.din);
+            push(g);
             cur ^= 1;
         }
     }
@@ -1219,7 +1360,7 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
         t->prog_host = prog;
     }
     for (int i = 0; i < 5; ++i) { t->prog_first[i] = first[i]; t->prog_count[i] = count[i]; }
-    t->chain_bufsz = CH_ROWS * ((maxk + 31) & ~31);
+    t->chain_bufsz = CH_ROWS * ((maxk + 15) & ~15);
     return CADM_OK;
 }
 
@@ -1230,6 +1371,9 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
     a.first[0] = t->prog_first[p0]; a.count[0] = t->prog_count[p0];
     a.ny = 1;
     if (p1 >= 0 && t->prog_count[p1] > 0) { a.first[1] = t->prog_first[p1]; a.count[1] = t->prog_count[p1]; a.ny = 2; }
+    a.npre[0] = t->npre[p0];
+    for (int i = 0; i < t->npre[p0]; ++i) a.pre[0][i] = t->pre[p0][i];
+    if (a.ny == 2) { a.npre[1] = t->npre[p1]; for (int i = 0; i < t->npre[p1]; ++i) a.pre[1][i] = t->pre[p1][i]; }
     a.B = B; a.bufsz = t->chain_bufsz;
     a.tbuf = ctx->tbuf ? ctx->tbuf + 256 * (p0 / 2) : nullptr;   // [fwd | bwd | bwd context] x 256 stamps (tools/chain_timing.py)
     a.E = ctx->E; a.ntiles = (B + CH_ROWS - 1) / CH_ROWS;
@@ -1237,12 +1381,6 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
     const int per = a.ntiles * a.ny;
     a.ips = (per + a.G - 1) / a.G;
     const int rounds = (ctx->E + 7) / 8;
-    auto pf_net = [&](const std::vector<DenseRef>& net) {
-        for (auto& d : net)
-            if (a.npf < CH_MAXPF) { a.pf_ptr[a.npf] = d.W; a.pf_n[a.npf] = d.din * d.dout; ++a.npf; }
-    };
-    if (p0 == PROG_BWD_CP || (p0 == PROG_FWD_FF && ctx->C > 0)) pf_net(ctx->cp);
-    if (p0 != PROG_BWD_CP) { pf_net(ctx->ff); if (a.ny == 2) pf_net(ctx->back); }
     const size_t lds = CH_MAXSTAGE * sizeof(ChainStage) + 3 * (size_t)t->chain_bufsz * sizeof(float);
     CADM_REQUIRE(lds <= 160 * 1024, "training chain: layer too wide for the LDS-resident activation tile");
     CADM_REQUIRE((long long)B * (t->chain_bufsz / CH_ROWS) * 4 < (1LL << 32),
@@ -1265,6 +1403,8 @@ int forward_nets(cadm_ctx* ctx, const RowMap& map, const float* obs, const float
     const int E = ctx->E, D = ctx->D, K0 = ctx->K0;
     const long R = (long)E * B;
     int rc;
+    if (!t->pack_buf && (rc = alloc_packs(ctx))) return rc;
+    if (ctx->train_packs_stale && (rc = pack_streams(ctx, s))) return rc;
     if ((rc = sync_programs(ctx, s))) return rc;
     AsmP ap{};
     ap.map = map;
@@ -1348,30 +1488,32 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     DwArgs da{};
     da.B = B; da.lr_t = lr_t; da.b1 = hp.beta1; da.b2 = hp.beta2; da.eps = hp.epsilon;
     int tiles = 0;
-    auto add_job = [&](const float* X, int ldx, const float* dZ, const DenseRef& L, float wdc, AdamSlot& aw, AdamSlot& ab) -> int {
+    auto add_job = [&](const float* X, int ldx, const float* dZ, const DenseRef& L, float wdc, AdamSlot& aw, AdamSlot& ab,
+                       const PackDst& pf, const PackDst& pb) -> int {
         CADM_REQUIRE(da.njobs < DW_MAXJOBS, "cadm_train_step: too many layers for the grouped weight-gradient launch");
         DwJob& j = da.job[da.njobs++];
         j.X = X; j.dZ = dZ; j.W = L.W; j.Mw = aw.m; j.Vw = aw.v; j.bW = L.b; j.bM = ab.m; j.bV = ab.v;
         j.ldx = ldx; j.M = L.din; j.N = L.dout; j.tile0 = tiles; j.wdc = wdc; j.tn = (L.dout + TN - 1) / TN;
+        j.pf = pf; j.pb = pb;
         tiles += j.tn * ((L.din + TM - 1) / TM);
         return CADM_OK;
     };
     auto net_jobs = [&](std::vector<DenseRef>& net, const float* X, NetBufs& nb, std::vector<AdamSlot>& ad, const float* dMu,
-                        const float* dLv) -> int {
+                        const float* dLv, std::vector<PackDst>& pf, std::vector<PackDst>& pb) -> int {
         int r;
         for (int l = 0; l < NH; ++l)
-            if ((r = add_job(l == 0 ? X : nb.h[l - 1], l == 0 ? K0 : HID, nb.dz[l], net[l], wd_dyn(l), ad[2 * l], ad[2 * l + 1]))) return r;
-        if ((r = add_job(nb.h[NH - 1], HID, dMu, net[NH], wd_dyn(NH), ad[2 * NH], ad[2 * NH + 1]))) return r;
-        if (dLv && (r = add_job(nb.h[NH - 1], HID, dLv, net[NH + 1], wd_dyn(NH + 1), ad[2 * (NH + 1)], ad[2 * (NH + 1) + 1]))) return r;
+            if ((r = add_job(l == 0 ? X : nb.h[l - 1], l == 0 ? K0 : HID, nb.dz[l], net[l], wd_dyn(l), ad[2 * l], ad[2 * l + 1], pf[l], pb[l]))) return r;
+        if ((r = add_job(nb.h[NH - 1], HID, dMu, net[NH], wd_dyn(NH), ad[2 * NH], ad[2 * NH + 1], pf[NH], pb[NH]))) return r;
+        if (dLv && (r = add_job(nb.h[NH - 1], HID, dLv, net[NH + 1], wd_dyn(NH + 1), ad[2 * (NH + 1)], ad[2 * (NH + 1) + 1], pf[NH + 1], pb[NH + 1]))) return r;
         return CADM_OK;
     };
-    if ((rc = net_jobs(ctx->ff, t->Xff, t->ff, t->a_ff, t->dMu, det ? nullptr : t->dLv))) return rc;
-    if (has_back && (rc = net_jobs(ctx->back, t->Xbk, t->bk, t->a_bk, t->dBmu, nullptr))) return rc;
+    if ((rc = net_jobs(ctx->ff, t->Xff, t->ff, t->a_ff, t->dMu, det ? nullptr : t->dLv, t->pf_ff, t->pb_ff))) return rc;
+    if (has_back && (rc = net_jobs(ctx->back, t->Xbk, t->bk, t->a_bk, t->dBmu, nullptr, t->pf_bk, t->pb_bk))) return rc;
     if (has_cp) {
         auto wd_cp = [&](int l) { return coeff * (l < ncp ? hp.context_weight_decays[l] : hp.context_weight_decays[ncp]); };
         for (int l = 0; l <= ncp; ++l)
             if ((rc = add_job(l == 0 ? t->Xcp : t->cp.h[l - 1], l == 0 ? cpin : ctx->cp[l - 1].dout, l == ncp ? t->dCtx : t->cp.dz[l],
-                              ctx->cp[l], wd_cp(l), t->a_cp[2 * l], t->a_cp[2 * l + 1]))) return rc;
+                              ctx->cp[l], wd_cp(l), t->a_cp[2 * l], t->a_cp[2 * l + 1], t->pf_cp[l], t->pb_cp[l]))) return rc;
     }
     // output_logvar outside the data path (deterministic forward net / backward net): its weight only sees the L2 term
     // (a job without data: X = null), its bias has no gradient at all and is skipped like TF does
@@ -1379,6 +1521,7 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
         CADM_REQUIRE(da.njobs < DW_MAXJOBS, "cadm_train_step: too many layers for the grouped weight-gradient launch");
         DwJob& j = da.job[da.njobs++];
         j.X = nullptr; j.dZ = nullptr; j.W = L.W; j.Mw = aw.m; j.Vw = aw.v; j.bW = nullptr; j.bM = nullptr; j.bV = nullptr;
+        j.pf = PackDst{}; j.pb = PackDst{};
         j.ldx = 0; j.M = L.din; j.N = L.dout; j.tile0 = tiles; j.wdc = wdc; j.tn = (L.dout + TN - 1) / TN;
         tiles += j.tn * ((L.din + TM - 1) / TM);
         return CADM_OK;

@@ -202,8 +202,9 @@ class HipEngine:
         self.nets[net] = out
         if cur is None:
             self._register(net)
-        if net == "ff_model":
-            self._check(self.lib.cadm_repack(self._ctx, self.stream), "cadm_repack")
+        if cur is not None or net == "ff_model":     # weights rewritten in place: the library's packed copies follow
+            if "ff_model" in self.nets:
+                self._check(self.lib.cadm_repack(self._ctx, self.stream), "cadm_repack")
 
     def _register(self, net):
         prm = self.nets[net]
