@@ -97,7 +97,44 @@ __global__ void train_pack_kernel(const PackJob j, int E) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// chain kernel: a list of LOAD / GEMM stages over a 16-row batch tile held in LDS
+// input assembly (core/utils.py:372-379 and :619-621 of the reference): done by the forward chain's input tiles
+// ---------------------------------------------------------------------------------------------
+// Where batch row (e, b) lives in the caller's tensors.  Direct: row r of [E*B, .] tensors.  Indexed (`fit`'s windowed
+// dataset, cadm_train_step_rows): rid = idx[r], window w = row_w[rid], future offset f = row_f[rid]; per-step tensors are
+// [N, F, .] (source row w*F + f), history tensors [N, .] (source row w).
+struct RowMap {
+    const long long *idx, *row_w, *row_f;
+    int F, B;
+    long long idx_ld;                 // idx[e * idx_ld + b]: a batch is a column slice of the [E, n_train] bootstrap matrix
+};
+__device__ __forceinline__ void map_row(const RowMap& m, long r, long& srow, long& swin) {
+    if (!m.idx) { srow = r; swin = r; return; }
+    const long long rid = m.idx[(r / m.B) * m.idx_ld + r % m.B];
+    swin = m.row_w[rid];
+    srow = swin * m.F + m.row_f[rid];
+}
+
+
+__device__ __forceinline__ float preproc_at(int env, const float* o, int pf) {
+    if (env == CADM_ENV_HALFCHEETAH) {
+        if (pf == 0) return o[1];
+        if (pf == 1) return sinf(o[2]);
+        if (pf == 2) return cosf(o[2]);
+        return o[pf];
+    }
+    if (env == CADM_ENV_ANT) return o[pf + 1];
+    return o[pf];
+}
+
+struct ChainAsm {         // raw batch -> normalised network inputs
+    RowMap map;
+    const float *act, *cp_obs, *cp_act;
+    const float *obs_mean, *obs_std, *act_mean, *act_std, *cp_obs_mean, *cp_obs_std, *cp_act_mean, *cp_act_std;
+    int D, A, P, ncpo, ncpa, env;
+};
+
+// ---------------------------------------------------------------------------------------------
+// chain kernel: a list of GEMM stages over a 16-row batch tile held in LDS
 // ---------------------------------------------------------------------------------------------
 // Pointers read out of a stage table are generic to the compiler (flat_load: slower, and it ties the vector-memory
 // counter to the LDS one); they all point to device memory, so say so.
@@ -138,11 +175,14 @@ struct ChainLoad {        // input tile -> LDS: K columns of g0 (+ g1) [E][B][ld
     const float *g0, *g1; // zeros up to row zero_to (the consumer's k loop runs whole 16-row blocks without masking)
     float* gsum;          // echo of the sum [E][B][ldg]
     int ld_in, ldg, K, dst, dk0, zero_to;
+    int mode, pad;        // 0: as stored;  1..4: assembled from the raw batch (ChainAsm; formerly assemble_kernel): 1 = obs_preproc of
+                          //    the g0 rows (obs or next obs), 2 = action, 3 / 4 = the context encoder's (obs, act) history
 };
 struct ChainArgs {
     const ChainStage* prog;
     int first[2], count[2];                              // stage range per chain (y)
-    ChainLoad pre[2][2]; int npre[2];                    // the chain's inputs (kernel arguments: they are requested before the table is)
+    ChainLoad pre[2][4]; int npre[2];                    // the chain's inputs (kernel arguments: they are requested before the table is)
+    ChainAsm asmp;
     int B, bufsz;                                        // rows per member, floats per LDS activation buffer
     int E, ny, ntiles, G, ips;                           // work decomposition, see chain_kernel
     unsigned long long* tbuf;                            // cadm_dev_set_timing_buffer: clocks of member 0's first work item:
@@ -469,37 +509,86 @@ __device__ __forceinline__ void chain_group(const ChainStage* stg, const ChainGr
     if (dbg) dbg[2] = __builtin_readcyclecounter();
 }
 
-// The chain's input tiles.  Thread idx of a tile's index space owns LDS dword idx of the destination range (lane-linear,
-// conflict-free): (k & 3) fastest, then the row, then the k quad.  Loads are issued four deep before the first is used.
-__device__ __forceinline__ void chain_input(const ChainLoad& d, float* bufs, int bufsz, int e, int B, int row0, int tid) {
-    float* dst = bufs + d.dst * bufsz + (d.dk0 >> 2) * (4 * CH_ROWS);
-    const int total = ((d.zero_to - d.dk0) >> 2) * (4 * CH_ROWS);
-    gcptr g0 = as_global(d.g0), g1 = as_global(d.g1);
-    const bool two = d.g1 != nullptr;
-#pragma unroll 1
-    for (int base = 0; base < total; base += 4 * CH_THREADS) {
-        float v[4], w[4];
-        bool ok[4];
-        long off[4];
+// The chain's input tiles.  Element idx of a tile = (16-column block, row, column in the block): a wave covers 4 rows x 16
+// columns -- 4 segments of 64 bytes per load (the LDS-linear order, 16 rows x 4 columns, costs 16 segments per load and
+// made this prologue slower than the separate assembly kernel it replaces), a 4-way bank conflict on the LDS side.
+// Two phases, so that the loads of ALL of a chain's tiles (and the stage table's) are in flight together: fetch requests the
+// raw operands of a tile's elements -- the value, and for the assembled tiles its mean and std --, commit turns them into
+// inputs.  One global round trip for the whole kernel prologue instead of one per tile and operand.  A tile has ONE source
+// per operand (the assembled inputs are two tiles each: observation columns, action columns), so an element's addresses are
+// base + column: nothing for hipcc to branch on between the loads.
+template <int NU>
+struct ChainIn { float x[NU], a[NU], b[NU]; };
+struct ChainInSrc {
+    gcptr x0, a0, b0;
+    int hc;                   // half-cheetah obs_preproc (columns 0..2 <- o[1], sin o[2], cos o[2])
+    int shift;                // ant obs_preproc: column f <- o[f + 1]
+    bool rok, two;
+    long grow;
+};
+__device__ __forceinline__ ChainInSrc chain_input_src(const ChainLoad& d, const ChainAsm& ap, int e, int B, int row0, int tid) {
+    ChainInSrc r;
+    const int row = row0 + ((tid >> 4) & 15);                 // (512 threads = 2 x 256 elements: a thread keeps its row)
+    r.rok = row < B;
+    r.grow = (long)e * B + (r.rok ? row : 0);
+    long srow = r.grow, swin = r.grow;
+    if (d.mode) map_row(ap.map, r.grow, srow, swin);
+    r.hc = 0; r.shift = 0; r.two = false;
+    if (d.mode == 0) {
+        r.x0 = as_global(d.g0) + r.grow * d.ld_in;
+        r.two = d.g1 != nullptr;
+        r.a0 = r.two ? as_global(d.g1) + r.grow * d.ld_in : r.x0;
+        r.b0 = r.x0;
+    } else if (d.mode == 1) {          // preprocessed observation columns of (next) obs rows
+        r.x0 = as_global(d.g0) + srow * ap.D; r.a0 = as_global(ap.obs_mean); r.b0 = as_global(ap.obs_std);
+        r.hc = ap.env == CADM_ENV_HALFCHEETAH;
+        r.shift = ap.env == CADM_ENV_ANT;
+    } else if (d.mode == 2) {          // action columns
+        r.x0 = as_global(ap.act) + srow * ap.A; r.a0 = as_global(ap.act_mean); r.b0 = as_global(ap.act_std);
+    } else if (d.mode == 3) {          // context encoder: observation history
+        r.x0 = as_global(ap.cp_obs) + swin * ap.ncpo; r.a0 = as_global(ap.cp_obs_mean); r.b0 = as_global(ap.cp_obs_std);
+    } else {                           // context encoder: action history
+        r.x0 = as_global(ap.cp_act) + swin * ap.ncpa; r.a0 = as_global(ap.cp_act_mean); r.b0 = as_global(ap.cp_act_std);
+    }
+    return r;
+}
+template <int NU>
+__device__ __forceinline__ void chain_input_fetch(const ChainLoad& d, const ChainInSrc& r, int base, int tid, ChainIn<NU>& q) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = base + u * CH_THREADS + tid;
-            const int k = (idx >> 6) * 4 + (idx & 3), m = (idx >> 2) & 15, row = row0 + m;
-            ok[u] = idx < total && k < d.K && row < B;
-            off[u] = ok[u] ? ((long)e * B + row) * d.ld_in + k : 0;
-            v[u] = g0[off[u]];
-            w[u] = two ? g1[off[u]] : 0.0f;
-        }
+    for (int u = 0; u < NU; ++u) {
+        const int idx = base + u * CH_THREADS + tid;
+        const int k = (idx >> 8) * 16 + (idx & 15);
+        const int j = k < d.K ? k : 0;
+        const int jx = r.hc ? (j == 0 ? 1 : j <= 2 ? 2 : j) : j + r.shift;     // preproc_at's source column
+        q.x[u] = r.x0[jx];
+        q.a[u] = r.a0[j];
+        q.b[u] = r.b0[j];
+    }
+}
+template <int NU>
+__device__ __forceinline__ void chain_input_commit(const ChainLoad& d, const ChainInSrc& r, int base, int tid, const ChainIn<NU>& q,
+                                                   float* bufs, int bufsz) {
+    float* dst = bufs + d.dst * bufsz;
+    const int m = (tid >> 4) & 15;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = base + u * CH_THREADS + tid;
-            const float x = ok[u] ? v[u] + w[u] : 0.0f;
-            if (idx < total) dst[idx] = x;
-            if (ok[u] && d.gsum) {
-                const int k = (idx >> 6) * 4 + (idx & 3), m = (idx >> 2) & 15;
-                as_global(d.gsum)[((long)e * B + row0 + m) * d.ldg + k] = x;
+    for (int u = 0; u < NU; ++u) {
+        const int idx = base + u * CH_THREADS + tid;
+        const int k = (idx >> 8) * 16 + (idx & 15);
+        const bool ok = k < d.K && r.rok;
+        float x;
+        if (d.mode == 0) {
+            x = r.two ? q.x[u] + q.a[u] : q.x[u];
+        } else {
+            float t = q.x[u];
+            if (u == 0 && r.hc && base == 0) {              // (columns 1 and 2 only exist in a thread's first element; hc: mode 1)
+                if (k == 1) t = sinf(t);
+                else if (k == 2) t = cosf(t);
             }
+            x = (t - q.a[u]) / (q.b[u] + 1e-10f);
         }
+        x = ok ? x : 0.0f;
+        if (d.dk0 + k < d.zero_to) dst[lds_at(d.dk0 + k, m)] = x;
+        if (ok && d.gsum) as_global(d.gsum)[r.grow * d.ldg + k] = x;
     }
 }
 
@@ -519,28 +608,73 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     ChainStage* const stg = reinterpret_cast<ChainStage*>(chain_smem);
     float* const bufs = chain_smem + (CH_MAXSTAGE * sizeof(ChainStage)) / sizeof(float);
     const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+    // The argument block is ~1 KB (input tiles, assembly pointers): read where it is used, its 64-byte lines arrive one
+    // dependent scalar-memory round trip after the other (4.7 k cycles of prologue were measured that way even for the
+    // smallest chain).  Touch every line now, in one batch.
+    {
+        typedef __attribute__((address_space(4))) const int* kargp;
+        kargp ka = (kargp)__builtin_amdgcn_kernarg_segment_ptr();
+        int sink = 0;
+#pragma unroll
+        for (unsigned o = 0; o < sizeof(ChainArgs); o += 64) sink += ka[o / 4];
+        asm volatile("" ::"s"(sink));
+    }
     int e, item;
     const int per = a.ntiles * a.ny;
     if (!xcd_affine_item(a.E, a.G, a.ips, per, e, item)) return;
     const int y = item / a.ntiles, row0 = (item - y * a.ntiles) * CH_ROWS, B = a.B;
-    const int nst = a.count[y];
+    const int nst = y ? a.count[1] : a.count[0];
+    const bool timed0 = a.tbuf && item == 0 && e == 0 && tid == 0;
+    if (timed0) a.tbuf[200] = __builtin_readcyclecounter();
     // stage table of this chain -> LDS (one memory latency instead of one per stage); requested first, stored behind the
     // input tiles, which are described by kernel arguments and so are on their way before the table has arrived
     constexpr int TW = (CH_MAXSTAGE * (int)(sizeof(ChainStage) / sizeof(int)) + CH_THREADS - 1) / CH_THREADS;
     int tv[TW];
     const int nw = nst * (int)(sizeof(ChainStage) / sizeof(int));
     {
-        const int* g = reinterpret_cast<const int*>(a.prog + a.first[y]);
+        const int* g = reinterpret_cast<const int*>(a.prog + (y ? a.first[1] : a.first[0]));
 #pragma unroll
         for (int u = 0; u < TW; ++u) {
             const int i = tid + u * CH_THREADS;
             tv[u] = g[i < nw ? i : 0];
         }
     }
-    for (int i = 0; i < a.npre[y]; ++i) chain_input(a.pre[y][i], bufs, a.bufsz, e, B, row0, tid);
+    {
+        // (descriptors by value at static kernel-argument offsets: indexing them with the runtime y makes every field access
+        //  a scalar memory load of its own -- 13 k cycles of prologue were measured that way)
+        const int np = y ? a.npre[1] : a.npre[0];
+        const ChainLoad d0 = y ? a.pre[1][0] : a.pre[0][0], d1 = y ? a.pre[1][1] : a.pre[0][1], d2 = y ? a.pre[1][2] : a.pre[0][2],
+                        d3 = y ? a.pre[1][3] : a.pre[0][3];
+        // elements per thread requested in one go: 6 / 4 / 2 / 2 (96 / 64 / 32 / 32 columns; wider tiles loop).  Deeper would
+        // push the prologue past 128 VGPRs: hipcc then parks values in AGPRs -- the ring's (tests/test_isa_hygiene.py).
+        ChainIn<6> q0;
+        ChainIn<4> q1;
+        ChainIn<2> q2, q3;
+        const ChainInSrc r0 = chain_input_src(d0, a.asmp, e, B, row0, tid), r1 = chain_input_src(np > 1 ? d1 : d0, a.asmp, e, B, row0, tid),
+                         r2 = chain_input_src(np > 2 ? d2 : d0, a.asmp, e, B, row0, tid), r3 = chain_input_src(np > 3 ? d3 : d0, a.asmp, e, B, row0, tid);
+        chain_input_fetch(d0, r0, 0, tid, q0);
+        if (np > 1) chain_input_fetch(d1, r1, 0, tid, q1);
+        if (np > 2) chain_input_fetch(d2, r2, 0, tid, q2);
+        if (np > 3) chain_input_fetch(d3, r3, 0, tid, q3);
+        if (timed0) a.tbuf[201] = __builtin_readcyclecounter();
+        chain_input_commit(d0, r0, 0, tid, q0, bufs, a.bufsz);
+        if (np > 1) chain_input_commit(d1, r1, 0, tid, q1, bufs, a.bufsz);
+        if (np > 2) chain_input_commit(d2, r2, 0, tid, q2, bufs, a.bufsz);
+        if (np > 3) chain_input_commit(d3, r3, 0, tid, q3, bufs, a.bufsz);
+        for (int i = 0; i < np; ++i) {                        // the rest of wide tiles, one round trip per 32 columns
+            const ChainLoad& d = i == 0 ? d0 : i == 1 ? d1 : i == 2 ? d2 : d3;
+            const ChainInSrc& r = i == 0 ? r0 : i == 1 ? r1 : i == 2 ? r2 : r3;
+            const int done = (i == 0 ? 6 : i == 1 ? 4 : 2) * CH_THREADS;
+            for (int base = done; base < ((d.zero_to - d.dk0 + 15) & ~15) * CH_ROWS; base += 2 * CH_THREADS) {
+                chain_input_fetch(d, r, base, tid, q3);
+                chain_input_commit(d, r, base, tid, q3, bufs, a.bufsz);
+            }
+        }
+    }
 #pragma unroll
     for (int u = 0; u < TW; ++u)
         if (tid + u * CH_THREADS < nw) reinterpret_cast<int*>(stg)[tid + u * CH_THREADS] = tv[u];
+    if (timed0) a.tbuf[202] = __builtin_readcyclecounter();
     __syncthreads();
     const bool timed = a.tbuf && item == 0 && e == 0 && tid == 0;
     if (timed) a.tbuf[0] = __builtin_readcyclecounter();
@@ -649,7 +783,11 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     // The loads of slab s+1 are issued right after slab s has been stashed into LDS -- into the SAME registers, which are
     // dead by then -- so their latency runs under slab s's MFMAs at no register cost.
     static_assert(DW_NSLAB == 1, "the slab pipeline below keeps one slab of loads in flight");
+#if defined(CADM_DW_EXP) && CADM_DW_EXP == 2
+    const int KP = 0;
+#else
     const int KP = jb.X ? K : 0;                                       // X == null: L2-only job, gradient = wdc * W
+#endif
     auto issue = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < NLA; ++it) {
@@ -688,6 +826,9 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     // ---- epilogue: D layout col = lane & 15 -> n, row = (lane >> 4) * 4 + r -> m.  Adam touches W, m and v once each
     // (read + write): that traffic, not the GEMM, is most of this kernel, so the tile goes through LDS and every thread
     // updates 4 consecutive columns with 16-byte accesses (a D-layout thread would touch 12 scattered dwords x 6) ----
+#if defined(CADM_DW_EXP) && CADM_DW_EXP == 1
+    if (acc[0][0] != 12345.678f) return;
+#endif
     if ((N & 3) == 0) {
         __syncthreads();                                 // every wave is done reading the slab buffers
 #pragma unroll
@@ -748,70 +889,6 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
         float w = jb.bW[o], mo = jb.bM[o], vo = jb.bV[o];
         adam_update(w, mo, vo, colsum, a.lr_t, a.b1, a.b2, a.eps);
         jb.bW[o] = w; jb.bM[o] = mo; jb.bV[o] = vo;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// input assembly (core/utils.py:372-379 and :619-621 of the reference)
-// ---------------------------------------------------------------------------------------------
-// Where batch row (e, b) lives in the caller's tensors.  Direct: row r of [E*B, .] tensors.  Indexed (`fit`'s windowed
-// dataset, cadm_train_step_rows): rid = idx[r], window w = row_w[rid], future offset f = row_f[rid]; per-step tensors are
-// [N, F, .] (source row w*F + f), history tensors [N, .] (source row w).
-struct RowMap {
-    const long long *idx, *row_w, *row_f;
-    int F, B;
-    long long idx_ld;                 // idx[e * idx_ld + b]: a batch is a column slice of the [E, n_train] bootstrap matrix
-};
-__device__ __forceinline__ void map_row(const RowMap& m, long r, long& srow, long& swin) {
-    if (!m.idx) { srow = r; swin = r; return; }
-    const long long rid = m.idx[(r / m.B) * m.idx_ld + r % m.B];
-    swin = m.row_w[rid];
-    srow = swin * m.F + m.row_f[rid];
-}
-
-struct AsmP {
-    RowMap map;
-    const float *obs, *obs_next, *act, *cp_obs, *cp_act;
-    const float *obs_mean, *obs_std, *act_mean, *act_std, *cp_obs_mean, *cp_obs_std, *cp_act_mean, *cp_act_std;
-    float *Xff, *Xbk, *Xcp;
-    int rows, D, A, P, K0, ncpo, ncpa, env, has_back, has_cp;
-};
-
-__device__ __forceinline__ float preproc_at(int env, const float* o, int pf) {
-    if (env == CADM_ENV_HALFCHEETAH) {
-        if (pf == 0) return o[1];
-        if (pf == 1) return sinf(o[2]);
-        if (pf == 2) return cosf(o[2]);
-        return o[pf];
-    }
-    if (env == CADM_ENV_ANT) return o[pf + 1];
-    return o[pf];
-}
-
-__global__ void assemble_kernel(const AsmP p) {
-    const int row = blockIdx.x;                       // e * B + b
-    long srow, swin;
-    map_row(p.map, row, srow, swin);
-    for (int f = threadIdx.x; f < p.P + p.A; f += blockDim.x) {
-        if (f < p.P) {
-            const float inv = p.obs_std[f] + 1e-10f;
-            p.Xff[(long)row * p.K0 + f] = (preproc_at(p.env, p.obs + srow * p.D, f) - p.obs_mean[f]) / inv;
-            if (p.has_back) p.Xbk[(long)row * p.K0 + f] = (preproc_at(p.env, p.obs_next + srow * p.D, f) - p.obs_mean[f]) / inv;
-        } else {
-            const int a = f - p.P;
-            const float v = (p.act[srow * p.A + a] - p.act_mean[a]) / (p.act_std[a] + 1e-10f);
-            p.Xff[(long)row * p.K0 + f] = v;
-            if (p.has_back) p.Xbk[(long)row * p.K0 + f] = v;
-        }
-    }
-    if (p.has_cp) {
-        const int n = p.ncpo + p.ncpa;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            float v;
-            if (i < p.ncpo) v = (p.cp_obs[swin * p.ncpo + i] - p.cp_obs_mean[i]) / (p.cp_obs_std[i] + 1e-10f);
-            else v = (p.cp_act[swin * p.ncpa + (i - p.ncpo)] - p.cp_act_mean[i - p.ncpo]) / (p.cp_act_std[i - p.ncpo] + 1e-10f);
-            p.Xcp[(long)row * n + i] = v;
-        }
     }
 }
 
@@ -1005,7 +1082,8 @@ struct TrainState {
     std::vector<ChainStage> prog_host;
     ChainStage* prog_dev = nullptr;
     int prog_first[5] = {0, 0, 0, 0, 0}, prog_count[5] = {0, 0, 0, 0, 0};
-    ChainLoad pre[5][2]; int npre[5] = {0, 0, 0, 0, 0};         // the programs' input tiles (kernel arguments of the launch)
+    ChainLoad pre[5][4]; int npre[5] = {0, 0, 0, 0, 0};         // the programs' input tiles (kernel arguments of the launch)
+    ChainAsm asmp{};                                            // raw batch of the current call (forward launch)
     int chain_bufsz = 0;
 };
 
@@ -1214,8 +1292,9 @@ namespace {
 
 enum { PROG_FWD_FF = 0, PROG_FWD_BK = 1, PROG_BWD_FF = 2, PROG_BWD_BK = 3, PROG_BWD_CP = 4 };
 
-ChainLoad input_tile(const float* g0, const float* g1, float* gsum, int ld_in, int ldg, int K, int dst, int dk0, int zero_to) {
+ChainLoad input_tile(const float* g0, const float* g1, float* gsum, int ld_in, int ldg, int K, int dst, int dk0, int zero_to, int mode = 0) {
     ChainLoad d{};
+    d.mode = mode;
     d.g0 = g0; d.g1 = g1; d.gsum = gsum; d.ld_in = ld_in; d.ldg = ldg; d.K = K; d.dst = dst; d.dk0 = dk0; d.zero_to = zero_to;
     return d;
 }
@@ -1269,8 +1348,13 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
         if (has_cp) {
             // both inputs at once: the context encoder's history in buffer 0, this net's (obs, act) columns in buffer 2,
             // where the encoder's last stage drops the context vector behind them
-            input(input_tile(t->Xcp, nullptr, nullptr, cpin, 0, cpin, 0, 0, 16 * kblocks(cpin)));
-            input(input_tile(X, nullptr, nullptr, K0, 0, PA, 2, 0, 16 * kblocks(K0)));
+            // (assembled from the raw batch on the way in; the forward net's workgroups also leave the normalised copies that
+            //  the weight-gradient launch reads as layer-0 inputs.  g0 of the raw tiles is set per call: forward_nets)
+            const int ncpo = D * ctx->cfg.history_length;
+            input(input_tile(nullptr, nullptr, store_cp ? t->Xcp : nullptr, 0, cpin, ncpo, 0, 0, ncpo, 3));
+            input(input_tile(nullptr, nullptr, store_cp ? t->Xcp + ncpo : nullptr, 0, cpin, cpin - ncpo, 0, ncpo, 16 * kblocks(cpin), 4));
+            input(input_tile(nullptr, nullptr, X, 0, K0, ctx->P, 2, 0, ctx->P, 1));
+            input(input_tile(nullptr, nullptr, X + ctx->P, 0, K0, ctx->A, 2, ctx->P, 16 * kblocks(K0), 2));
             cur = 0;
             for (int l = 0; l <= ncp; ++l) {
                 const DenseRef& L = ctx->cp[l];
@@ -1288,7 +1372,8 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
             }
             cur = 2;
         } else {
-            input(input_tile(X, nullptr, nullptr, K0, 0, K0, 0, 0, 16 * kblocks(K0)));
+            input(input_tile(nullptr, nullptr, X, 0, K0, ctx->P, 0, 0, ctx->P, 1));
+            input(input_tile(nullptr, nullptr, X + ctx->P, 0, K0, ctx->A, 0, ctx->P, 16 * kblocks(K0), 2));
             cur = 0;
         }
         for (int l = 0; l < NH; ++l) {
@@ -1374,6 +1459,7 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
     a.npre[0] = t->npre[p0];
     for (int i = 0; i < t->npre[p0]; ++i) a.pre[0][i] = t->pre[p0][i];
     if (a.ny == 2) { a.npre[1] = t->npre[p1]; for (int i = 0; i < t->npre[p1]; ++i) a.pre[1][i] = t->pre[p1][i]; }
+    a.asmp = t->asmp;
     a.B = B; a.bufsz = t->chain_bufsz;
     a.tbuf = ctx->tbuf ? ctx->tbuf + 256 * (p0 / 2) : nullptr;   // [fwd | bwd | bwd context] x 256 stamps (tools/chain_timing.py)
     a.E = ctx->E; a.ntiles = (B + CH_ROWS - 1) / CH_ROWS;
@@ -1399,25 +1485,22 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
 int forward_nets(cadm_ctx* ctx, const RowMap& map, const float* obs, const float* act, const float* obs_next, const float* cp_obs,
                  const float* cp_act, int B, bool has_back, hipStream_t s) {
     TrainState* t = ctx->train;
-    const bool has_cp = ctx->C > 0;
-    const int E = ctx->E, D = ctx->D, K0 = ctx->K0;
-    const long R = (long)E * B;
+    const int D = ctx->D;
     int rc;
     if (!t->pack_buf && (rc = alloc_packs(ctx))) return rc;
     if (ctx->train_packs_stale && (rc = pack_streams(ctx, s))) return rc;
     if ((rc = sync_programs(ctx, s))) return rc;
-    AsmP ap{};
+    ChainAsm& ap = t->asmp;
     ap.map = map;
-    ap.obs = obs; ap.obs_next = obs_next; ap.act = act; ap.cp_obs = cp_obs; ap.cp_act = cp_act;
+    ap.act = act; ap.cp_obs = cp_obs; ap.cp_act = cp_act;
     ap.obs_mean = ctx->st.obs_mean; ap.obs_std = ctx->st.obs_std; ap.act_mean = ctx->st.act_mean; ap.act_std = ctx->st.act_std;
     ap.cp_obs_mean = ctx->st.cp_obs_mean; ap.cp_obs_std = ctx->st.cp_obs_std;
     ap.cp_act_mean = ctx->st.cp_act_mean; ap.cp_act_std = ctx->st.cp_act_std;
-    ap.Xff = t->Xff; ap.Xbk = t->Xbk; ap.Xcp = t->Xcp;
-    ap.rows = (int)R; ap.D = D; ap.A = ctx->A; ap.P = ctx->P; ap.K0 = K0;
+    ap.D = D; ap.A = ctx->A; ap.P = ctx->P;
     ap.ncpo = D * ctx->cfg.history_length; ap.ncpa = ctx->A * ctx->cfg.history_length;
-    ap.env = ctx->cfg.env_kind; ap.has_back = has_back; ap.has_cp = has_cp;
-    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)R), dim3(64), 0, s, ap);
-    CADM_CHECK_HIP(hipGetLastError());
+    ap.env = ctx->cfg.env_kind;
+    for (int i = 0; i < t->npre[PROG_FWD_FF]; ++i) if (t->pre[PROG_FWD_FF][i].mode == 1) t->pre[PROG_FWD_FF][i].g0 = obs;
+    for (int i = 0; i < t->npre[PROG_FWD_BK]; ++i) if (t->pre[PROG_FWD_BK][i].mode == 1) t->pre[PROG_FWD_BK][i].g0 = obs_next;
     return launch_chain(ctx, B, PROG_FWD_FF, has_back ? PROG_FWD_BK : -1, s);
 }
 

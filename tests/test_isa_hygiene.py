@@ -38,8 +38,8 @@ def _code_objects(path):
         pos = i + len(MAGIC)
 
 
-def _kernels(image):
-    """{demangled-ish symbol: instruction text} of the xdl rollout kernels of one code object."""
+def _kernels(image, match="rollout_xdl_kernel"):
+    """{demangled-ish symbol: instruction text} of the kernels of one code object whose name contains `match`."""
     with tempfile.NamedTemporaryFile(suffix=".co") as f:
         f.write(image)
         f.flush()
@@ -50,7 +50,7 @@ def _kernels(image):
         if m:
             if name is not None:
                 out[name] = buf
-            name, buf = (m.group(1), []) if "rollout_xdl_kernel" in m.group(1) else (None, [])
+            name, buf = (m.group(1), []) if match in m.group(1) else (None, [])
         elif name is not None:
             buf.append(line.strip())
     if name is not None:
@@ -132,3 +132,27 @@ def test_resident_fragments_never_leave_agprs():
             assert len(res) > 10, "%s: no MFMA reads its A operand from AGPRs -- residency is off" % sym
             checked += 1
     assert checked >= 5 * 2 * 3      # 5 envs x {C = 0, 10} x 3 noise modes at least for HID = 200
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump not available")
+def test_training_chain_ring_registers_are_left_alone():
+    """The training chains' operand ring is a[0:63], named literally in inline asm (cadm_amd/csrc/train.hip): hipcc must
+    not touch AGPRs in chain_kernel (under VGPR pressure it parks values there), must not spill, and no MFMA may directly
+    follow a VALU instruction (the asm MFMAs carry no wait states: their operands come from loads and ds_reads)."""
+    found = 0
+    for img in _code_objects(LIB):
+        for sym, ins in _kernels(img, "chain_kernel").items():
+            ins = [x.split("//")[0].strip() for x in ins if x.strip()]
+            found += 1
+            assert not [x for x in ins if x.startswith("scratch_")], "chain_kernel uses scratch"
+            mine = ("v_mfma_f32_16x16x4_f32", "global_load_dwordx4 a[")
+            alien = [x for x in ins if re.search(r"\ba\[?\d", x) and not x.startswith(mine)]
+            assert not alien, "hipcc touches AGPRs in chain_kernel: %s" % alien[:3]
+            mf = [i for i, x in enumerate(ins) if x.startswith("v_mfma_")]
+            assert len(mf) >= 64
+            for i in mf:
+                assert re.match(r"v_mfma_f32_16x16x4_f32 v\[\d+:\d+\], a\d+, v\d+, v\[", ins[i]), ins[i]
+                assert ins[i - 1].split()[0].startswith(("s_", "v_mfma")), "VALU instruction in front of an asm MFMA: %s / %s" % (ins[i - 1], ins[i])
+            ring = [x for x in ins if x.startswith("global_load_dwordx4 a[")]
+            assert ring and all(re.match(r"global_load_dwordx4 a\[\d+:\d+\], v\d+, s\[\d+:\d+\]", x) for x in ring)
+    assert found == 1

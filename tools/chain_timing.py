@@ -33,6 +33,8 @@ def main():
         if n < 2:
             continue
         d = np.diff(row[:n]).astype(np.float64)
+        pro = raw[li, 200:203]
+        print("   prologue: entry -> loads issued %d, -> committed %d, -> first barrier passed %d ticks" % (pro[1] - pro[0], pro[2] - pro[1], row[0] - pro[2]))
         print("%-20s total %8.0f ticks | " % (lname, row[n - 1] - row[0]) + " ".join("%5.0f" % x for x in d))
         fine = raw[li, 64:64 + 4 * (n - 1)].reshape(n - 1, 4)
         print("   wave 0 per GEMM stage: k loop / epilogue   " + "  ".join("%d/%d" % (r[1] - r[0], r[2] - r[1]) for r in fine if r[0]))
