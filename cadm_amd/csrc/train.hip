@@ -726,7 +726,9 @@ static_assert(sizeof(DwArgs) <= 4096, "kernel argument block");
 // stash the slab's loads into LDS as they land, barrier, MFMA sweep; 4 waves side by side, each 48 x 16.  Occupancy beats
 // panel depth here: 2-slab panels (156 VGPRs, 3 per CU) and register double-buffering (178 VGPRs) both measured slower.
 __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
-    __shared__ __attribute__((aligned(16))) float dw_smem[DW_NSLAB * TK * (LDA + LDB)];
+    constexpr int LDK = TK + 4;                          // fast path: slabs stored [feature][k]
+    constexpr int DW_SMEM = DW_NSLAB * TK * (LDA + LDB) > (TM + TN) * LDK ? DW_NSLAB * TK * (LDA + LDB) : (TM + TN) * LDK;
+    __shared__ __attribute__((aligned(16))) float dw_smem[DW_SMEM];
     float* const As = dw_smem;
     float* const Bs = dw_smem + DW_NSLAB * TK * LDA;
     constexpr int LDC = TN + 4;                          // the finished tile, staged for the vectorised Adam epilogue
@@ -783,11 +785,7 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     // The loads of slab s+1 are issued right after slab s has been stashed into LDS -- into the SAME registers, which are
     // dead by then -- so their latency runs under slab s's MFMAs at no register cost.
     static_assert(DW_NSLAB == 1, "the slab pipeline below keeps one slab of loads in flight");
-#if defined(CADM_DW_EXP) && CADM_DW_EXP == 2
-    const int KP = 0;
-#else
     const int KP = jb.X ? K : 0;                                       // X == null: L2-only job, gradient = wdc * W
-#endif
     auto issue = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < NLA; ++it) {
@@ -800,8 +798,85 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
             rb[0][it] = pb[it][(long)(k < kmax ? k : kmax) * N];
         }
     };
-    if (KP > 0) issue(0);
-    for (int k0 = 0; k0 < KP; k0 += TK) {
+    // Fast path (whole slabs, 16-byte rows): a slab is fetched with 16-byte loads -- a lane takes 4 consecutive features of one
+    // batch row, 8 lanes 128 contiguous bytes of it (lanes along the batch instead -- conflict-free stores without a swizzle --
+    // fetch a 64-byte line per 16 bytes used: 0.225 ms per step) -- and stashed TRANSPOSED ([feature][k], k contiguous), so that
+    // an MFMA operand for 4 k-steps is one ds_read_b128: per slab and wave 4 global loads, 14 LDS writes and
+    // 8 LDS reads next to the 24 MFMAs, where the generic path below spends 14 + 14 + 32 and a clamp / select per element.
+    // (On this part the matrix pipe does not overlap with another wave's VALU work: every instruction saved is MFMA time.)
+    // k-steps are taken in the order k = 16 g + 4 q + u (lane group q, u = 0..3) -- any order, as long as A and B agree.
+    const bool vec = KP > 0 && (K % TK) == 0 && ((jb.ldx | N | M) & 3) == 0 && M >= 4 && N >= 4 &&
+                     ((reinterpret_cast<size_t>(jb.X) | reinterpret_cast<size_t>(jb.dZ)) & 15) == 0;
+    if (vec) {
+        float* const At = dw_smem;
+        float* const Bt = dw_smem + TM * LDK;
+        const int c = lane & 15, q = lane >> 4;
+        // quads of a slab: A 32 rows x 12 (8 per row for every thread, the other 4 for threads 0..127), B 32 rows x 16 (8 + 8):
+        // a wave reads 8 rows x 128 bytes (or 16 x 64) per load.  LDS position of (feature f, k): f * LDK + 4 * ((k >> 2) ^
+        // ((f >> 2) & 7)) + (k & 3) -- the XOR spreads a wave's transposed stores over all banks (2 lanes per bank)
+        const int kl = tid >> 3, ql = tid & 7, kl2 = (tid >> 2) & 31, ql2 = 8 + (tid & 3);
+        const bool a1 = tid < 128;
+        const int ma0 = mb + 4 * ql < M ? mb + 4 * ql : M - 4, ma1 = mb + 4 * ql2 < M ? mb + 4 * ql2 : M - 4;
+        const int nb0 = nb + 4 * ql < N ? nb + 4 * ql : N - 4, nb1 = nb + 32 + 4 * ql < N ? nb + 32 + 4 * ql : N - 4;
+        const floatx4* pA0 = reinterpret_cast<const floatx4*>(A + (long)kl * jb.ldx + ma0);
+        const floatx4* pA1 = reinterpret_cast<const floatx4*>(A + (long)kl2 * jb.ldx + ma1);
+        const floatx4* pB0 = reinterpret_cast<const floatx4*>(Bm + (long)kl * N + nb0);
+        const floatx4* pB1 = reinterpret_cast<const floatx4*>(Bm + (long)kl * N + nb1);
+        const long sA = (long)TK * jb.ldx / 4, sB = (long)TK * N / 4;    // slab strides in float4
+        float* const wA0 = At + (4 * ql) * LDK + 4 * ((kl >> 2) ^ (ql & 7)) + (kl & 3);
+        float* const wA1 = At + (4 * ql2) * LDK + 4 * ((kl2 >> 2) ^ (ql2 & 7)) + (kl2 & 3);
+        float* const wB0 = Bt + (4 * ql) * LDK + 4 * ((kl >> 2) ^ (ql & 7)) + (kl & 3);
+        float* const wB1 = Bt + (32 + 4 * ql) * LDK + 4 * ((kl >> 2) ^ ((8 + ql) & 7)) + (kl & 3);
+        const bool n_ok = nb + 16 * wn < N;                              // units past the matrix edge are skipped
+        // two slabs of loads in flight (registers): slab s + 2 is requested when slab s has been stashed
+        struct Slab { floatx4 a0, a1, b0, b1; } r[2];
+        auto fetch = [&](Slab& d) {
+            d.a0 = *pA0; d.a1 = a1 ? *pA1 : floatx4{0.f, 0.f, 0.f, 0.f}; d.b0 = *pB0; d.b1 = *pB1;
+            pA0 += sA; pA1 += sA; pB0 += sB; pB1 += sB;
+        };
+        auto slab = [&](Slab& d, int k0) {
+            if (k0 > 0) __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wA0[j * LDK] = d.a0[j];
+                if (a1) wA1[j * LDK] = d.a1[j];
+                wB0[j * LDK] = d.b0[j];
+                wB1[j * LDK] = d.b1[j];
+            }
+            __syncthreads();
+            if (k0 + 2 * TK < KP) fetch(d);
+            if (do_colsum) {
+#pragma unroll
+                for (int x = 0; x < TK / 4; ++x) {
+                    const floatx4 v = *reinterpret_cast<const floatx4*>(Bt + tid * LDK + 4 * (x ^ ((tid >> 2) & 7)));
+                    colsum += v[0]; colsum += v[1]; colsum += v[2]; colsum += v[3];
+                }
+            }
+            if (n_ok) {
+                const int fb = 16 * wn + c;
+#pragma unroll
+                for (int g = 0; g < TK / 16; ++g) {
+                    const floatx4 b4 = *reinterpret_cast<const floatx4*>(Bt + fb * LDK + 4 * ((4 * g + q) ^ ((fb >> 2) & 7)));
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        if (mb + 16 * i >= M) continue;
+                        const int fa = 16 * i + c;
+                        const floatx4 a4 = *reinterpret_cast<const floatx4*>(At + fa * LDK + 4 * ((4 * g + q) ^ ((fa >> 2) & 7)));
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u], b4[u], acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        fetch(r[0]);
+        if (KP > TK) fetch(r[1]);
+        for (int k0 = 0; k0 < KP; k0 += 2 * TK) {
+            slab(r[0], k0);
+            if (k0 + TK < KP) slab(r[1], k0 + TK);
+        }
+    }
+    if (!vec && KP > 0) issue(0);
+    for (int k0 = 0; !vec && k0 < KP; k0 += TK) {
         if (k0 > 0) __syncthreads();               // previous slab fully consumed before its LDS is overwritten
 #pragma unroll
         for (int it = 0; it < NLA; ++it) As[la[it]] = (va[it] && k0 + ka[it] <= kmax) ? ra[0][it] : 0.0f;
@@ -826,9 +901,6 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     // ---- epilogue: D layout col = lane & 15 -> n, row = (lane >> 4) * 4 + r -> m.  Adam touches W, m and v once each
     // (read + write): that traffic, not the GEMM, is most of this kernel, so the tile goes through LDS and every thread
     // updates 4 consecutive columns with 16-byte accesses (a D-layout thread would touch 12 scattered dwords x 6) ----
-#if defined(CADM_DW_EXP) && CADM_DW_EXP == 1
-    if (acc[0][0] != 12345.678f) return;
-#endif
     if ((N & 3) == 0) {
         __syncthreads();                                 // every wave is done reading the slab buffers
 #pragma unroll
