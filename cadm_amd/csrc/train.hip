@@ -700,6 +700,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
 // ---------------------------------------------------------------------------------------------
 struct DwJob {                       // W[e] (M x N) <- Adam(W, X[e]^T dZ[e] + wdc W);  b[e] <- Adam(b, colsum dZ[e])
     const float *X, *dZ;             // X [E][B][ldx] (first M columns), dZ [E][B][N]
+    const float* dZ2;                // optional second gradient, added on load (the context encoder's, from the two dynamics nets)
     float *W, *Mw, *Vw, *bW, *bM, *bV;
     int ldx, M, N, tile0;            // tile0: first workgroup (blockIdx.x) of this job
     float wdc;
@@ -780,6 +781,8 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
         pb[it] = Bm + (vb[it] ? nb + bn : 0);
     }
     const int kmax = K - 1;
+    const bool two = jb.dZ2 != nullptr;
+    const long d2 = two ? jb.dZ2 - jb.dZ : 0;            // (same shape and member stride as dZ)
     const bool do_colsum = jb.bW && mb == 0 && tid < TN;
 
     // The loads of slab s+1 are issued right after slab s has been stashed into LDS -- into the SAME registers, which are
@@ -795,7 +798,9 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
 #pragma unroll
         for (int it = 0; it < NLB; ++it) {
             const int k = k0 + kb[it];
-            rb[0][it] = pb[it][(long)(k < kmax ? k : kmax) * N];
+            const long o = (long)(k < kmax ? k : kmax) * N;
+            const float v1 = pb[it][o], v2 = pb[it][o + d2];        // (both loads unconditional: d2 = 0 without a second gradient)
+            rb[0][it] = two ? v1 + v2 : v1;
         }
     };
     // Fast path (whole slabs, 16-byte rows): a slab is fetched with 16-byte loads -- a lane takes 4 consecutive features of one
@@ -806,7 +811,7 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     // (On this part the matrix pipe does not overlap with another wave's VALU work: every instruction saved is MFMA time.)
     // k-steps are taken in the order k = 16 g + 4 q + u (lane group q, u = 0..3) -- any order, as long as A and B agree.
     const bool vec = KP > 0 && (K % TK) == 0 && ((jb.ldx | N | M) & 3) == 0 && M >= 4 && N >= 4 &&
-                     ((reinterpret_cast<size_t>(jb.X) | reinterpret_cast<size_t>(jb.dZ)) & 15) == 0;
+                     ((reinterpret_cast<size_t>(jb.X) | reinterpret_cast<size_t>(jb.dZ) | reinterpret_cast<size_t>(jb.dZ2)) & 15) == 0;
     if (vec) {
         float* const At = dw_smem;
         float* const Bt = dw_smem + TM * LDK;
@@ -829,9 +834,10 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
         float* const wB1 = Bt + (32 + 4 * ql) * LDK + 4 * ((kl >> 2) ^ ((8 + ql) & 7)) + (kl & 3);
         const bool n_ok = nb + 16 * wn < N;                              // units past the matrix edge are skipped
         // two slabs of loads in flight (registers): slab s + 2 is requested when slab s has been stashed
-        struct Slab { floatx4 a0, a1, b0, b1; } r[2];
+        struct Slab { floatx4 a0, a1, b0, b1, c0, c1; } r[2];      // (c: the second gradient, added when the slab is stashed)
         auto fetch = [&](Slab& d) {
             d.a0 = *pA0; d.a1 = a1 ? *pA1 : floatx4{0.f, 0.f, 0.f, 0.f}; d.b0 = *pB0; d.b1 = *pB1;
+            if (two) { d.c0 = pB0[d2 / 4]; d.c1 = pB1[d2 / 4]; }     // (used at the stash only: the branch costs no wait)
             pA0 += sA; pA1 += sA; pB0 += sB; pB1 += sB;
         };
         auto slab = [&](Slab& d, int k0) {
@@ -840,8 +846,8 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
             for (int j = 0; j < 4; ++j) {
                 wA0[j * LDK] = d.a0[j];
                 if (a1) wA1[j * LDK] = d.a1[j];
-                wB0[j * LDK] = d.b0[j];
-                wB1[j * LDK] = d.b1[j];
+                wB0[j * LDK] = two ? d.b0[j] + d.c0[j] : d.b0[j];
+                wB1[j * LDK] = two ? d.b1[j] + d.c1[j] : d.b1[j];
             }
             __syncthreads();
             if (k0 + 2 * TK < KP) fetch(d);
@@ -1141,6 +1147,7 @@ struct TrainState {
     // views
     float *Xff = nullptr, *Xbk = nullptr, *Xcp = nullptr, *dCtx = nullptr;
     NetBufs ff, bk, cp;
+    std::vector<float*> cp_dz_bk;     // the context encoder's dz as propagated from the backward model's chain (cp.dz: from the forward net's)
     float *dMu = nullptr, *dLv = nullptr, *dBmu = nullptr, *terms = nullptr, *red = nullptr;
     // Adam moments, same order as the registered layers: W then b
     std::vector<AdamSlot> a_ff, a_bk, a_cp;   // 2 per layer
@@ -1295,14 +1302,14 @@ static int ensure_workspace(cadm_ctx* ctx, int B) {
     auto need = [&](size_t n) { size_t o = total; total += (n + 63) & ~(size_t)63; return o; };
     const size_t oXff = need(R * K0), oXbk = need(R * K0), oXcp = need(R * (cpin > 0 ? cpin : 1));
     const size_t odCtx = need(R * Cw), odCff = need(R * Cw), odCbk = need(R * Cw);
-    std::vector<size_t> oz_ff(NH), oh_ff(NH), od_ff(NH), oz_bk(NH), oh_bk(NH), od_bk(NH), oz_cp(ncp), oh_cp(ncp), od_cp(ncp);
+    std::vector<size_t> oz_ff(NH), oh_ff(NH), od_ff(NH), oz_bk(NH), oh_bk(NH), od_bk(NH), oz_cp(ncp), oh_cp(ncp), od_cp(ncp), od_cpb(ncp);
     for (int l = 0; l < NH; ++l) {
         oz_ff[l] = need(R * HID); oh_ff[l] = need(R * HID); od_ff[l] = need(R * HID);
         oz_bk[l] = need(R * HID); oh_bk[l] = need(R * HID); od_bk[l] = need(R * HID);
     }
     for (int l = 0; l < ncp; ++l) {
         const size_t w = ctx->cfg.cp_hidden[l];
-        oz_cp[l] = need(R * w); oh_cp[l] = need(R * w); od_cp[l] = need(R * w);
+        oz_cp[l] = need(R * w); oh_cp[l] = need(R * w); od_cp[l] = need(R * w); od_cpb[l] = need(R * w);
     }
     const size_t omu = need(R * D), olv = need(R * D), obmu = need(R * D), oblv = need(R * D);
     const size_t odMu = need(R * D), odLv = need(R * D), odBmu = need(R * D);
@@ -1317,7 +1324,8 @@ static int ensure_workspace(cadm_ctx* ctx, int B) {
         t->ff.z[l] = w + oz_ff[l]; t->ff.h[l] = w + oh_ff[l]; t->ff.dz[l] = w + od_ff[l];
         t->bk.z[l] = w + oz_bk[l]; t->bk.h[l] = w + oh_bk[l]; t->bk.dz[l] = w + od_bk[l];
     }
-    for (int l = 0; l < ncp; ++l) { t->cp.z[l] = w + oz_cp[l]; t->cp.h[l] = w + oh_cp[l]; t->cp.dz[l] = w + od_cp[l]; }
+    t->cp_dz_bk.resize(ncp);
+    for (int l = 0; l < ncp; ++l) { t->cp.z[l] = w + oz_cp[l]; t->cp.h[l] = w + oh_cp[l]; t->cp.dz[l] = w + od_cp[l]; t->cp_dz_bk[l] = w + od_cpb[l]; }
     t->ff.mu = w + omu; t->ff.lv = w + olv; t->bk.mu = w + obmu; t->bk.lv = w + oblv;
     t->dMu = w + odMu; t->dLv = w + odLv; t->dBmu = w + odBmu;
     t->terms = w + oterms; t->red = w + ored;
@@ -1463,7 +1471,7 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
         }
     };
     auto bwd_prog = [&](const std::vector<DenseRef>& net, const std::vector<PackDst>& pb, const std::vector<int>& ptb, NetBufs& nb,
-                        const float* dMu, const float* dLv) {
+                        const float* dMu, const float* dLv, std::vector<float*>& cp_dz) {
         const int KBd = kblocks(D);
         // [dMu | dLv] side by side along k (the heads' transposed operands are concatenated the same way)
         input(input_tile(dMu, nullptr, nullptr, D, 0, D, 0, 0, 16 * KBd));
@@ -1481,29 +1489,31 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
             push(g);
             cur = dst;
         }
-        if (has_cp) {   // only the context columns of the input carry a gradient
-            ChainStage g = gemm_stage(cur, -1, 0, ACT_NONE, ACT_NONE);
+        if (has_cp) {   // only the context columns of the input carry a gradient ...
+            int dst = (cur + 1) % 3;
+            ChainStage g = gemm_stage(cur, dst, 0, ACT_NONE, ACT_NONE);
             add_seg(g, pb[0], ptb[0], nullptr, nullptr, nullptr, nb.dctx, C, C, 0);
             push(g);
+            cur = dst;
+            // ... and it goes on down the context encoder in the same chain: backpropagation is linear in the incoming
+            // gradient, so each dynamics net carries ITS share (cp_dz) and the weight-gradient launch adds the two on load --
+            // no third chain launch, no pass of the context gradient through global memory
+            for (int l = ncp; l >= 1; --l) {
+                const DenseRef& L = ctx->cp[l];
+                dst = (cur + 1) % 3;
+                ChainStage h = gemm_stage(cur, dst, 0, ACT_RELU, ACT_NONE);
+                add_seg(h, t->pb_cp[l], t->ptb_cp[l], nullptr, t->cp.z[l - 1], nullptr, cp_dz[l - 1], L.din, L.din, L.din);
+                push(h);
+                cur = dst;
+            }
         }
     };
 
     cur_prog = PROG_FWD_FF; first[PROG_FWD_FF] = (int)prog.size(); fwd_prog(ctx->ff, t->pf_ff, t->pt_ff, t->Xff, t->ff, true, !det); count[PROG_FWD_FF] = (int)prog.size() - first[PROG_FWD_FF];
     cur_prog = PROG_FWD_BK; first[PROG_FWD_BK] = (int)prog.size(); if (has_back) fwd_prog(ctx->back, t->pf_bk, t->pt_bk, t->Xbk, t->bk, false, false); count[PROG_FWD_BK] = (int)prog.size() - first[PROG_FWD_BK];
-    cur_prog = PROG_BWD_FF; first[PROG_BWD_FF] = (int)prog.size(); bwd_prog(ctx->ff, t->pb_ff, t->ptb_ff, t->ff, t->dMu, det ? nullptr : t->dLv); count[PROG_BWD_FF] = (int)prog.size() - first[PROG_BWD_FF];
-    cur_prog = PROG_BWD_BK; first[PROG_BWD_BK] = (int)prog.size(); if (has_back) bwd_prog(ctx->back, t->pb_bk, t->ptb_bk, t->bk, t->dBmu, nullptr); count[PROG_BWD_BK] = (int)prog.size() - first[PROG_BWD_BK];
-    cur_prog = PROG_BWD_CP; first[PROG_BWD_CP] = (int)prog.size();
-    if (has_cp) {
-        input(input_tile(t->ff.dctx, has_back ? t->bk.dctx : nullptr, t->dCtx, C, C, C, 0, 0, 16 * kblocks(C)));
-        int cur = 0;
-        for (int l = ncp; l >= 1; --l) {
-            const DenseRef& L = ctx->cp[l];
-            ChainStage g = gemm_stage(cur, cur ^ 1, 0, ACT_RELU, ACT_NONE);
-            add_seg(g, t->pb_cp[l], t->ptb_cp[l], nullptr, t->cp.z[l - 1], nullptr, t->cp.dz[l - 1], L.din, L.din, L.din);
-            push(g);
-            cur ^= 1;
-        }
-    }
+    cur_prog = PROG_BWD_FF; first[PROG_BWD_FF] = (int)prog.size(); bwd_prog(ctx->ff, t->pb_ff, t->ptb_ff, t->ff, t->dMu, det ? nullptr : t->dLv, t->cp.dz); count[PROG_BWD_FF] = (int)prog.size() - first[PROG_BWD_FF];
+    cur_prog = PROG_BWD_BK; first[PROG_BWD_BK] = (int)prog.size(); if (has_back) bwd_prog(ctx->back, t->pb_bk, t->ptb_bk, t->bk, t->dBmu, nullptr, t->cp_dz_bk); count[PROG_BWD_BK] = (int)prog.size() - first[PROG_BWD_BK];
+    cur_prog = PROG_BWD_CP; first[PROG_BWD_CP] = (int)prog.size();      // (folded into the dynamics nets' backward chains)
     count[PROG_BWD_CP] = (int)prog.size() - first[PROG_BWD_CP];
     for (int i = 0; i < 5; ++i) CADM_REQUIRE(count[i] <= CH_MAXSTAGE, "training chain too long (more than 20 stages): too many layers");
 
@@ -1637,7 +1647,6 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
 
     // backward chains (read W) ...
     if ((rc = launch_chain(ctx, B, PROG_BWD_FF, has_back ? PROG_BWD_BK : -1, s))) return rc;
-    if (has_cp && (rc = launch_chain(ctx, B, PROG_BWD_CP, -1, s))) return rc;
 
     // ... then every layer's weight gradient + Adam as one grouped launch (overwrites W)
     DwArgs da{};
@@ -1647,7 +1656,7 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
                        const PackDst& pf, const PackDst& pb) -> int {
         CADM_REQUIRE(da.njobs < DW_MAXJOBS, "cadm_train_step: too many layers for the grouped weight-gradient launch");
         DwJob& j = da.job[da.njobs++];
-        j.X = X; j.dZ = dZ; j.W = L.W; j.Mw = aw.m; j.Vw = aw.v; j.bW = L.b; j.bM = ab.m; j.bV = ab.v;
+        j.X = X; j.dZ = dZ; j.dZ2 = nullptr; j.W = L.W; j.Mw = aw.m; j.Vw = aw.v; j.bW = L.b; j.bM = ab.m; j.bV = ab.v;
         j.ldx = ldx; j.M = L.din; j.N = L.dout; j.tile0 = tiles; j.wdc = wdc; j.tn = (L.dout + TN - 1) / TN;
         j.pf = pf; j.pb = pb;
         tiles += j.tn * ((L.din + TM - 1) / TM);
@@ -1666,16 +1675,18 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     if (has_back && (rc = net_jobs(ctx->back, t->Xbk, t->bk, t->a_bk, t->dBmu, nullptr, t->pf_bk, t->pb_bk))) return rc;
     if (has_cp) {
         auto wd_cp = [&](int l) { return coeff * (l < ncp ? hp.context_weight_decays[l] : hp.context_weight_decays[ncp]); };
-        for (int l = 0; l <= ncp; ++l)
-            if ((rc = add_job(l == 0 ? t->Xcp : t->cp.h[l - 1], l == 0 ? cpin : ctx->cp[l - 1].dout, l == ncp ? t->dCtx : t->cp.dz[l],
+        for (int l = 0; l <= ncp; ++l) {      // gradient = the forward net's share (+ the backward model's), added on load
+            if ((rc = add_job(l == 0 ? t->Xcp : t->cp.h[l - 1], l == 0 ? cpin : ctx->cp[l - 1].dout, l == ncp ? t->ff.dctx : t->cp.dz[l],
                               ctx->cp[l], wd_cp(l), t->a_cp[2 * l], t->a_cp[2 * l + 1], t->pf_cp[l], t->pb_cp[l]))) return rc;
+            if (has_back) da.job[da.njobs - 1].dZ2 = l == ncp ? t->bk.dctx : t->cp_dz_bk[l];
+        }
     }
     // output_logvar outside the data path (deterministic forward net / backward net): its weight only sees the L2 term
     // (a job without data: X = null), its bias has no gradient at all and is skipped like TF does
     auto l2_only_job = [&](const DenseRef& L, float wdc, AdamSlot& aw) -> int {
         CADM_REQUIRE(da.njobs < DW_MAXJOBS, "cadm_train_step: too many layers for the grouped weight-gradient launch");
         DwJob& j = da.job[da.njobs++];
-        j.X = nullptr; j.dZ = nullptr; j.W = L.W; j.Mw = aw.m; j.Vw = aw.v; j.bW = nullptr; j.bM = nullptr; j.bV = nullptr;
+        j.X = nullptr; j.dZ = nullptr; j.dZ2 = nullptr; j.W = L.W; j.Mw = aw.m; j.Vw = aw.v; j.bW = nullptr; j.bM = nullptr; j.bV = nullptr;
         j.pf = PackDst{}; j.pb = PackDst{};
         j.ldx = 0; j.M = L.din; j.N = L.dout; j.tile0 = tiles; j.wdc = wdc; j.tn = (L.dout + TN - 1) / TN;
         tiles += j.tn * ((L.din + TM - 1) / TM);
