@@ -134,6 +134,41 @@ struct ChainAsm {         // raw batch -> normalised network inputs
 };
 
 // ---------------------------------------------------------------------------------------------
+// loss terms and their reductions (dynamics.py:269-314): parameters of the forward chain's closing phase (chain_loss_phase)
+// ---------------------------------------------------------------------------------------------
+struct LossP {
+    RowMap map;
+    const float *mu, *lv, *bmu;              // head outputs [E*B, D]
+    const float *delta, *back_delta;         // raw targets [E*B, D] (or through map)
+    const float *dmean, *dstd, *bdmean, *bdstd, *maxlv, *minlv;
+    float *dMu, *dLv, *dBmu;                 // d loss / d head pre-activation
+    long n;                                  // E*B*D
+    int D, B, det, has_back;
+    float back_coeff;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Deterministic reductions of the loss terms.  out: [4 + 2D] = {mse, mu_loss, var_loss, back_mse, d/d max_logvar [D],
+// d/d min_logvar [D]}.  The workgroup that finishes last turns the sums into losses_out = [mse, back_mse, recon]
+// (dynamics.py:505-507: recon = loss - reg - coeff * l2) and, when training a probabilistic model, applies Adam to
+// max/min_logvar (data term + the 0.01 regulariser of dynamics.py:308) -- nothing else reads them until the next step.
+struct ReduceP {
+    float* part;                                   // [workgroups][4 + 2D] per-workgroup partial sums
+    int D; float* out; unsigned* counter;
+    int det, has_back; float back_coeff; float* losses_out;
+    int adam_mm;                                   // 1: update max/min_logvar
+    float *maxlv, *minlv, *mx_m, *mx_v, *mn_m, *mn_v;
+    float lr_t, b1, b2, eps;
+};
+
+__device__ __forceinline__ float wave_sum_fixed(float v) {            // xor butterfly: the same order on every run
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
 // chain kernel: a list of GEMM stages over a 16-row batch tile held in LDS
 // ---------------------------------------------------------------------------------------------
 // Pointers read out of a stage table are generic to the compiler (flat_load: slower, and it ties the vector-memory
@@ -183,6 +218,8 @@ struct ChainArgs {
     int first[2], count[2];                              // stage range per chain (y)
     ChainLoad pre[2][4]; int npre[2];                    // the chain's inputs (kernel arguments: they are requested before the table is)
     ChainAsm asmp;
+    int loss_on, loss_buf, loss_lv0, loss_slots;         // forward launch of a training step: losses + head gradients behind the heads
+    LossP lossp; ReduceP lossr;                          //  (head outputs in LDS buffer loss_buf: mu at rows 0.., logvar at rows loss_lv0..)
     int B, bufsz;                                        // rows per member, floats per LDS activation buffer
     int E, ny, ntiles, G, ips;                           // work decomposition, see chain_kernel
     unsigned long long* tbuf;                            // cadm_dev_set_timing_buffer: clocks of member 0's first work item:
@@ -464,17 +501,18 @@ __device__ __forceinline__ void chain_group(const ChainStage* stg, const ChainGr
     }
     if (dsti >= 0) {
         float* dst = bufs + dsti * bufsz;
+        const int sg0 = sg ? 32 * tp1 : 0;                // a second segment's columns follow the first's tile pairs
         if (VEC) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                *reinterpret_cast<floatx4*>(dst + lds_at(dk0 + n0[j], m)) = n0[j] < N ? v1[j] : floatx4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<floatx4*>(dst + lds_at(dk0 + sg0 + n0[j], m)) = n0[j] < N ? v1[j] : floatx4{0.f, 0.f, 0.f, 0.f};
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int n = n0[j] + r;
-                    if (n < N || zfill) dst[lds_at(dk0 + n, m)] = n < N ? v1[j][r] : 0.0f;
+                    if (n < N || zfill) dst[lds_at(dk0 + sg0 + n, m)] = n < N ? v1[j][r] : 0.0f;
                 }
         }
     }
@@ -603,6 +641,134 @@ __device__ __forceinline__ bool xcd_affine_item(int E, int G, int ips, int per, 
     return e < E && item < per;
 }
 
+// Closing phase of the forward launch of a training step: the workgroup's 16 rows x D head outputs are still in LDS, so the
+// loss terms, the head gradients and the workgroup's share of every reduction are taken here instead of in a launch of their
+// own (9 us of pure latency).  Forward-net workgroups own terms {mse, mu_loss, var_loss, d/d max_logvar,
+// d/d min_logvar}, backward-model workgroups back_mse.  Reductions in a fixed order throughout: a workgroup's partials
+// (rows ascending), then -- by the workgroup that arrives last -- all partials in slot order: no float atomics, the result
+// does not depend on which workgroup is last.  That one also finalises (losses_out, Adam on max / min_logvar), exactly as
+// the separate loss / reduction launch of earlier rounds did.
+__device__ __forceinline__ void chain_loss_phase(const ChainArgs& a, float* bufs, float* scr, int e, int y, int row0, int tid) {
+    const LossP& p = a.lossp;
+    const ReduceP& r = a.lossr;
+    const int D = p.D, B = p.B, nel = CH_ROWS * D, lane = tid & 63, wave = tid >> 6;
+    const float* hb = bufs + a.loss_buf * a.bufsz;
+    for (int el = tid; el < nel; el += CH_THREADS) {
+        const int m = el / D, d = el - m * D, row = row0 + m;
+        float tm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (row < B) {
+            const long grow = (long)e * B + row, i = grow * D + d;
+            long srow, swin;
+            map_row(p.map, grow, srow, swin);
+            const long si = srow * D + d;                              // this element in the caller's target tensors
+            const float s = 1.0f / ((float)B * (float)D);             // reduce_mean over b then d; reduce_sum over e
+            const float mu = hb[lds_at(d, m)];
+            if (y == 0) {
+                const float t = (p.delta[si] - p.dmean[d]) / (p.dstd[d] + 1e-10f);
+                const float diff = mu - t;
+                tm[0] = diff * diff * s;                                                  // mse            (:273-274)
+                if (p.det) {
+                    p.dMu[i] = 2.0f * s * diff;
+                    p.dLv[i] = 0.0f;
+                } else {
+                    const float mx = p.maxlv[d], mn = p.minlv[d], lv0 = hb[lds_at(a.loss_lv0 + d, m)];
+                    const float u = mx - tf_softplus(mx - lv0);                           // core/utils.py:356
+                    const float lvc = mn + tf_softplus(u - mn);                           // core/utils.py:357
+                    const float invvar = expf(-lvc);                                      // :303
+                    tm[1] = diff * diff * invvar * s;                                     // mu_loss        (:304-305)
+                    tm[2] = lvc * s;                                                      // var_loss       (:306-307)
+                    const float g_lvc = s * (1.0f - diff * diff * invvar);
+                    const float s1 = sigmoidf_(u - mn), s2 = sigmoidf_(mx - lv0);         // softplus' = sigmoid
+                    p.dMu[i] = 2.0f * s * diff * invvar;
+                    p.dLv[i] = g_lvc * s1 * s2;
+                    tm[4] = g_lvc * s1 * (1.0f - s2);                                     // d / d max_logvar (without the 0.01 reg)
+                    tm[5] = g_lvc * (1.0f - s1);                                          // d / d min_logvar
+                }
+            } else {
+                const float tb = (p.back_delta[si] - p.bdmean[d]) / (p.bdstd[d] + 1e-10f);
+                const float db = mu - tb;
+                tm[3] = db * db * s;                                                      // back_mse       (:280-281)
+                p.dBmu[i] = p.back_coeff * 2.0f * s * db;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) scr[q * nel + el] = tm[q];
+    }
+    __syncthreads();
+    const int NQ = 4 + 2 * D;
+    const int slot = (e * a.ny + y) * a.ntiles + row0 / CH_ROWS;
+    float* part = r.part + (size_t)slot * NQ;
+    if (wave < 4) {                                                // scalar terms: wave q sums scr[q][*]
+        float v = 0.0f;
+        for (int j = lane; j < nel; j += 64) v += scr[wave * nel + j];
+        v = wave_sum_fixed(v);
+        if (lane == 0) __hip_atomic_store(part + wave, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {                                                       // per-dim terms: one thread per (bound, dim), rows ascending
+        for (int o = tid - 256; o < 2 * D; o += 256) {
+            const int which = o / D, d = o - which * D;
+            float v = 0.0f;
+            for (int m = 0; m < CH_ROWS; ++m) v += scr[(4 + which) * nel + m * D + d];
+            __hip_atomic_store(part + 4 + o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // Hand-off to the last workgroup WITHOUT an agent-scope fence: a release fence writes back the XCD's whole L2, which at
+    // this point holds the megabytes of z / h the chain has just stored (measured: + 48 us on the launch).  The partials
+    // are device-coherent stores (sc1: written through, past the non-coherent L2s) that have completed (vmcnt) before the
+    // arrival counter is bumped, and the last workgroup reads them with device-coherent loads.
+    int* const flag = reinterpret_cast<int*>(scr + (6 * nel > CH_THREADS ? 6 * nel : CH_THREADS));     // (launch_chain sizes scr)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) *flag = atomicInc(r.counter, a.loss_slots - 1) == (unsigned)(a.loss_slots - 1);     // wraps back to 0 for the next step
+    __syncthreads();
+    if (!*flag) return;
+    // sum over the slots: G groups of threads take contiguous chunks of slots (loads eight at a time -- one after the other
+    // they are 160 dependent fabric round trips: + 48 us measured), then the chunks are added in order
+    float* red = r.out;
+    const int G = NQ <= CH_THREADS ? CH_THREADS / NQ : 1, CS = (a.loss_slots + G - 1) / G;
+    for (int q0 = 0; q0 < NQ; q0 += CH_THREADS) {
+        const int q = q0 + tid % (NQ < CH_THREADS ? NQ : CH_THREADS), g = tid / (NQ < CH_THREADS ? NQ : CH_THREADS);
+        float v = 0.0f;
+        if (g < G && q < NQ) {
+            const int w1 = (g + 1) * CS < a.loss_slots ? (g + 1) * CS : a.loss_slots;
+            for (int w0 = g * CS; w0 < w1; w0 += 8) {
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    x[u] = __hip_atomic_load(r.part + (size_t)(w0 + u < w1 ? w0 + u : w1 - 1) * NQ + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += w0 + u < w1 ? x[u] : 0.0f;
+            }
+            scr[g * NQ + (q - q0)] = v;
+        }
+        __syncthreads();
+        if (tid < NQ - q0 && tid < CH_THREADS) {
+            float tot = 0.0f;
+            for (int gg = 0; gg < G; ++gg) tot += scr[gg * NQ + tid];
+            red[q0 + tid] = tot;
+        }
+        __syncthreads();
+    }
+    __syncthreads();                   // (red: written and read inside this workgroup, through its own L1 / L2)
+    if (tid == 0) {
+        const float mse = red[0], mu_loss = red[1], var_loss = red[2], back = red[3];
+        float recon = r.det ? mse : mu_loss + var_loss;
+        if (r.has_back) recon += r.back_coeff * back;
+        r.losses_out[0] = mse;
+        r.losses_out[1] = r.has_back ? back : 0.0f;
+        r.losses_out[2] = recon;
+    }
+    if (r.adam_mm && tid < 2 * D) {
+        const bool mx = tid < D;
+        const int d = mx ? tid : tid - D;
+        float* w = (mx ? r.maxlv : r.minlv) + d;
+        float* m = (mx ? r.mx_m : r.mn_m) + d;
+        float* v = (mx ? r.mx_v : r.mn_v) + d;
+        float ww = *w, mm = *m, vv = *v;
+        adam_update(ww, mm, vv, red[4 + tid] + (mx ? 0.01f : -0.01f), r.lr_t, r.b1, r.b2, r.eps);
+        *w = ww; *m = mm; *v = vv;
+    }
+}
+
 __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float chain_smem[];
     ChainStage* const stg = reinterpret_cast<ChainStage*>(chain_smem);
@@ -693,6 +859,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
         __syncthreads();
         if (timed) a.tbuf[si + 1] = __builtin_readcyclecounter();
     }
+    if (a.loss_on) chain_loss_phase(a, bufs, bufs + 3 * a.bufsz, e, y, row0, tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -973,157 +1140,6 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
 // ---------------------------------------------------------------------------------------------
 // losses (dynamics.py:269-314) and output-layer gradients
 // ---------------------------------------------------------------------------------------------
-struct LossP {
-    RowMap map;
-    const float *mu, *lv, *bmu;              // head outputs [E*B, D]
-    const float *delta, *back_delta;         // raw targets [E*B, D] (or through map)
-    const float *dmean, *dstd, *bdmean, *bdstd, *maxlv, *minlv;
-    float *dMu, *dLv, *dBmu;                 // d loss / d head pre-activation
-    long n;                                  // E*B*D
-    int D, B, det, has_back;
-    float back_coeff;
-};
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// Deterministic reductions of the loss terms.  out: [4 + 2D] = {mse, mu_loss, var_loss, back_mse, d/d max_logvar [D],
-// d/d min_logvar [D]}.  The workgroup that finishes last turns the sums into losses_out = [mse, back_mse, recon]
-// (dynamics.py:505-507: recon = loss - reg - coeff * l2) and, when training a probabilistic model, applies Adam to
-// max/min_logvar (data term + the 0.01 regulariser of dynamics.py:308) -- nothing else reads them until the next step.
-struct ReduceP {
-    float* part;                                   // [workgroups][4 + 2D] per-workgroup partial sums
-    int D; float* out; unsigned* counter;
-    int det, has_back; float back_coeff; float* losses_out;
-    int adam_mm;                                   // 1: update max/min_logvar
-    float *maxlv, *minlv, *mx_m, *mx_v, *mn_m, *mn_v;
-    float lr_t, b1, b2, eps;
-};
-
-__device__ __forceinline__ float wave_sum_fixed(float v) {            // xor butterfly: the same order on every run
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-
-// One launch for the losses, the head gradients and every reduction over them (was: a loss kernel that wrote 6 term
-// arrays + a reduction kernel that read them back).  A workgroup takes LR_THREADS consecutive elements of [E*B, D],
-// reduces its six terms in LDS in a fixed order (4 scalar sums; per-dim sums of the two logvar-bound gradients) and
-// writes 4 + 2D partials; the last workgroup to arrive sums the partials (again in a fixed order: no float atomics,
-// the result does not depend on which workgroup is last) and finalises.
-constexpr int LR_THREADS = 1024;
-
-__global__ __launch_bounds__(LR_THREADS) void loss_reduce_kernel(const LossP p, const ReduceP r) {
-    __shared__ float sh[6][LR_THREADS];
-    __shared__ float wsum[LR_THREADS / 64][64];
-    __shared__ bool is_last;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned i0 = blockIdx.x * (unsigned)LR_THREADS;          // (host: n < 2^31 -- 32-bit div / mod)
-    const unsigned i = i0 + tid;
-    float tm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    if (i < (unsigned)p.n) {
-        const int d = (int)(i % (unsigned)p.D);
-        long srow, swin;
-        map_row(p.map, (long)(i / (unsigned)p.D), srow, swin);
-        const long si = srow * p.D + d;                            // this element in the caller's target tensors
-        const float s = 1.0f / ((float)p.B * (float)p.D);         // reduce_mean over b then d; reduce_sum over e
-        const float t = (p.delta[si] - p.dmean[d]) / (p.dstd[d] + 1e-10f);
-        const float mu = p.mu[i];
-        const float diff = mu - t;
-        tm[0] = diff * diff * s;                                                  // mse            (:273-274)
-        if (p.det) {
-            p.dMu[i] = 2.0f * s * diff;
-            p.dLv[i] = 0.0f;
-        } else {
-            const float mx = p.maxlv[d], mn = p.minlv[d], lv0 = p.lv[i];
-            const float u = mx - tf_softplus(mx - lv0);                           // core/utils.py:356
-            const float lvc = mn + tf_softplus(u - mn);                           // core/utils.py:357
-            const float invvar = expf(-lvc);                                      // :303
-            tm[1] = diff * diff * invvar * s;                                     // mu_loss        (:304-305)
-            tm[2] = lvc * s;                                                      // var_loss       (:306-307)
-            const float g_lvc = s * (1.0f - diff * diff * invvar);
-            const float s1 = sigmoidf_(u - mn), s2 = sigmoidf_(mx - lv0);         // softplus' = sigmoid
-            p.dMu[i] = 2.0f * s * diff * invvar;
-            p.dLv[i] = g_lvc * s1 * s2;
-            tm[4] = g_lvc * s1 * (1.0f - s2);                                     // d / d max_logvar (without the 0.01 reg)
-            tm[5] = g_lvc * (1.0f - s1);                                          // d / d min_logvar
-        }
-        if (p.has_back) {
-            const float tb = (p.back_delta[si] - p.bdmean[d]) / (p.bdstd[d] + 1e-10f);
-            const float db = p.bmu[i] - tb;
-            tm[3] = db * db * s;                                                  // back_mse       (:280-281)
-            p.dBmu[i] = p.back_coeff * 2.0f * s * db;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) sh[q][tid] = tm[q];
-    __syncthreads();
-    const int NQ = 4 + 2 * r.D;
-    float* part = r.part + (size_t)blockIdx.x * NQ;
-    if (wave < 4) {                                                // scalar terms: wave q sums sh[q][*]
-        float v = 0.0f;
-#pragma unroll
-        for (int k = 0; k < LR_THREADS / 64; ++k) v += sh[wave][lane + 64 * k];
-        v = wave_sum_fixed(v);
-        if (lane == 0) part[wave] = v;
-    } else {                                                       // per-dim terms: 16 lanes per (bound, dim)
-        const int sub = tid & 15, j00 = (int)(i0 % (unsigned)r.D);
-        for (int o = (tid - 256) >> 4; o < 2 * r.D; o += (LR_THREADS - 256) >> 4) {     // (uniform per 16-lane group)
-            const int which = o / r.D, d = o % r.D;
-            float v = 0.0f;
-            for (int j = (d - j00 + r.D) % r.D + sub * r.D; j < LR_THREADS; j += 16 * r.D) v += sh[4 + which][j];
-#pragma unroll
-            for (int x = 8; x > 0; x >>= 1) v += __shfl_xor(v, x, 64);
-            if (sub == 0) part[4 + o] = v;
-        }
-    }
-    __syncthreads();                                              // (every wave's partials have left for L2)
-    if (tid == 0) {
-        __threadfence();                                          // one agent-scope release per workgroup
-        is_last = atomicInc(r.counter, gridDim.x - 1) == gridDim.x - 1;     // wraps back to 0 for the next step
-        if (is_last) __threadfence();
-    }
-    __syncthreads();
-    if (!is_last) return;
-    // sum of the partials: lane = output (64 at a time), the waves take interleaved workgroups, wave partials meet in LDS
-    const volatile float* all = r.part;
-    volatile float* red = r.out;
-    const int W = (int)gridDim.x;
-    for (int q0 = 0; q0 < NQ; q0 += 64) {
-        const int q = q0 + lane;
-        float v = 0.0f;
-        if (q < NQ)
-            for (int w = wave; w < W; w += LR_THREADS / 64) v += all[(size_t)w * NQ + q];
-        wsum[wave][lane] = v;
-        __syncthreads();
-        if (wave == 0 && q < NQ) {
-            float tot = 0.0f;
-#pragma unroll
-            for (int k = 0; k < LR_THREADS / 64; ++k) tot += wsum[k][lane];
-            red[q] = tot;
-        }
-        __syncthreads();
-    }
-    __threadfence_block();
-    if (tid == 0) {
-        const float mse = red[0], mu_loss = red[1], var_loss = red[2], back = red[3];
-        float recon = r.det ? mse : mu_loss + var_loss;
-        if (r.has_back) recon += r.back_coeff * back;
-        r.losses_out[0] = mse;
-        r.losses_out[1] = r.has_back ? back : 0.0f;
-        r.losses_out[2] = recon;
-    }
-    if (r.adam_mm && tid < 2 * r.D) {
-        const bool mx = tid < r.D;
-        const int d = mx ? tid : tid - r.D;
-        float* w = (mx ? r.maxlv : r.minlv) + d;
-        float* m = (mx ? r.mx_m : r.mn_m) + d;
-        float* v = (mx ? r.mx_v : r.mn_v) + d;
-        float ww = *w, mm = *m, vv = *v;
-        adam_update(ww, mm, vv, red[4 + tid] + (mx ? 0.01f : -0.01f), r.lr_t, r.b1, r.b2, r.eps);
-        *w = ww; *m = mm; *v = vv;
-    }
-}
-
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1163,6 +1179,7 @@ struct TrainState {
     int prog_first[5] = {0, 0, 0, 0, 0}, prog_count[5] = {0, 0, 0, 0, 0};
     ChainLoad pre[5][4]; int npre[5] = {0, 0, 0, 0, 0};         // the programs' input tiles (kernel arguments of the launch)
     ChainAsm asmp{};                                            // raw batch of the current call (forward launch)
+    int loss_buf = 0, loss_lv0 = 0;                             // where the forward chains leave the head outputs in LDS
     int chain_bufsz = 0;
 };
 
@@ -1313,7 +1330,7 @@ static int ensure_workspace(cadm_ctx* ctx, int B) {
     }
     const size_t omu = need(R * D), olv = need(R * D), obmu = need(R * D), oblv = need(R * D);
     const size_t odMu = need(R * D), odLv = need(R * D), odBmu = need(R * D);
-    const size_t oterms = need(((R * D + LR_THREADS - 1) / LR_THREADS) * (4 + 2 * (size_t)D)), ored = need(4 + 2 * (size_t)D + 8);
+    const size_t oterms = need((size_t)ctx->E * 2 * ((B + CH_ROWS - 1) / CH_ROWS) * (4 + 2 * (size_t)D)), ored = need(4 + 2 * (size_t)D + 8);   // a slot per forward workgroup
     CADM_CHECK_HIP(hipMalloc(&t->ws, total * sizeof(float)));
     t->ws_floats = total;
     float* w = t->ws;
@@ -1463,8 +1480,11 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
             push(g);
             cur = dst;
         }
-        {   // the heads side by side: mu on the first tile pairs, logvar behind them
-            ChainStage g = gemm_stage(cur, -1, 0, ACT_NONE, ACT_NONE);
+        {   // the heads side by side: mu on the first tile pairs, logvar behind them; also left in LDS for the loss phase
+            const int hd = cur == 0 ? 1 : 0;
+            t->loss_buf = hd; t->loss_lv0 = 16 * pt[NH];
+            ChainStage g = gemm_stage(cur, hd, 0, ACT_NONE, ACT_NONE);
+            g.zfill = 0;
             add_seg(g, pf[NH], pt[NH], net[NH].b, nullptr, nullptr, nb.mu, D, D, 0);
             if (want_lv) add_seg(g, pf[NH + 1], pt[NH + 1], net[NH + 1].b, nullptr, nullptr, nb.lv, D, D, 0);
             push(g);
@@ -1531,7 +1551,9 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
     return CADM_OK;
 }
 
-int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
+struct ChainLossCfg { LossP lp; ReduceP rp; };
+
+int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s, const ChainLossCfg* loss = nullptr) {
     TrainState* t = ctx->train;
     ChainArgs a{};
     a.prog = t->prog_dev;
@@ -1549,7 +1571,13 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
     const int per = a.ntiles * a.ny;
     a.ips = (per + a.G - 1) / a.G;
     const int rounds = (ctx->E + 7) / 8;
-    const size_t lds = CH_MAXSTAGE * sizeof(ChainStage) + 3 * (size_t)t->chain_bufsz * sizeof(float);
+    size_t lds = CH_MAXSTAGE * sizeof(ChainStage) + 3 * (size_t)t->chain_bufsz * sizeof(float);
+    if (loss) {     // closing loss phase: 6 term arrays of the workgroup's 16 x D elements + a flag behind the activation buffers
+        a.loss_on = 1; a.loss_buf = t->loss_buf; a.loss_lv0 = t->loss_lv0; a.loss_slots = ctx->E * a.ny * a.ntiles;
+        a.lossp = loss->lp; a.lossr = loss->rp;
+        const size_t terms = 6 * (size_t)CH_ROWS * ctx->D;          // (the final reduction reuses it for up to CH_THREADS chunk sums)
+        lds += ((terms > CH_THREADS ? terms : CH_THREADS) + 4) * sizeof(float);
+    }
     CADM_REQUIRE(lds <= 160 * 1024, "training chain: layer too wide for the LDS-resident activation tile");
     CADM_REQUIRE((long long)B * (t->chain_bufsz / CH_ROWS) * 4 < (1LL << 32),
                  "training chain: batch of %d rows too large for 32-bit per-member offsets", B);
@@ -1565,7 +1593,7 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s) {
 
 // forward of the context / forward (/ backward) nets on one [E,B,.] batch into the workspace
 int forward_nets(cadm_ctx* ctx, const RowMap& map, const float* obs, const float* act, const float* obs_next, const float* cp_obs,
-                 const float* cp_act, int B, bool has_back, hipStream_t s) {
+                 const float* cp_act, int B, bool has_back, hipStream_t s, const ChainLossCfg* loss = nullptr) {
     TrainState* t = ctx->train;
     const int D = ctx->D;
     int rc;
@@ -1583,7 +1611,7 @@ int forward_nets(cadm_ctx* ctx, const RowMap& map, const float* obs, const float
     ap.env = ctx->cfg.env_kind;
     for (int i = 0; i < t->npre[PROG_FWD_FF]; ++i) if (t->pre[PROG_FWD_FF][i].mode == 1) t->pre[PROG_FWD_FF][i].g0 = obs;
     for (int i = 0; i < t->npre[PROG_FWD_BK]; ++i) if (t->pre[PROG_FWD_BK][i].mode == 1) t->pre[PROG_FWD_BK][i].g0 = obs_next;
-    return launch_chain(ctx, B, PROG_FWD_FF, has_back ? PROG_FWD_BK : -1, s);
+    return launch_chain(ctx, B, PROG_FWD_FF, has_back ? PROG_FWD_BK : -1, s, loss);
 }
 
 __global__ void clamp_logvar_kernel(const float* lv, const float* maxlv, const float* minlv, float* out, long n, int D) {
@@ -1615,9 +1643,7 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     const int cpin = (ctx->D + ctx->A) * ctx->cfg.history_length;
     const long R = (long)E * B;
 
-    if ((rc = forward_nets(ctx, map, obs, act, obs_next, cp_obs, cp_act, B, has_back, s))) return rc;
-
-    // ---- losses + head gradients ----
+    // ---- forward + losses + head gradients ----
     LossP lp{};
     lp.map = map;
     lp.mu = t->ff.mu; lp.lv = t->ff.lv; lp.bmu = t->bk.mu; lp.delta = delta; lp.back_delta = back_delta;
@@ -1637,8 +1663,9 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     rp.mx_m = t->a_mx.m; rp.mx_v = t->a_mx.v; rp.mn_m = t->a_mn.m; rp.mn_v = t->a_mn.v;
     rp.lr_t = lr_t; rp.b1 = hp.beta1; rp.b2 = hp.beta2; rp.eps = hp.epsilon;
     CADM_REQUIRE(lp.n < (1L << 31), "cadm_train_step: E*B*D too large");
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3((unsigned)((lp.n + LR_THREADS - 1) / LR_THREADS)), dim3(LR_THREADS), 0, s, lp, rp);
-    CADM_CHECK_HIP(hipGetLastError());
+    // forward chains; their closing phase takes the losses, the head gradients and the reductions (chain_loss_phase)
+    ChainLossCfg lc{lp, rp};
+    if ((rc = forward_nets(ctx, map, obs, act, obs_next, cp_obs, cp_act, B, has_back, s, &lc))) return rc;
     if (!train) return CADM_OK;
 
     // ---- backward + Adam ----
