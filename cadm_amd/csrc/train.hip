@@ -218,7 +218,8 @@ struct ChainArgs {
     int first[2], count[2];                              // stage range per chain (y)
     ChainLoad pre[2][4]; int npre[2];                    // the chain's inputs (kernel arguments: they are requested before the table is)
     ChainAsm asmp;
-    int loss_on, loss_buf, loss_lv0, loss_slots;         // forward launch of a training step: losses + head gradients behind the heads
+    int loss_on, loss_buf, loss_lv0, loss_slots, loss_final;   // forward launch of a training step: losses + head gradients behind the
+                                                         //  heads; loss_final: this launch also sums the partials (evaluation)
     LossP lossp; ReduceP lossr;                          //  (head outputs in LDS buffer loss_buf: mu at rows 0.., logvar at rows loss_lv0..)
     int B, bufsz;                                        // rows per member, floats per LDS activation buffer
     int E, ny, ntiles, G, ips;                           // work decomposition, see chain_kernel
@@ -641,6 +642,59 @@ __device__ __forceinline__ bool xcd_affine_item(int E, int G, int ips, int per, 
     return e < E && item < per;
 }
 
+// Sums of the workgroups' partials in a fixed order (G groups of threads take contiguous chunks of slots -- loads eight at a
+// time: one after the other they are 160 dependent round trips, + 48 us measured --, then the chunks are added in order), the
+// three reported losses, and Adam on max / min_logvar (data term + the 0.01 regulariser of dynamics.py:308).
+template <int NT, bool COHERENT>
+__device__ __forceinline__ void loss_finalize(const ReduceP& r, int slots, float* scr, int tid) {
+    const int D = r.D, NQ = 4 + 2 * D;
+    float* red = r.out;
+    const int W = NQ < NT ? NQ : NT, G = NT / W, CS = (slots + G - 1) / G;
+    for (int q0 = 0; q0 < NQ; q0 += NT) {
+        const int q = q0 + tid % W, g = tid / W;
+        if (g < G && q < NQ) {
+            float v = 0.0f;
+            const int w1 = (g + 1) * CS < slots ? (g + 1) * CS : slots;
+            for (int w0 = g * CS; w0 < w1; w0 += 8) {
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float* src = r.part + (size_t)(w0 + u < w1 ? w0 + u : w1 - 1) * NQ + q;
+                    x[u] = COHERENT ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += w0 + u < w1 ? x[u] : 0.0f;
+            }
+            scr[g * W + (q - q0)] = v;
+        }
+        __syncthreads();
+        if (tid < W && q0 + tid < NQ) {
+            float tot = 0.0f;
+            for (int gg = 0; gg < G; ++gg) tot += scr[gg * W + tid];
+            red[q0 + tid] = tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float mse = red[0], mu_loss = red[1], var_loss = red[2], back = red[3];
+        float recon = r.det ? mse : mu_loss + var_loss;
+        if (r.has_back) recon += r.back_coeff * back;
+        r.losses_out[0] = mse;
+        r.losses_out[1] = r.has_back ? back : 0.0f;
+        r.losses_out[2] = recon;
+    }
+    if (r.adam_mm && tid < 2 * D) {
+        const bool mx = tid < D;
+        const int d = mx ? tid : tid - D;
+        float* w = (mx ? r.maxlv : r.minlv) + d;
+        float* m = (mx ? r.mx_m : r.mn_m) + d;
+        float* v = (mx ? r.mx_v : r.mn_v) + d;
+        float ww = *w, mm = *m, vv = *v;
+        adam_update(ww, mm, vv, red[4 + tid] + (mx ? 0.01f : -0.01f), r.lr_t, r.b1, r.b2, r.eps);
+        *w = ww; *m = mm; *v = vv;
+    }
+}
+
 // Closing phase of the forward launch of a training step: the workgroup's 16 rows x D head outputs are still in LDS, so the
 // loss terms, the head gradients and the workgroup's share of every reduction are taken here instead of in a launch of their
 // own (9 us of pure latency).  Forward-net workgroups own terms {mse, mu_loss, var_loss, d/d max_logvar,
@@ -702,71 +756,34 @@ __device__ __forceinline__ void chain_loss_phase(const ChainArgs& a, float* bufs
         float v = 0.0f;
         for (int j = lane; j < nel; j += 64) v += scr[wave * nel + j];
         v = wave_sum_fixed(v);
-        if (lane == 0) __hip_atomic_store(part + wave, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            if (a.loss_final) __hip_atomic_store(part + wave, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else part[wave] = v;
+        }
     } else {                                                       // per-dim terms: one thread per (bound, dim), rows ascending
         for (int o = tid - 256; o < 2 * D; o += 256) {
             const int which = o / D, d = o - which * D;
             float v = 0.0f;
             for (int m = 0; m < CH_ROWS; ++m) v += scr[(4 + which) * nel + m * D + d];
-            __hip_atomic_store(part + 4 + o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.loss_final) __hip_atomic_store(part + 4 + o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else part[4 + o] = v;
         }
     }
-    // Hand-off to the last workgroup WITHOUT an agent-scope fence: a release fence writes back the XCD's whole L2, which at
-    // this point holds the megabytes of z / h the chain has just stored (measured: + 48 us on the launch).  The partials
-    // are device-coherent stores (sc1: written through, past the non-coherent L2s) that have completed (vmcnt) before the
-    // arrival counter is bumped, and the last workgroup reads them with device-coherent loads.
+    // Training step: the partials are ordinary stores; the sums are taken by a spare workgroup of the weight-gradient launch
+    // (loss_finalize in dw_adam_kernel: the kernel boundary orders the two, nothing waits for anybody, and the reduction is off
+    // the step's critical path).  Evaluation (no further launch): hand-off to the last workgroup WITHOUT an agent-scope fence --
+    // a release fence writes back the XCD's whole L2, which at this point holds the megabytes of z / h the chain has just
+    // stored (measured: + 48 us on the launch).  There the partials are device-coherent stores (sc1: written through, past
+    // the non-coherent L2s) that have completed (vmcnt) before the arrival counter is bumped, and the last workgroup reads them
+    // with device-coherent loads.
+    if (!a.loss_final) return;
     int* const flag = reinterpret_cast<int*>(scr + (6 * nel > CH_THREADS ? 6 * nel : CH_THREADS));     // (launch_chain sizes scr)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) *flag = atomicInc(r.counter, a.loss_slots - 1) == (unsigned)(a.loss_slots - 1);     // wraps back to 0 for the next step
     __syncthreads();
     if (!*flag) return;
-    // sum over the slots: G groups of threads take contiguous chunks of slots (loads eight at a time -- one after the other
-    // they are 160 dependent fabric round trips: + 48 us measured), then the chunks are added in order
-    float* red = r.out;
-    const int G = NQ <= CH_THREADS ? CH_THREADS / NQ : 1, CS = (a.loss_slots + G - 1) / G;
-    for (int q0 = 0; q0 < NQ; q0 += CH_THREADS) {
-        const int q = q0 + tid % (NQ < CH_THREADS ? NQ : CH_THREADS), g = tid / (NQ < CH_THREADS ? NQ : CH_THREADS);
-        float v = 0.0f;
-        if (g < G && q < NQ) {
-            const int w1 = (g + 1) * CS < a.loss_slots ? (g + 1) * CS : a.loss_slots;
-            for (int w0 = g * CS; w0 < w1; w0 += 8) {
-                float x[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    x[u] = __hip_atomic_load(r.part + (size_t)(w0 + u < w1 ? w0 + u : w1 - 1) * NQ + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v += w0 + u < w1 ? x[u] : 0.0f;
-            }
-            scr[g * NQ + (q - q0)] = v;
-        }
-        __syncthreads();
-        if (tid < NQ - q0 && tid < CH_THREADS) {
-            float tot = 0.0f;
-            for (int gg = 0; gg < G; ++gg) tot += scr[gg * NQ + tid];
-            red[q0 + tid] = tot;
-        }
-        __syncthreads();
-    }
-    __syncthreads();                   // (red: written and read inside this workgroup, through its own L1 / L2)
-    if (tid == 0) {
-        const float mse = red[0], mu_loss = red[1], var_loss = red[2], back = red[3];
-        float recon = r.det ? mse : mu_loss + var_loss;
-        if (r.has_back) recon += r.back_coeff * back;
-        r.losses_out[0] = mse;
-        r.losses_out[1] = r.has_back ? back : 0.0f;
-        r.losses_out[2] = recon;
-    }
-    if (r.adam_mm && tid < 2 * D) {
-        const bool mx = tid < D;
-        const int d = mx ? tid : tid - D;
-        float* w = (mx ? r.maxlv : r.minlv) + d;
-        float* m = (mx ? r.mx_m : r.mn_m) + d;
-        float* v = (mx ? r.mx_v : r.mn_v) + d;
-        float ww = *w, mm = *m, vv = *v;
-        adam_update(ww, mm, vv, red[4 + tid] + (mx ? 0.01f : -0.01f), r.lr_t, r.b1, r.b2, r.eps);
-        *w = ww; *m = mm; *v = vv;
-    }
+    loss_finalize<CH_THREADS, true>(r, a.loss_slots, scr, tid);
 }
 
 __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
@@ -879,6 +896,7 @@ struct DwArgs {
     DwJob job[DW_MAXJOBS];
     int njobs, B, tiles, E;          // tiles: work items per member
     float lr_t, b1, b2, eps;
+    ReduceP lossr; int loss_slots;   // the step's loss partials (chain_loss_phase), summed by a spare workgroup of this launch
 };
 static_assert(sizeof(DwArgs) <= 4096, "kernel argument block");
 
@@ -904,6 +922,10 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     // Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8), each with its own L2.  Consecutive work items
     // (member-major, then job, then tile) re-read the same X / dZ panels, so XCD x gets the x-th CONTIGUOUS eighth of them:
     // a panel is then fetched into one L2 instead of up to eight (the kernel is fabric-bound: W, m, v alone are 44 MB).
+    if (blockIdx.x >= gridDim.x - 8) {                   // (eight spare workgroups keep the XCD arithmetic below; one works)
+        if (blockIdx.x == gridDim.x - 8 && a.loss_slots > 0) loss_finalize<256, false>(a.lossr, a.loss_slots, dw_smem, threadIdx.x);
+        return;
+    }
     const int per_xcd = (a.tiles * a.E + 7) >> 3;
     const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (item >= a.tiles * a.E) return;
@@ -1551,7 +1573,7 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
     return CADM_OK;
 }
 
-struct ChainLossCfg { LossP lp; ReduceP rp; };
+struct ChainLossCfg { LossP lp; ReduceP rp; int final; };
 
 int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s, const ChainLossCfg* loss = nullptr) {
     TrainState* t = ctx->train;
@@ -1573,7 +1595,7 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s, const Chai
     const int rounds = (ctx->E + 7) / 8;
     size_t lds = CH_MAXSTAGE * sizeof(ChainStage) + 3 * (size_t)t->chain_bufsz * sizeof(float);
     if (loss) {     // closing loss phase: 6 term arrays of the workgroup's 16 x D elements + a flag behind the activation buffers
-        a.loss_on = 1; a.loss_buf = t->loss_buf; a.loss_lv0 = t->loss_lv0; a.loss_slots = ctx->E * a.ny * a.ntiles;
+        a.loss_on = 1; a.loss_final = loss->final; a.loss_buf = t->loss_buf; a.loss_lv0 = t->loss_lv0; a.loss_slots = ctx->E * a.ny * a.ntiles;
         a.lossp = loss->lp; a.lossr = loss->rp;
         const size_t terms = 6 * (size_t)CH_ROWS * ctx->D;          // (the final reduction reuses it for up to CH_THREADS chunk sums)
         lds += ((terms > CH_THREADS ? terms : CH_THREADS) + 4) * sizeof(float);
@@ -1664,7 +1686,7 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     rp.lr_t = lr_t; rp.b1 = hp.beta1; rp.b2 = hp.beta2; rp.eps = hp.epsilon;
     CADM_REQUIRE(lp.n < (1L << 31), "cadm_train_step: E*B*D too large");
     // forward chains; their closing phase takes the losses, the head gradients and the reductions (chain_loss_phase)
-    ChainLossCfg lc{lp, rp};
+    ChainLossCfg lc{lp, rp, train ? 0 : 1};
     if ((rc = forward_nets(ctx, map, obs, act, obs_next, cp_obs, cp_act, B, has_back, s, &lc))) return rc;
     if (!train) return CADM_OK;
 
@@ -1722,7 +1744,8 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     if (det && (rc = l2_only_job(ctx->ff[NH + 1], wd_dyn(NH + 1), t->a_ff[2 * (NH + 1)]))) return rc;
     if (has_back && (rc = l2_only_job(ctx->back[NH + 1], wd_dyn(NH + 1), t->a_bk[2 * (NH + 1)]))) return rc;
     da.tiles = tiles; da.E = E;
-    hipLaunchKernelGGL(dw_adam_kernel, dim3(8 * ((tiles * E + 7) / 8)), dim3(256), 0, s, da);
+    da.lossr = rp; da.loss_slots = E * (has_back ? 2 : 1) * ((B + CH_ROWS - 1) / CH_ROWS);
+    hipLaunchKernelGGL(dw_adam_kernel, dim3(8 * ((tiles * E + 7) / 8) + 8), dim3(256), 0, s, da);
     CADM_CHECK_HIP(hipGetLastError());
     ctx->packed = false;   // planner streams are stale until cadm_repack
     return CADM_OK;
