@@ -104,7 +104,9 @@ int cadm_ctx_destroy(cadm_ctx* ctx);
 int cadm_set_weights(cadm_ctx* ctx, int net, int layer, float* W, float* b);
 /* max_logvar / min_logvar [1,D] (core/utils.py:338-339). */
 int cadm_set_logvar_bounds(cadm_ctx* ctx, int net, float* max_logvar, float* min_logvar);
-/* Re-pack the planner's weight streams from the registered master weights (after load()/fit()). */
+/* The caller has written master weights in place (load(), a manual assign; ANY net): re-pack the planner's weight streams
+ * now and mark the training chains' packed operand copies stale (rebuilt at the next cadm_train_step / cadm_predict;
+ * training steps themselves keep them current).  Writing registered weights without this call leaves both on old values. */
 int cadm_repack(cadm_ctx* ctx, void* stream);
 
 /* The 12 normalisation vectors fed per call in the reference (dynamics.py:344-347,604-645), order:
