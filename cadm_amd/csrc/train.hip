@@ -145,6 +145,7 @@ struct LossP {
     long n;                                  // E*B*D
     int D, B, det, has_back;
     float back_coeff;
+    int Dp;                                  // row stride of dMu / dLv / dBmu (D rounded up to 4: zero columns behind D)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -711,7 +712,7 @@ __device__ __forceinline__ void chain_loss_phase(const ChainArgs& a, float* bufs
         const int m = el / D, d = el - m * D, row = row0 + m;
         float tm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         if (row < B) {
-            const long grow = (long)e * B + row, i = grow * D + d;
+            const long grow = (long)e * B + row, i = grow * p.Dp + d;
             long srow, swin;
             map_row(p.map, grow, srow, swin);
             const long si = srow * D + d;                              // this element in the caller's target tensors
@@ -887,6 +888,7 @@ struct DwJob {                       // W[e] (M x N) <- Adam(W, X[e]^T dZ[e] + w
     const float* dZ2;                // optional second gradient, added on load (the context encoder's, from the two dynamics nets)
     float *W, *Mw, *Vw, *bW, *bM, *bV;
     int ldx, M, N, tile0;            // tile0: first workgroup (blockIdx.x) of this job
+    int ldz, pad;                    // row stride of dZ (>= N: the head / context gradients are stored with rows padded to 16 bytes)
     float wdc;
     int tn;                          // column tiles
     PackDst pf, pb;                  // the chain kernel's packed copies of W (forward / transposed operand), kept current here
@@ -897,6 +899,8 @@ struct DwArgs {
     int njobs, B, tiles, E;          // tiles: work items per member
     float lr_t, b1, b2, eps;
     ReduceP lossr; int loss_slots;   // the step's loss partials (chain_loss_phase), summed by a spare workgroup of this launch
+    unsigned long long* tbuf;        // cadm_dev_set_timing_buffer (tools/chain_timing.py): per workgroup [1024 + 2 b] start / end,
+                                     // [4096 + b] job and flavour, [5200 + b] end of the slab loop (s_memrealtime, 100 MHz)
 };
 static_assert(sizeof(DwArgs) <= 4096, "kernel argument block");
 
@@ -930,6 +934,10 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (item >= a.tiles * a.E) return;
     const int e = item / a.tiles, tile = item - e * a.tiles;
+#ifdef CADM_DW_TIMING       // (developer build only, tools/chain_timing.py: the stamps cost registers -- 132 VGPRs = 3 workgroups per CU)
+    const bool tstamp = a.tbuf && threadIdx.x == 0 && blockIdx.x < 1000;
+    if (tstamp) a.tbuf[1024 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     int ji = 0;
 #pragma unroll 1
     while (ji + 1 < a.njobs && tile >= a.job[ji + 1].tile0) ++ji;
@@ -939,7 +947,7 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     const int M = jb.M, N = jb.N, K = a.B;
     const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
     const float* A = jb.X + (long)e * K * jb.ldx;       // A(m = k_in, k = b) = X[b][k_in]
-    const float* Bm = jb.dZ + (long)e * K * N;          // B(k = b, n)        = dZ[b][n]
+    const float* Bm = jb.dZ + (long)e * K * jb.ldz;     // B(k = b, n)        = dZ[b][n]
     constexpr int MI = TM / 16;
     floatx4 acc[MI];
 #pragma unroll
@@ -987,7 +995,7 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
 #pragma unroll
         for (int it = 0; it < NLB; ++it) {
             const int k = k0 + kb[it];
-            const long o = (long)(k < kmax ? k : kmax) * N;
+            const long o = (long)(k < kmax ? k : kmax) * jb.ldz;
             const float v1 = pb[it][o], v2 = pb[it][o + d2];        // (both loads unconditional: d2 = 0 without a second gradient)
             rb[0][it] = two ? v1 + v2 : v1;
         }
@@ -999,7 +1007,11 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     // 8 LDS reads next to the 24 MFMAs, where the generic path below spends 14 + 14 + 32 and a clamp / select per element.
     // (On this part the matrix pipe does not overlap with another wave's VALU work: every instruction saved is MFMA time.)
     // k-steps are taken in the order k = 16 g + 4 q + u (lane group q, u = 0..3) -- any order, as long as A and B agree.
-    const bool vec = KP > 0 && (K % TK) == 0 && ((jb.ldx | N | M) & 3) == 0 && M >= 4 && N >= 4 &&
+    // (rows are read in 16-byte pieces up to the next multiple of 4 columns: the workspace pads the odd-width tensors -- the
+    //  normalised inputs, the head and context gradients -- with zero columns, so that the few jobs on them do not fall back to
+    //  the scalar loop: they were the launch's tail, 25-28 us of slab loop against 13-17)
+    const int Mq = (M + 3) & ~3, Nq = (N + 3) & ~3;
+    const bool vec = KP > 0 && (K % TK) == 0 && ((jb.ldx | jb.ldz) & 3) == 0 && Mq <= jb.ldx && Nq <= jb.ldz &&
                      ((reinterpret_cast<size_t>(jb.X) | reinterpret_cast<size_t>(jb.dZ) | reinterpret_cast<size_t>(jb.dZ2)) & 15) == 0;
     if (vec) {
         float* const At = dw_smem;
@@ -1010,13 +1022,13 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
         // ((f >> 2) & 7)) + (k & 3) -- the XOR spreads a wave's transposed stores over all banks (2 lanes per bank)
         const int kl = tid >> 3, ql = tid & 7, kl2 = (tid >> 2) & 31, ql2 = 8 + (tid & 3);
         const bool a1 = tid < 128;
-        const int ma0 = mb + 4 * ql < M ? mb + 4 * ql : M - 4, ma1 = mb + 4 * ql2 < M ? mb + 4 * ql2 : M - 4;
-        const int nb0 = nb + 4 * ql < N ? nb + 4 * ql : N - 4, nb1 = nb + 32 + 4 * ql < N ? nb + 32 + 4 * ql : N - 4;
+        const int ma0 = mb + 4 * ql < Mq ? mb + 4 * ql : Mq - 4, ma1 = mb + 4 * ql2 < Mq ? mb + 4 * ql2 : Mq - 4;
+        const int nb0 = nb + 4 * ql < Nq ? nb + 4 * ql : Nq - 4, nb1 = nb + 32 + 4 * ql < Nq ? nb + 32 + 4 * ql : Nq - 4;
         const floatx4* pA0 = reinterpret_cast<const floatx4*>(A + (long)kl * jb.ldx + ma0);
         const floatx4* pA1 = reinterpret_cast<const floatx4*>(A + (long)kl2 * jb.ldx + ma1);
-        const floatx4* pB0 = reinterpret_cast<const floatx4*>(Bm + (long)kl * N + nb0);
-        const floatx4* pB1 = reinterpret_cast<const floatx4*>(Bm + (long)kl * N + nb1);
-        const long sA = (long)TK * jb.ldx / 4, sB = (long)TK * N / 4;    // slab strides in float4
+        const floatx4* pB0 = reinterpret_cast<const floatx4*>(Bm + (long)kl * jb.ldz + nb0);
+        const floatx4* pB1 = reinterpret_cast<const floatx4*>(Bm + (long)kl * jb.ldz + nb1);
+        const long sA = (long)TK * jb.ldx / 4, sB = (long)TK * jb.ldz / 4;    // slab strides in float4
         float* const wA0 = At + (4 * ql) * LDK + 4 * ((kl >> 2) ^ (ql & 7)) + (kl & 3);
         float* const wA1 = At + (4 * ql2) * LDK + 4 * ((kl2 >> 2) ^ (ql2 & 7)) + (kl2 & 3);
         float* const wB0 = Bt + (4 * ql) * LDK + 4 * ((kl >> 2) ^ (ql & 7)) + (kl & 3);
@@ -1096,6 +1108,9 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     // ---- epilogue: D layout col = lane & 15 -> n, row = (lane >> 4) * 4 + r -> m.  Adam touches W, m and v once each
     // (read + write): that traffic, not the GEMM, is most of this kernel, so the tile goes through LDS and every thread
     // updates 4 consecutive columns with 16-byte accesses (a D-layout thread would touch 12 scattered dwords x 6) ----
+#ifdef CADM_DW_TIMING
+    if (tstamp) a.tbuf[5200 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     if ((N & 3) == 0) {
         __syncthreads();                                 // every wave is done reading the slab buffers
 #pragma unroll
@@ -1151,6 +1166,9 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
                 if (jb.pb.P && np >= 0 && np < jb.pb.ncols) jb.pb.P[(long)e * jb.pb.sP + pack_index(jb.pb, n, np)] = w;
             }
     }
+#ifdef CADM_DW_TIMING
+    if (tstamp) { a.tbuf[1024 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime(); a.tbuf[4096 + blockIdx.x] = ji * 2 + (vec ? 1 : 0); }
+#endif
     if (do_colsum && nb + tid < N) {
         const long o = (long)e * N + nb + tid;
         float w = jb.bW[o], mo = jb.bM[o], vo = jb.bV[o];
@@ -1202,6 +1220,7 @@ struct TrainState {
     ChainLoad pre[5][4]; int npre[5] = {0, 0, 0, 0, 0};         // the programs' input tiles (kernel arguments of the launch)
     ChainAsm asmp{};                                            // raw batch of the current call (forward launch)
     int loss_buf = 0, loss_lv0 = 0;                             // where the forward chains leave the head outputs in LDS
+    int K0p = 0, cpinp = 0, Dp = 0, Cp = 0;                     // padded row strides of Xff / Xbk, Xcp, dMu / dLv / dBmu, the dctx buffers
     int chain_bufsz = 0;
 };
 
@@ -1328,6 +1347,8 @@ static int pack_streams(cadm_ctx* ctx, hipStream_t s) {
     return CADM_OK;
 }
 
+static inline int r4(int n) { return (n + 3) & ~3; }
+
 static int ensure_workspace(cadm_ctx* ctx, int B) {
     TrainState* t = ctx->train;
     if (B <= t->B && t->ws) return CADM_OK;
@@ -1339,8 +1360,12 @@ static int ensure_workspace(cadm_ctx* ctx, int B) {
     const size_t Cw = ctx->C > 0 ? ctx->C : 1;
     size_t total = 0;
     auto need = [&](size_t n) { size_t o = total; total += (n + 63) & ~(size_t)63; return o; };
-    const size_t oXff = need(R * K0), oXbk = need(R * K0), oXcp = need(R * (cpin > 0 ? cpin : 1));
-    const size_t odCtx = need(R * Cw), odCff = need(R * Cw), odCbk = need(R * Cw);
+    // odd-width tensors that the weight-gradient launch reads get rows padded to a multiple of 4 floats (zero columns: the
+    // buffer is cleared once, nothing writes them): dw_adam_kernel then takes its 16-byte loop on them too
+    const int K0p = r4(K0), cpinp = r4(cpin > 0 ? cpin : 1), Dp = r4(D), Cp = r4((int)Cw);
+    t->K0p = K0p; t->cpinp = cpinp; t->Dp = Dp; t->Cp = Cp;
+    const size_t oXff = need(R * K0p), oXbk = need(R * K0p), oXcp = need(R * cpinp);
+    const size_t odCtx = need(R * Cp), odCff = need(R * Cp), odCbk = need(R * Cp);
     std::vector<size_t> oz_ff(NH), oh_ff(NH), od_ff(NH), oz_bk(NH), oh_bk(NH), od_bk(NH), oz_cp(ncp), oh_cp(ncp), od_cp(ncp), od_cpb(ncp);
     for (int l = 0; l < NH; ++l) {
         oz_ff[l] = need(R * HID); oh_ff[l] = need(R * HID); od_ff[l] = need(R * HID);
@@ -1351,9 +1376,10 @@ static int ensure_workspace(cadm_ctx* ctx, int B) {
         oz_cp[l] = need(R * w); oh_cp[l] = need(R * w); od_cp[l] = need(R * w); od_cpb[l] = need(R * w);
     }
     const size_t omu = need(R * D), olv = need(R * D), obmu = need(R * D), oblv = need(R * D);
-    const size_t odMu = need(R * D), odLv = need(R * D), odBmu = need(R * D);
+    const size_t odMu = need(R * Dp), odLv = need(R * Dp), odBmu = need(R * Dp);
     const size_t oterms = need((size_t)ctx->E * 2 * ((B + CH_ROWS - 1) / CH_ROWS) * (4 + 2 * (size_t)D)), ored = need(4 + 2 * (size_t)D + 8);   // a slot per forward workgroup
     CADM_CHECK_HIP(hipMalloc(&t->ws, total * sizeof(float)));
+    CADM_CHECK_HIP(hipMemset(t->ws, 0, total * sizeof(float)));
     t->ws_floats = total;
     float* w = t->ws;
     t->Xff = w + oXff; t->Xbk = w + oXbk; t->Xcp = w + oXcp; t->dCtx = w + odCtx; t->ff.dctx = w + odCff; t->bk.dctx = w + odCbk;
@@ -1470,10 +1496,10 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
             // (assembled from the raw batch on the way in; the forward net's workgroups also leave the normalised copies that
             //  the weight-gradient launch reads as layer-0 inputs.  g0 of the raw tiles is set per call: forward_nets)
             const int ncpo = D * ctx->cfg.history_length;
-            input(input_tile(nullptr, nullptr, store_cp ? t->Xcp : nullptr, 0, cpin, ncpo, 0, 0, ncpo, 3));
-            input(input_tile(nullptr, nullptr, store_cp ? t->Xcp + ncpo : nullptr, 0, cpin, cpin - ncpo, 0, ncpo, 16 * kblocks(cpin), 4));
-            input(input_tile(nullptr, nullptr, X, 0, K0, ctx->P, 2, 0, ctx->P, 1));
-            input(input_tile(nullptr, nullptr, X + ctx->P, 0, K0, ctx->A, 2, ctx->P, 16 * kblocks(K0), 2));
+            input(input_tile(nullptr, nullptr, store_cp ? t->Xcp : nullptr, 0, t->cpinp, ncpo, 0, 0, ncpo, 3));
+            input(input_tile(nullptr, nullptr, store_cp ? t->Xcp + ncpo : nullptr, 0, t->cpinp, cpin - ncpo, 0, ncpo, 16 * kblocks(cpin), 4));
+            input(input_tile(nullptr, nullptr, X, 0, t->K0p, ctx->P, 2, 0, ctx->P, 1));
+            input(input_tile(nullptr, nullptr, X + ctx->P, 0, t->K0p, ctx->A, 2, ctx->P, 16 * kblocks(K0), 2));
             cur = 0;
             for (int l = 0; l <= ncp; ++l) {
                 const DenseRef& L = ctx->cp[l];
@@ -1485,14 +1511,14 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
                     cur ^= 1;
                 } else {   // context vector -> the ctx columns of this net's input (LDS and global)
                     ChainStage g = gemm_stage(cur, 2, PA, ACT_NONE, ACT_NONE);
-                    add_seg(g, t->pf_cp[l], t->pt_cp[l], L.b, nullptr, nullptr, X + PA, L.dout, K0, 0);
+                    add_seg(g, t->pf_cp[l], t->pt_cp[l], L.b, nullptr, nullptr, X + PA, L.dout, t->K0p, 0);
                     push(g);
                 }
             }
             cur = 2;
         } else {
-            input(input_tile(nullptr, nullptr, X, 0, K0, ctx->P, 0, 0, ctx->P, 1));
-            input(input_tile(nullptr, nullptr, X + ctx->P, 0, K0, ctx->A, 0, ctx->P, 16 * kblocks(K0), 2));
+            input(input_tile(nullptr, nullptr, X, 0, t->K0p, ctx->P, 0, 0, ctx->P, 1));
+            input(input_tile(nullptr, nullptr, X + ctx->P, 0, t->K0p, ctx->A, 0, ctx->P, 16 * kblocks(K0), 2));
             cur = 0;
         }
         for (int l = 0; l < NH; ++l) {
@@ -1516,8 +1542,8 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
                         const float* dMu, const float* dLv, std::vector<float*>& cp_dz) {
         const int KBd = kblocks(D);
         // [dMu | dLv] side by side along k (the heads' transposed operands are concatenated the same way)
-        input(input_tile(dMu, nullptr, nullptr, D, 0, D, 0, 0, 16 * KBd));
-        if (dLv) input(input_tile(dLv, nullptr, nullptr, D, 0, D, 0, 16 * KBd, 32 * KBd));
+        input(input_tile(dMu, nullptr, nullptr, t->Dp, 0, D, 0, 0, 16 * KBd));
+        if (dLv) input(input_tile(dLv, nullptr, nullptr, t->Dp, 0, D, 0, 16 * KBd, 32 * KBd));
         {   // d z_{NH-1} = (dMu W_mu^T (+ dLv W_lv^T)) * act'(z_{NH-1})
             ChainStage g = gemm_stage(0, 1, 0, dyn_act(ctx), ACT_NONE);
             add_seg(g, pb[NH], ptb[NH], nullptr, nb.z[NH - 1], nullptr, nb.dz[NH - 1], HID, HID, HID);
@@ -1534,7 +1560,7 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
         if (has_cp) {   // only the context columns of the input carry a gradient ...
             int dst = (cur + 1) % 3;
             ChainStage g = gemm_stage(cur, dst, 0, ACT_NONE, ACT_NONE);
-            add_seg(g, pb[0], ptb[0], nullptr, nullptr, nullptr, nb.dctx, C, C, 0);
+            add_seg(g, pb[0], ptb[0], nullptr, nullptr, nullptr, nb.dctx, C, t->Cp, 0);
             push(g);
             cur = dst;
             // ... and it goes on down the context encoder in the same chain: backpropagation is linear in the incoming
@@ -1660,9 +1686,8 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     if (rc) return rc;
     TrainState* t = ctx->train;
     const cadm_train_hparams& hp = t->hp;
-    const int E = ctx->E, NH = ctx->NH, HID = ctx->HID, D = ctx->D, K0 = ctx->K0;
+    const int E = ctx->E, NH = ctx->NH, HID = ctx->HID, D = ctx->D;
     const int ncp = has_cp ? ctx->cfg.n_cp_hidden : 0;
-    const int cpin = (ctx->D + ctx->A) * ctx->cfg.history_length;
     const long R = (long)E * B;
 
     // ---- forward + losses + head gradients ----
@@ -1672,7 +1697,7 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     lp.dmean = ctx->st.delta_mean; lp.dstd = ctx->st.delta_std; lp.bdmean = ctx->st.back_delta_mean; lp.bdstd = ctx->st.back_delta_std;
     lp.maxlv = ctx->ff_maxlv; lp.minlv = ctx->ff_minlv;
     lp.dMu = t->dMu; lp.dLv = t->dLv; lp.dBmu = t->dBmu;
-    lp.n = R * D; lp.D = D; lp.B = B; lp.det = det; lp.has_back = has_back; lp.back_coeff = hp.back_coeff;
+    lp.n = R * D; lp.D = D; lp.Dp = t->Dp; lp.B = B; lp.det = det; lp.has_back = has_back; lp.back_coeff = hp.back_coeff;
     // lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t)  (TF1 Adam)
     if (train) t->step += 1;
     const float lr_t = (float)(hp.learning_rate * sqrt(1.0 - pow((double)hp.beta2, (double)t->step)) /
@@ -1701,12 +1726,12 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     DwArgs da{};
     da.B = B; da.lr_t = lr_t; da.b1 = hp.beta1; da.b2 = hp.beta2; da.eps = hp.epsilon;
     int tiles = 0;
-    auto add_job = [&](const float* X, int ldx, const float* dZ, const DenseRef& L, float wdc, AdamSlot& aw, AdamSlot& ab,
+    auto add_job = [&](const float* X, int ldx, const float* dZ, int ldz, const DenseRef& L, float wdc, AdamSlot& aw, AdamSlot& ab,
                        const PackDst& pf, const PackDst& pb) -> int {
         CADM_REQUIRE(da.njobs < DW_MAXJOBS, "cadm_train_step: too many layers for the grouped weight-gradient launch");
         DwJob& j = da.job[da.njobs++];
         j.X = X; j.dZ = dZ; j.dZ2 = nullptr; j.W = L.W; j.Mw = aw.m; j.Vw = aw.v; j.bW = L.b; j.bM = ab.m; j.bV = ab.v;
-        j.ldx = ldx; j.M = L.din; j.N = L.dout; j.tile0 = tiles; j.wdc = wdc; j.tn = (L.dout + TN - 1) / TN;
+        j.ldx = ldx; j.ldz = ldz; j.M = L.din; j.N = L.dout; j.tile0 = tiles; j.wdc = wdc; j.tn = (L.dout + TN - 1) / TN;
         j.pf = pf; j.pb = pb;
         tiles += j.tn * ((L.din + TM - 1) / TM);
         return CADM_OK;
@@ -1715,9 +1740,9 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
                         const float* dLv, std::vector<PackDst>& pf, std::vector<PackDst>& pb) -> int {
         int r;
         for (int l = 0; l < NH; ++l)
-            if ((r = add_job(l == 0 ? X : nb.h[l - 1], l == 0 ? K0 : HID, nb.dz[l], net[l], wd_dyn(l), ad[2 * l], ad[2 * l + 1], pf[l], pb[l]))) return r;
-        if ((r = add_job(nb.h[NH - 1], HID, dMu, net[NH], wd_dyn(NH), ad[2 * NH], ad[2 * NH + 1], pf[NH], pb[NH]))) return r;
-        if (dLv && (r = add_job(nb.h[NH - 1], HID, dLv, net[NH + 1], wd_dyn(NH + 1), ad[2 * (NH + 1)], ad[2 * (NH + 1) + 1], pf[NH + 1], pb[NH + 1]))) return r;
+            if ((r = add_job(l == 0 ? X : nb.h[l - 1], l == 0 ? t->K0p : HID, nb.dz[l], HID, net[l], wd_dyn(l), ad[2 * l], ad[2 * l + 1], pf[l], pb[l]))) return r;
+        if ((r = add_job(nb.h[NH - 1], HID, dMu, t->Dp, net[NH], wd_dyn(NH), ad[2 * NH], ad[2 * NH + 1], pf[NH], pb[NH]))) return r;
+        if (dLv && (r = add_job(nb.h[NH - 1], HID, dLv, t->Dp, net[NH + 1], wd_dyn(NH + 1), ad[2 * (NH + 1)], ad[2 * (NH + 1) + 1], pf[NH + 1], pb[NH + 1]))) return r;
         return CADM_OK;
     };
     if ((rc = net_jobs(ctx->ff, t->Xff, t->ff, t->a_ff, t->dMu, det ? nullptr : t->dLv, t->pf_ff, t->pb_ff))) return rc;
@@ -1725,8 +1750,8 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     if (has_cp) {
         auto wd_cp = [&](int l) { return coeff * (l < ncp ? hp.context_weight_decays[l] : hp.context_weight_decays[ncp]); };
         for (int l = 0; l <= ncp; ++l) {      // gradient = the forward net's share (+ the backward model's), added on load
-            if ((rc = add_job(l == 0 ? t->Xcp : t->cp.h[l - 1], l == 0 ? cpin : ctx->cp[l - 1].dout, l == ncp ? t->ff.dctx : t->cp.dz[l],
-                              ctx->cp[l], wd_cp(l), t->a_cp[2 * l], t->a_cp[2 * l + 1], t->pf_cp[l], t->pb_cp[l]))) return rc;
+            if ((rc = add_job(l == 0 ? t->Xcp : t->cp.h[l - 1], l == 0 ? t->cpinp : ctx->cp[l - 1].dout, l == ncp ? t->ff.dctx : t->cp.dz[l],
+                              l == ncp ? t->Cp : ctx->cp[l].dout, ctx->cp[l], wd_cp(l), t->a_cp[2 * l], t->a_cp[2 * l + 1], t->pf_cp[l], t->pb_cp[l]))) return rc;
             if (has_back) da.job[da.njobs - 1].dZ2 = l == ncp ? t->bk.dctx : t->cp_dz_bk[l];
         }
     }
@@ -1737,13 +1762,14 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
         DwJob& j = da.job[da.njobs++];
         j.X = nullptr; j.dZ = nullptr; j.dZ2 = nullptr; j.W = L.W; j.Mw = aw.m; j.Vw = aw.v; j.bW = nullptr; j.bM = nullptr; j.bV = nullptr;
         j.pf = PackDst{}; j.pb = PackDst{};
-        j.ldx = 0; j.M = L.din; j.N = L.dout; j.tile0 = tiles; j.wdc = wdc; j.tn = (L.dout + TN - 1) / TN;
+        j.ldx = 0; j.ldz = 0; j.M = L.din; j.N = L.dout; j.tile0 = tiles; j.wdc = wdc; j.tn = (L.dout + TN - 1) / TN;
         tiles += j.tn * ((L.din + TM - 1) / TM);
         return CADM_OK;
     };
     if (det && (rc = l2_only_job(ctx->ff[NH + 1], wd_dyn(NH + 1), t->a_ff[2 * (NH + 1)]))) return rc;
     if (has_back && (rc = l2_only_job(ctx->back[NH + 1], wd_dyn(NH + 1), t->a_bk[2 * (NH + 1)]))) return rc;
     da.tiles = tiles; da.E = E;
+    da.tbuf = ctx->tbuf;
     da.lossr = rp; da.loss_slots = E * (has_back ? 2 : 1) * ((B + CH_ROWS - 1) / CH_ROWS);
     hipLaunchKernelGGL(dw_adam_kernel, dim3(8 * ((tiles * E + 7) / 8) + 8), dim3(256), 0, s, da);
     CADM_CHECK_HIP(hipGetLastError());
