@@ -1118,16 +1118,28 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) dw_smem[(i * 16 + (lane >> 4) * 4 + r) * LDC + wn * 16 + (lane & 15)] = acc[i][r];
         __syncthreads();
+        // W, m, v of the thread's three column quads are requested TOGETHER (addresses clamped into the layer, never predicated:
+        // with a branch around each quad hipcc waits for one quad's loads before it issues the next -- three dependent round trips)
+        constexpr int NQD = TM * TN / 4 / 256;
+        floatx4 w3[NQD], m3[NQD], v3[NQD];
 #pragma unroll
-        for (int it = 0; it < TM * TN / 4 / 256; ++it) {
+        for (int it = 0; it < NQD; ++it) {
+            const int idx = tid + it * 256;
+            const int ml = idx / (TN / 4), n4 = (idx % (TN / 4)) * 4;
+            const int mc = mb + ml < M ? mb + ml : M - 1, nc = nb + n4 < N ? nb + n4 : N - 4;
+            const long o = ((long)e * M + mc) * N + nc;
+            w3[it] = *reinterpret_cast<const floatx4*>(jb.W + o); m3[it] = *reinterpret_cast<const floatx4*>(jb.Mw + o);
+            v3[it] = *reinterpret_cast<const floatx4*>(jb.Vw + o);
+        }
+#pragma unroll
+        for (int it = 0; it < NQD; ++it) {
             const int idx = tid + it * 256;
             const int ml = idx / (TN / 4), n4 = (idx % (TN / 4)) * 4;
             const int m = mb + ml, n = nb + n4;
             if (m >= M || n >= N) continue;
             const long o = ((long)e * M + m) * N + n;
             const floatx4 g = *reinterpret_cast<const floatx4*>(dw_smem + ml * LDC + n4);
-            floatx4 w = *reinterpret_cast<const floatx4*>(jb.W + o), mo = *reinterpret_cast<const floatx4*>(jb.Mw + o),
-                    vo = *reinterpret_cast<const floatx4*>(jb.Vw + o);
+            floatx4 w = w3[it], mo = m3[it], vo = v3[it];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float wc = w[c], mc = mo[c], vc = vo[c];
@@ -1150,6 +1162,16 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
             }
         }
     } else {
+        // (odd N: the heads, the context vector) -- the loads of all 12 elements first, clamped, for the same reason
+        float ws_[MI][4], ms_[MI][4], vs_[MI][4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb + i * 16 + (lane >> 4) * 4 + r, n = nb + wn * 16 + (lane & 15);
+                const long o = ((long)e * M + (m < M ? m : M - 1)) * N + (n < N ? n : N - 1);
+                ws_[i][r] = jb.W[o]; ms_[i][r] = jb.Mw[o]; vs_[i][r] = jb.Vw[o];
+            }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1158,7 +1180,7 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
                 const int n = nb + wn * 16 + (lane & 15);
                 if (m >= M || n >= N) continue;
                 const long o = ((long)e * M + m) * N + n;
-                float w = jb.W[o], mo = jb.Mw[o], vo = jb.Vw[o];
+                float w = ws_[i][r], mo = ms_[i][r], vo = vs_[i][r];
                 adam_update(w, mo, vo, acc[i][r] + jb.wdc * w, a.lr_t, a.b1, a.b2, a.eps);
                 jb.W[o] = w; jb.Mw[o] = mo; jb.Vw[o] = vo;
                 if (jb.pf.P) jb.pf.P[(long)e * jb.pf.sP + pack_index(jb.pf, m, n)] = w;
