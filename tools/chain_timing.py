@@ -18,7 +18,7 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     hid = int(os.environ.get("CHAIN_HID", "200"))
     prob = synth.make_problem(env="halfcheetah", context=True, E=5, with_back=True, seed=0, hidden_sizes=(hid,) * 4)
-    eng = make_engine(prob, p=20, lib=_lib.load_dev())
+    eng = make_engine(prob, p=20, lib=_lib.load_dev(os.environ.get("CHAIN_LIB")))      # CHAIN_LIB: a build with -DCADM_DW_TIMING for the dw_adam report
     batch = {k: eng._t(v) for k, v in synth.make_train_batch(prob, B=B, seed=1).items()}
     tbuf = torch.zeros(8192, dtype=torch.int64, device=eng.device)
     eng._check(eng.lib.cadm_dev_set_timing_buffer(eng._ctx, ct.c_void_p(tbuf.data_ptr())))
