@@ -703,7 +703,18 @@ __device__ __forceinline__ void loss_finalize(const ReduceP& r, int slots, float
 // (rows ascending), then -- by the workgroup that arrives last -- all partials in slot order: no float atomics, the result
 // does not depend on which workgroup is last.  That one also finalises (losses_out, Adam on max / min_logvar), exactly as
 // the separate loss / reduction launch of earlier rounds did.
-__device__ __forceinline__ void chain_loss_phase(const ChainArgs& a, float* bufs, float* scr, int e, int y, int row0, int tid) {
+// The normalised target of a thread's FIRST element (el = tid; the only one when 16 D <= 512): requested in the kernel prologue,
+// a whole forward pass before it is needed -- its memory latency used to sit at the end of the launch.
+__device__ __forceinline__ float chain_loss_target(const LossP& p, int e, int y, int row0, int el) {
+    const int D = p.D, m = el / D, d = el - m * D, row = row0 + m;
+    if (el >= CH_ROWS * D || row >= p.B) return 0.0f;
+    long srow, swin;
+    map_row(p.map, (long)e * p.B + row, srow, swin);
+    const long si = srow * D + d;                                      // this element in the caller's target tensors
+    return y == 0 ? (p.delta[si] - p.dmean[d]) / (p.dstd[d] + 1e-10f) : (p.back_delta[si] - p.bdmean[d]) / (p.bdstd[d] + 1e-10f);
+}
+
+__device__ __forceinline__ void chain_loss_phase(const ChainArgs& a, float* bufs, float* scr, int e, int y, int row0, int tid, float tgt0) {
     const LossP& p = a.lossp;
     const ReduceP& r = a.lossr;
     const int D = p.D, B = p.B, nel = CH_ROWS * D, lane = tid & 63, wave = tid >> 6;
@@ -713,13 +724,11 @@ __device__ __forceinline__ void chain_loss_phase(const ChainArgs& a, float* bufs
         float tm[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         if (row < B) {
             const long grow = (long)e * B + row, i = grow * p.Dp + d;
-            long srow, swin;
-            map_row(p.map, grow, srow, swin);
-            const long si = srow * D + d;                              // this element in the caller's target tensors
             const float s = 1.0f / ((float)B * (float)D);             // reduce_mean over b then d; reduce_sum over e
             const float mu = hb[lds_at(d, m)];
+            const float tgt = el == tid ? tgt0 : chain_loss_target(p, e, y, row0, el);     // (normalised target)
             if (y == 0) {
-                const float t = (p.delta[si] - p.dmean[d]) / (p.dstd[d] + 1e-10f);
+                const float t = tgt;
                 const float diff = mu - t;
                 tm[0] = diff * diff * s;                                                  // mse            (:273-274)
                 if (p.det) {
@@ -740,7 +749,7 @@ __device__ __forceinline__ void chain_loss_phase(const ChainArgs& a, float* bufs
                     tm[5] = g_lvc * (1.0f - s1);                                          // d / d min_logvar
                 }
             } else {
-                const float tb = (p.back_delta[si] - p.bdmean[d]) / (p.bdstd[d] + 1e-10f);
+                const float tb = tgt;
                 const float db = mu - tb;
                 tm[3] = db * db * s;                                                      // back_mse       (:280-281)
                 p.dBmu[i] = p.back_coeff * 2.0f * s * db;
@@ -862,6 +871,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     __syncthreads();
     const bool timed = a.tbuf && item == 0 && e == 0 && tid == 0;
     if (timed) a.tbuf[0] = __builtin_readcyclecounter();
+    const float tgt0 = a.loss_on ? chain_loss_target(a.lossp, e, y, row0, tid) : 0.0f;
     ChainOps ops;
     ChainGroup cur = next_group(stg, nst, -1, 0, wave, e);
     load_ops(stg, cur, e, B, row0, lane, ops);
@@ -877,7 +887,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
         __syncthreads();
         if (timed) a.tbuf[si + 1] = __builtin_readcyclecounter();
     }
-    if (a.loss_on) chain_loss_phase(a, bufs, bufs + 3 * a.bufsz, e, y, row0, tid);
+    if (a.loss_on) chain_loss_phase(a, bufs, bufs + 3 * a.bufsz, e, y, row0, tid, tgt0);
 }
 
 // ---------------------------------------------------------------------------------------------
