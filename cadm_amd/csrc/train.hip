@@ -905,6 +905,8 @@ struct DwJob {                       // W[e] (M x N) <- Adam(W, X[e]^T dZ[e] + w
 };
 #define DW_MAXJOBS 20
 struct DwArgs {
+    int tile0s[DW_MAXJOBS];          // the jobs' first tiles again, compact: the job search reads two 64-byte lines of the argument block
+                                     // instead of one line per job it steps over (each a dependent scalar-memory round trip)
     DwJob job[DW_MAXJOBS];
     int njobs, B, tiles, E;          // tiles: work items per member
     float lr_t, b1, b2, eps;
@@ -950,7 +952,7 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
 #endif
     int ji = 0;
 #pragma unroll 1
-    while (ji + 1 < a.njobs && tile >= a.job[ji + 1].tile0) ++ji;
+    while (ji + 1 < a.njobs && tile >= a.tile0s[ji + 1]) ++ji;
     const DwJob& jb = a.job[ji];
     const int t = tile - jb.tile0;
     const int mb = (t / jb.tn) * TM, nb = (t % jb.tn) * TN;
@@ -1802,6 +1804,7 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     if (has_back && (rc = l2_only_job(ctx->back[NH + 1], wd_dyn(NH + 1), t->a_bk[2 * (NH + 1)]))) return rc;
     da.tiles = tiles; da.E = E;
     da.tbuf = ctx->tbuf;
+    for (int i = 0; i < da.njobs; ++i) da.tile0s[i] = da.job[i].tile0;
     da.lossr = rp; da.loss_slots = E * (has_back ? 2 : 1) * ((B + CH_ROWS - 1) / CH_ROWS);
     hipLaunchKernelGGL(dw_adam_kernel, dim3(8 * ((tiles * E + 7) / 8) + 8), dim3(256), 0, s, da);
     CADM_CHECK_HIP(hipGetLastError());
