@@ -410,7 +410,7 @@ __device__ __forceinline__ void load_ops(const ChainStage* stg, const ChainGroup
 // One tile pair of a GEMM stage: k loop over the ring, epilogue.  At the end of the epilogue -- behind this group's
 // stores -- the NEXT group's operands and first ring blocks are requested: by the time the stage-end barrier has been
 // passed they have landed, so a stage starts with MFMAs instead of an L2 round trip.
-__device__ __forceinline__ void chain_group(const ChainStage* stg, const ChainGroup& g, const ChainGroup& nxt, ChainOps& ops,
+__device__ __forceinline__ void chain_group(const ChainStage* stg, int nst, int wave, const ChainGroup& g, ChainGroup& nxt, ChainOps& ops,
                                             float* bufs, int bufsz, int e, int B, int row0, int lane, unsigned long long* dbg) {
     if (dbg) dbg[0] = __builtin_readcyclecounter();
     const ChainStage& st = stg[g.si];
@@ -544,6 +544,7 @@ __device__ __forceinline__ void chain_group(const ChainStage* stg, const ChainGr
                 }
         }
     }
+    nxt = next_group(stg, nst, g.si, g.tp, wave, e);       // (looked up here, not in front of the k loop: its LDS reads are round trips)
     load_ops(stg, nxt, e, B, row0, lane, ops);
     ring_prologue(nxt, loff);
     if (dbg) dbg[2] = __builtin_readcyclecounter();
@@ -878,9 +879,9 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     ring_prologue(cur, 16u * (unsigned)lane);
     for (int si = 0; si < nst; ++si) {
         while (cur.si == si) {
-            const ChainGroup nxt = next_group(stg, nst, si, cur.tp, wave, e);
+            ChainGroup nxt;
             unsigned long long* dbg = timed ? a.tbuf + 64 + si * 4 : nullptr;
-            chain_group(stg, cur, nxt, ops, bufs, a.bufsz, e, B, row0, lane, dbg);
+            chain_group(stg, nst, wave, cur, nxt, ops, bufs, a.bufsz, e, B, row0, lane, dbg);
             cur = nxt;
         }
         if (timed) a.tbuf[64 + si * 4 + 3] = __builtin_readcyclecounter();
