@@ -275,6 +275,8 @@ struct ChainGroup {       // one wave's work in one stage: a tile pair
     int KB;
     gcbytes w0;           // block 0 of the pair (tile 1 right behind tile 0)
     int bstep;            // bytes from one k-block to the next
+    int sg, nb, src;      // its segment, first column inside the segment, LDS buffer of the stage's input: looked up with the
+                          // group (one stage ahead), so that nothing the k loop needs is read out of the table at stage start
 };
 
 // block i of the group -> ring slot S (both tiles); (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset)
@@ -353,6 +355,7 @@ __device__ __forceinline__ ChainGroup group_of(const ChainStage* stg, int si, in
     const ChainSeg& seg = st.seg[sg];
     ChainGroup g;
     g.si = si; g.tp = tp; g.KB = uni(st.KB);
+    g.sg = sg; g.nb = 32 * (tp - (sg ? tp1 : 0)); g.src = uni(st.src);
     g.w0 = uni((gcbytes)(as_global(seg.P) + (long)e * seg.sP + (long)(2 * (tp - (sg ? tp1 : 0))) * CH_BLK_FLOATS));
     g.bstep = uni(seg.nt) * (CH_BLK_FLOATS * 4);
     return g;
@@ -363,7 +366,7 @@ __device__ __forceinline__ ChainGroup next_group(const ChainStage* stg, int nst,
     for (int sj = si + 1; sj < nst; ++sj)
         if (wave < uni(stg[sj].ntp)) return group_of(stg, sj, wave, e);
     ChainGroup g;
-    g.si = -1; g.tp = 0; g.KB = 0; g.w0 = nullptr; g.bstep = 0;
+    g.si = -1; g.tp = 0; g.KB = 0; g.w0 = nullptr; g.bstep = 0; g.sg = 0; g.nb = 0; g.src = 0;
     return g;
 }
 
@@ -416,23 +419,21 @@ __device__ __forceinline__ void chain_group(const ChainStage* stg, int nst, int 
     const ChainStage& st = stg[g.si];
     const int m = lane & 15, q = lane >> 4;
     const unsigned loff = 16u * (unsigned)lane;
-    const int tp1 = uni(st.tp1);
-    const int sg = g.tp >= tp1 ? 1 : 0;
+    const int sg = g.sg, rtp1 = st.tp1;
     const ChainSeg& seg = st.seg[sg];
-    const int nb = 32 * (g.tp - (sg ? tp1 : 0));          // first column of the pair inside its segment
-    // stage constants -> SGPRs (they come out of LDS): scalar address bases, uniform branches on the activation kinds
-    const int N = uni(seg.N), ldo = uni(seg.ldo), dk0 = uni(st.dk0), dsti = uni(st.dst);
-    const int act_d = uni(st.act_d), act_o = uni(st.act_o), zfill = uni(st.zfill);
-    const bool VEC = uni(seg.vec) != 0;
-    gcbytes p_o0 = uni_ptr(seg.out0), p_o1 = uni_ptr(seg.out1);
-    const bool has_z = uni_ptr(seg.zprev) != nullptr, has_b = uni_ptr(seg.bias) != nullptr, s0 = p_o0 != nullptr, s1 = p_o1 != nullptr;
+    const int nb = g.nb;                                  // first column of the pair inside its segment
+    // The epilogue's stage constants are REQUESTED here (plain LDS reads into VGPRs, all independent) and made scalar behind the
+    // k loop: read and used in front of it, their two or three dependent LDS round trips delayed every stage's first MFMA.
+    const int rN = seg.N, rldo = seg.ldo, rdk0 = st.dk0, rdst = st.dst, ract_d = st.act_d, ract_o = st.act_o, rzf = st.zfill, rvec = seg.vec;
+    const float *rbias = seg.bias, *rz = seg.zprev;
+    float *ro0 = seg.out0, *ro1 = seg.out1;
     const long mrow = (long)e * B;                        // first row of this member in the [E][B][.] tensors
     const int row = row0 + m;
     const floatx4 bv[2] = {ops.bv[0], ops.bv[1]}, zp[2] = {ops.zp[0], ops.zp[1]};
     const int n0[2] = {nb + 4 * q, nb + 16 + 4 * q};
     floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
     {   // ---- k loop: block i of the pair sits in ring slot i % 8; its loads were issued 7 blocks earlier ----
-        const float* abase = bufs + uni(st.src) * bufsz + 4 * lane;       // activation block i: + 256 i floats
+        const float* abase = bufs + g.src * bufsz + 4 * lane;             // activation block i: + 256 i floats
         floatx4 xa[4];
         xa[0] = *reinterpret_cast<const floatx4*>(abase);
         xa[1] = *reinterpret_cast<const floatx4*>(abase + CH_BLK_FLOATS * (g.KB > 1 ? 1 : 0));
@@ -442,6 +443,12 @@ __device__ __forceinline__ void chain_group(const ChainStage* stg, int nst, int 
         ring_done(acc);
     }
     if (dbg) dbg[1] = __builtin_readcyclecounter();
+    // stage constants -> SGPRs: scalar address bases, uniform branches on the activation kinds
+    const int N = uni(rN), ldo = uni(rldo), dk0 = uni(rdk0), dsti = uni(rdst), tp1 = uni(rtp1);
+    const int act_d = uni(ract_d), act_o = uni(ract_o), zfill = uni(rzf);
+    const bool VEC = uni(rvec) != 0;
+    gcbytes p_o0 = uni_ptr(ro0), p_o1 = uni_ptr(ro1);
+    const bool has_z = uni_ptr(rz) != nullptr, has_b = uni_ptr(rbias) != nullptr, s0 = p_o0 != nullptr, s1 = p_o1 != nullptr;
     floatx4 v0[2], v1[2];                         // [tile][r]: before / after the output activation
 #pragma unroll
     for (int j = 0; j < 2; ++j)
