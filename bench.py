@@ -1,7 +1,9 @@
 """bench.py -- CEM rollout row-steps/s of the PE-TS+CaDM planner on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 without WORLD_SIZE in the environment: bench.py launches its own N ranks (re-executes itself under
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`); launched BY
+  torch.distributed.run (WORLD_SIZE / RANK / LOCAL_RANK set) it is one of the ranks.  Rank 0 prints the one JSON line.
 
 A "step" is ONE `MLPEnsembleCEMDynamicsModel.get_action` on BASELINE.json's configs[1] (halfcheetah PE-TS+CaDM, ens=5,
 part=20, cand=200 per GPU, H=30, m=1): context encoder + 5 CEM iterations x (sample, 30-step fused rollout of cand*part rows,
@@ -24,6 +26,8 @@ padding) / 2500.  `mfma_busy` and `traffic` come from the committed rocprofv3 PM
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from collections import OrderedDict
@@ -36,7 +40,7 @@ import torch  # noqa: E402
 
 F16_MFMA_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: dense f16 / bf16 MFMA
 FP32_MFMA_PEAK_TFLOPS = 157.3   # same guide, "Peak FP32 (matrix)": what v_mfma_f32_*_f32 could reach (reported for context only)
-PMC_FILE = "r3_pmc_%s.json"     # profiles/: mean counters per rollout dispatch from separate rocprofv3 --pmc passes of this command
+PMC_FILE = "r4_pmc_%s.json"     # profiles/: mean counters per rollout dispatch from separate rocprofv3 --pmc passes of this command
 
 
 def flops_per_row_step(K0, hid, D, n_hidden):
@@ -159,6 +163,77 @@ def train_step_bench(device, lib=None, steps=100, warmup=10, B=256):
             "workload": "halfcheetah CaDM ensemble + backward model, fwd/bwd/TF1-Adam, fp32"}
 
 
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: run the N ranks ourselves, one process per GPU, as the
+    driver's own multi-GPU form does (torch.distributed.run, rendezvous on 127.0.0.1).  Rank 0's JSON line passes through on
+    stdout; the launcher's exit code is the job's."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool's hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+class DryRunPlanner:
+    """--dry-run: the launcher / rank / JSON plumbing of this file on CPU over gloo, with NO planner behind it (tests/
+    test_bench_launcher.py: the N > 1 path must not rot between the rare runs on a multi-GPU node).  Every number it produces
+    is a placeholder and the line says so (`data: "dry-run"`)."""
+    RAMP_PLANS = 0
+
+    def __init__(self, cfg, m, n_per_gpu, world, rank, dist):
+        self.cfg, self.m, self.world, self.rank, self.dist = cfg, m, world, rank, dist
+        self.n_per_gpu, self.n, self.p, self.E, self.H = n_per_gpu, n_per_gpu * world, cfg["p"], cfg["E"], cfg["H"]
+        self.prob = {"K0": 34, "D": 18, "env": cfg["env"], "m": m, "H": self.H}
+        self.collective, self.rccl_nranks = ("gloo all-gather (dry run)", world) if world > 1 else ("none", 1)
+        self.iters = 5
+
+    def _step(self):
+        time.sleep(1e-3)
+        if self.dist is not None:
+            mine = torch.full((self.m, self.n_per_gpu), float(self.rank))
+            for _ in range(self.iters):                       # the path's one all-gather per CEM iteration
+                out = [torch.empty_like(mine) for _ in range(self.world)]
+                self.dist.all_gather(out, mine)
+            assert [float(o[0, 0]) for o in out] == [float(r) for r in range(self.world)]
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def _timed(self, steps, warmup):
+        for _ in range(warmup):
+            self._step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self._step()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def run_api(self, steps, warmup):
+        return self._timed(steps, warmup)
+
+    def run_device(self, steps, warmup, profile=True):
+        e = self._timed(steps, warmup)
+        return dict(elapsed=e, kern_ms=e * 1e3 * 0.8, kern_launches=steps * self.iters,
+                    ag_ms=0.01 * steps * self.iters if self.world > 1 else 0.0, ag_calls=steps * self.iters if self.world > 1 else 0)
+
+    summary = None   # bound below (same arithmetic as Planner.summary)
+
+    def close(self):
+        pass
+
+
 class Planner:
     """One planner problem on this rank's GPU, built through the DROP-IN CLASS (cadm_amd.dynamics) with synthetic weights and
     statistics; candidate-sharded over the ranks of the default process group when world > 1 (in-library RCCL)."""
@@ -193,6 +268,7 @@ class Planner:
         self.obs, self.cp_obs, self.cp_act = eng._t(prob["obs"]), eng._t(prob["cp_obs"]), eng._t(prob["cp_act"])
         self.init_mean, self.init_var = eng._t(prob["init_mean"]), eng._t(prob["init_var"])
         self.collective, self.rccl_nranks = "none", 1
+        self.iters = eng.num_cem_iters
 
     # ---- numpy in -> numpy out through the class (the reference's call, dynamics.py:344-367 / vanilla :191-207)
     def api_call(self, prev_sol):
@@ -256,9 +332,11 @@ class Planner:
         assert np.isfinite(plan).all() and np.abs(plan).max() <= 1.0
         return elapsed
 
-    def run_device(self, steps, warmup):
-        """K planner calls on HBM-resident inputs (cadm_cem_plan only), the rollout launches and the all-gathers bracketed by
-        hipEvents on the launch stream inside the library.  -> dict(elapsed [s, max over ranks], kern_ms, kern_launches, ag_*)."""
+    def run_device(self, steps, warmup, profile=True):
+        """K planner calls on HBM-resident inputs (cadm_cem_plan only).  profile=True: the rollout launches and the all-gathers
+        are bracketed by hipEvents on the launch stream inside the library (kernel / collective times; the events cost a few us
+        per get_action, so the wall time of THIS pass is not the device-resident figure); profile=False: no events, wall time only.
+        -> dict(elapsed [s, max over ranks], kern_ms, kern_launches, ag_*)."""
         eng = self.eng
         if self.world > 1 and eng.dist_world == 1:
             eng.dist_init(self.dist.group.WORLD)
@@ -267,26 +345,30 @@ class Planner:
                                       self.init_mean, self.init_var, self.n, seed=0, call=c)
         for w in range(warmup):
             step(w)
-        eng.profile_enable(True)
+        if profile:
+            eng.profile_enable(True)
         self.barrier()
         t0 = time.perf_counter()
         for k in range(steps):
             plan = step(warmup + k)
         self.barrier()
         elapsed = self._max_over_ranks(time.perf_counter() - t0)
-        kern_ms, kern_launches = eng.profile_read()
-        ag_ms, ag_calls = eng.profile_read_collective()
-        eng.profile_enable(False)
+        kern_ms = ag_ms = 0.0
+        kern_launches = ag_calls = 0
+        if profile:
+            kern_ms, kern_launches = eng.profile_read()
+            ag_ms, ag_calls = eng.profile_read_collective()
+            eng.profile_enable(False)
         assert torch.isfinite(plan).all()
         return dict(elapsed=elapsed, kern_ms=kern_ms, kern_launches=kern_launches, ag_ms=ag_ms, ag_calls=ag_calls)
 
     def summary(self, r, steps):
-        row_steps = self.m * self.n * self.p * self.H * self.eng.num_cem_iters
+        row_steps = self.m * self.n * self.p * self.H * self.iters
         prob = self.prob
         fl = flops_per_row_step(prob["K0"], 200, prob["D"], 4)
         xfl = executed_mfma_flops_per_row_step(prob["K0"], 200, prob["D"], 4)
         rows_per_launch = self.m * self.n_per_gpu * self.p * self.H
-        kavg = r["kern_ms"] / 1e3 / max(r["kern_launches"], 1)
+        kavg = r["kern_ms"] / 1e3 / max(r["kern_launches"], 1) or float("nan")
         return dict(value=row_steps * steps / r["elapsed"], ms_per_get_action=r["elapsed"] / steps * 1e3,
                     kernel_avg_launch_ms=kavg * 1e3, launches=r["kern_launches"], row_steps_per_launch=rows_per_launch,
                     achieved_tflops=rows_per_launch * fl / kavg / 1e12, executed_f16_mfma_tflops=rows_per_launch * xfl / kavg / 1e12,
@@ -298,9 +380,36 @@ class Planner:
         self.eng.close()
 
 
+DryRunPlanner.summary = Planner.summary
+
+
 LEGS = {   # name: (config, m, candidates per GPU)
     "cfg3": ("cfg3", 1, 2000), "cfg4": ("cfg4", 1, 1000), "cfg5": ("cfg5", 1, 1000), "m10": ("cfg2", 10, 200),
 }
+
+
+def pmc_block(config, build_id):
+    """Counters of the dominant kernel.  PMC counters cannot be read from inside this process; they come from separate
+    `rocprofv3 --pmc` passes of THIS command (tools/profile_round.sh), committed under profiles/ as means per rollout dispatch
+    together with the build id (cadm_build_id(): hash of the kernel sources) of the library they were measured on.  A file from
+    another build is NOT quoted: the fields stay null and `pmc_note` says why.
+    gfx950 (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide coalesced reads at half their bytes -> doubled; KB -> bytes."""
+    tpath = os.path.join(ROOT, "profiles", PMC_FILE % config)
+    if not os.path.exists(tpath):
+        return None, None, None, "no committed PMC pass for this workload"
+    raw = json.load(open(tpath))
+    src = "profiles/" + PMC_FILE % config
+    if raw.get("build_id") != build_id:
+        return None, None, src, ("%s was measured on build %s, the loaded library is build %s: counters not quoted (re-run "
+                                 "tools/profile_round.sh)" % (src, raw.get("build_id"), build_id))
+    traffic = None
+    if "FETCH_SIZE" in raw and "WRITE_SIZE" in raw:
+        traffic = (2.0 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"]) * 1024.0
+    # SIMD-cycles the matrix pipe was busy / SIMD-cycles of the launch (tools/pmc_extract.py: SQ_VALU_MFMA_BUSY_CYCLES /
+    # (4 SIMDs x CUs x GRBM_GUI_ACTIVE))
+    return traffic, raw.get("mfma_busy_frac"), src, (
+        "mfma_busy (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of the launch) and traffic (bytes/launch = 2*FETCH_SIZE + WRITE_SIZE) are read "
+        "from the committed rocprofv3 --pmc passes of this command on THIS build (build id %s), not measured in this run" % build_id)
 
 
 def main():
@@ -314,60 +423,70 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline leg (and the parity block measured inside it)")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no legs, no training-step leg, no cpu baseline / parity")
     ap.add_argument("--lib", default=None, help="DEVELOPER: bind the run to another build of the library (tools/ab.sh); default = the product")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rank / JSON plumbing only, on CPU over gloo, no planner (tests/test_bench_launcher.py)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     from cadm_amd import _lib, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world)
-    torch.cuda.set_device(local_rank)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dist = None
+    if not args.dry_run:
+        if torch.cuda.device_count() < world:
+            raise SystemExit("--gpus %d but only %d visible GPU(s)" % (world, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dry_run:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     lib = _lib.load_dev(args.lib) if args.lib else None
+    build_id = "dry-run" if args.dry_run else (lib or _lib.load()).cadm_build_id().decode()
 
     def make(name, cand=None):
         cfgname, m, n_per_gpu = LEGS[name] if name in LEGS else (name, 1, synth.CONFIGS[name]["n"])
+        if args.dry_run:
+            return DryRunPlanner(dict(synth.CONFIGS[cfgname]), m, cand or n_per_gpu, world, rank, dist), cfgname, m
         return Planner(dict(synth.CONFIGS[cfgname]), m, cand or n_per_gpu, world, rank, local_rank, dist, lib), cfgname, m
 
     head, cfgname, m = make(args.config, args.cand_per_gpu)
     api_elapsed = head.run_api(args.steps, args.warmup)
-    r = head.run_device(args.steps, args.warmup)
+    plain = head.run_device(args.steps, args.warmup, profile=False)      # device-resident wall time: no event bracketing
+    r = head.run_device(args.steps, args.warmup, profile=True)           # kernel / collective times from hipEvents
     s = head.summary(r, args.steps)
     cfg = head.cfg
     api_ms = api_elapsed / args.steps * 1e3
+    dev_ms = plain["elapsed"] / args.steps * 1e3
     api_value = s["row_steps_per_get_action"] * args.steps / api_elapsed
 
-    # counters of the dominant kernel: PMC counters cannot be read from inside this process; they come from separate
-    # `rocprofv3 --pmc` passes of THIS command (tools/profile_round.sh), committed under profiles/ as means per rollout dispatch.
-    # gfx950 (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide coalesced reads at half their bytes -> doubled; KB -> bytes.
     traffic = mfma_busy = pmc_src = None
-    tpath = os.path.join(ROOT, "profiles", PMC_FILE % args.config)
-    if world == 1 and args.cand_per_gpu is None and os.path.exists(tpath):
-        raw = json.load(open(tpath))
-        pmc_src = "profiles/" + PMC_FILE % args.config
-        if "FETCH_SIZE" in raw and "WRITE_SIZE" in raw:
-            traffic = (2.0 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"]) * 1024.0
-        # SIMD-cycles the matrix pipe was busy / SIMD-cycles of the launch (tools/pmc_extract.py: SQ_VALU_MFMA_BUSY_CYCLES /
-        # (4 SIMDs x CUs x GRBM_GUI_ACTIVE))
-        mfma_busy = raw.get("mfma_busy_frac")
+    pmc_note = "PMC passes are recorded for the default single-GPU workloads only"
+    if world == 1 and args.cand_per_gpu is None and not args.dry_run:
+        traffic, mfma_busy, pmc_src, pmc_note = pmc_block(args.config, build_id)
     peak_equiv = F16_MFMA_PEAK_TFLOPS / 3.0
     out = {
         "metric": "CEM rollout row-steps/s (cand x part x horizon x 5 CEM iters per get_action; ens=%d members)" % cfg["E"],
         "value": api_value, "unit": "row-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": api_ms, "get_action_latency_ms": api_ms, "plans_per_s": 1e3 / api_ms, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
+        "scaling": "weak", "vs_baseline": None, "per_gpu_value": api_value / world,
         "value_note": "wall time of the drop-in class's get_action, numpy in -> numpy out, warm-start shift between calls (SURVEY.md 8d); "
                       "`device_resident` = the same planner with inputs already in HBM",
-        "device_resident": {"value": s["value"], "unit": "row-steps/s", "device_ms_per_get_action": s["ms_per_get_action"]},
-        "api_overhead_us": (api_ms - s["ms_per_get_action"]) * 1e3,
+        "device_resident": {"value": s["row_steps_per_get_action"] / (dev_ms * 1e-3), "unit": "row-steps/s", "device_ms_per_get_action": dev_ms,
+                            "note": "cadm_cem_plan back to back on HBM-resident inputs, no hipEvent bracketing; the pass that yields the "
+                                    "kernel times (events on) took %.4f ms per get_action" % s["ms_per_get_action"]},
+        "api_overhead_us": (api_ms - dev_ms) * 1e3,
         "dtype": "f32 (each fp32 product as 3 f16 MFMA products of 2-way split operands, fp32 accumulate; error <= 2^-22 per product; "
                  "measured parity: see `parity`)",
-        "data": "synthetic",
+        "data": "dry-run (placeholders: no planner ran)" if args.dry_run else "synthetic",
+        "build_id": build_id,
         "config": {"workload": "%s: %s PE-TS+CaDM get_action, ens=%d part=%d cand=%d (%d/GPU) H=%d m=%d, random-init weights"
                                % (args.config, cfg["env"], cfg["E"], cfg["p"], head.n, head.n_per_gpu, cfg["H"], m),
                    "global_candidates": head.n, "parallelism": "candidate-shard x%d" % world, "collective": head.collective,
@@ -378,9 +497,9 @@ def main():
                                   "products per fp32 product (v_mfma_f32_16x16x32_f16); `achieved` counts the algorithmic fp32 FLOPs of SURVEY 8d",
                      "pipe": "v_mfma_f32_16x16x32_f16", "pipe_peak": F16_MFMA_PEAK_TFLOPS,
                      "pipe_executed": s["executed_f16_mfma_tflops"], "pipe_frac": s["executed_f16_mfma_tflops"] / F16_MFMA_PEAK_TFLOPS,
-                     "mfma_busy": mfma_busy, "traffic": traffic, "pmc_source": pmc_src,
-                     "pmc_note": "mfma_busy (SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of the launch) and traffic (bytes/launch = 2*FETCH_SIZE + "
-                                 "WRITE_SIZE) are read from the committed rocprofv3 --pmc passes of this command, NOT measured in this run",
+                     "mfma_busy": mfma_busy, "traffic": traffic, "pmc_source": pmc_src, "pmc_note": pmc_note,
+                     "traffic_note": "fabric bytes per launch summed over the 8 XCD L2s: each L2 fetches the packed weight stream once (algorithmic: "
+                                     "once per chip, ~3.4 MB incl. actions and returns); ~0.2 TB/s, not what bounds the kernel",
                      "fp32_matrix_peak_for_context": FP32_MFMA_PEAK_TFLOPS,
                      "kernel": "rollout_xdl_kernel", "avg_launch_ms": s["kernel_avg_launch_ms"], "launches": s["launches"],
                      "launch_note": "one 'launch' = one rollout of all rows over the horizon, bracketed by hipEvents inside libcadm_hip.so on "
@@ -401,7 +520,8 @@ def main():
         lsteps = max(5, min(args.steps, 20))
         ls = pl.summary(pl.run_device(lsteps, 2), lsteps)
         out["legs"][name] = {"workload": "%s env=%s m=%d cand=%d (%d/GPU)" % (lcfg, pl.cfg["env"], lm, pl.n, pl.n_per_gpu),
-                             "value": ls["value"], "unit": "row-steps/s", "protocol": "device-resident inputs",
+                             "value": ls["value"], "per_gpu_value": ls["value"] / world, "unit": "row-steps/s",
+                             "protocol": "device-resident inputs",
                              "ms_per_get_action": ls["ms_per_get_action"],
                              "kernel_avg_launch_ms": ls["kernel_avg_launch_ms"], "achieved_tflops": ls["achieved_tflops"],
                              "roofline_frac": ls["achieved_tflops"] / peak_equiv,
@@ -410,11 +530,11 @@ def main():
         pl.close()
 
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(prob_head, n_head, p_head)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             out["parity"] = parity_block()
-        if world == 1 and not args.no_extras:
+        if world == 1 and not args.no_extras and not args.dry_run:
             out["train_step"] = train_step_bench("cuda:%d" % local_rank, lib)
         print(json.dumps(out))
     if dist is not None:

@@ -59,6 +59,7 @@ _u32, _i = C.c_uint32, C.c_int
 SIGNATURES = {
     "cadm_last_error": (C.c_char_p, []),
     "cadm_abi_version": (_i, []),
+    "cadm_build_id": (C.c_char_p, []),
     "cadm_ctx_create": (_i, [C.POINTER(Config), C.POINTER(_P)]),
     "cadm_ctx_destroy": (_i, [_P]),
     "cadm_set_weights": (_i, [_P, _i, _i, _P, _P]),
@@ -108,14 +109,27 @@ _dev_libs = {}
 
 
 def build(verbose=False):
-    """Compile libcadm_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", CSRC, "-j", str(os.cpu_count() or 4)],
+    """Compile libcadm_hip.so (+ the developer library) for gfx950 with hipcc (cross-compiles without a GPU).  Returns
+    {"up_to_date_before": bool, "compiled": [objects hipcc produced in this call], "build_id": str} and prints one line saying
+    so: an incremental `make` on a tree that already holds current objects compiles nothing, and the caller should be able
+    to tell that from a build that exercised the compiler."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    before = subprocess.run(["make", "-C", CSRC, "-q", "HIPCC=" + hipcc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 0
+    r = subprocess.run(["make", "-C", CSRC, "-j", str(os.cpu_count() or 4), "HIPCC=" + hipcc],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or r.returncode != 0:
         print(r.stdout)
     if r.returncode != 0:
         raise CadmError("building libcadm_hip.so failed (see output above)")
-    return LIB_PATH
+    compiled = [ln.split(" -o ")[-1].strip() for ln in r.stdout.splitlines() if " -c " in ln and " -o " in ln]
+    linked = [ln.split(" -o ")[-1].strip() for ln in r.stdout.splitlines() if " -shared " in ln]
+    try:
+        bid = open(os.path.join(CSRC, "build_id.h")).read().split('"')[1]
+    except Exception:
+        bid = "?"
+    print("cadm_amd build: %s; hipcc compiled %d object(s), linked %d librar(ies); build id %s"
+          % ("tree was up to date" if before else "tree was stale", len(compiled), len(linked), bid))
+    return {"up_to_date_before": before, "compiled": compiled, "linked": linked, "build_id": bid}
 
 
 def load():

@@ -91,6 +91,9 @@ typedef struct cadm_config {
 
 const char* cadm_last_error(void);
 int cadm_abi_version(void);
+/* 16 hex digits: sha256 over the kernel sources (csrc/ *.hip, *.h, include/cadm_hip.h) this binary was compiled from.  Profiling
+ * artefacts (profiles/ *pmc*.json) record it, and bench.py only quotes counters whose build id equals the loaded library's. */
+const char* cadm_build_id(void);
 
 /* Build / free the per-model device state (replaces graph construction, dynamics.py:107-342). */
 int cadm_ctx_create(const cadm_config* cfg, cadm_ctx** out);

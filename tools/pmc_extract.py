@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Averages rocprofv3 --pmc counter_collection.csv files over the dispatches of one kernel (name substring).
-usage: tools/pmc_extract.py <dir with pmc_*/> <kernel-substring>  ->  JSON {counter: mean per dispatch, "_dispatches": n}"""
+usage: tools/pmc_extract.py <dir with pmc_*/> <kernel-substring> [build-id]
+  ->  JSON {counter: mean per dispatch, "_dispatches": n, "build_id": cadm_build_id() of the library that was measured}"""
 import csv
 import glob
 import json
@@ -23,6 +24,8 @@ def main():
                 cnt[name] = cnt.get(name, 0) + 1
     out = {k: acc[k] / cnt[k] for k in sorted(acc)}
     out["_dispatches"] = max(cnt.values()) if cnt else 0
+    if len(sys.argv) > 3:
+        out["build_id"] = sys.argv[3]      # bench.py quotes these counters only for the build they were measured on
     # share of SIMD-cycles of a launch in which the matrix pipe was busy: SQ_VALU_MFMA_BUSY_CYCLES is summed over all SIMDs;
     # GRBM_GUI_ACTIVE is the launch's duration in GPU clocks summed over the 8 XCDs (both per dispatch); 4 SIMDs x 256 CUs
     if "SQ_VALU_MFMA_BUSY_CYCLES" in out and out.get("GRBM_GUI_ACTIVE"):

@@ -16,5 +16,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS S
   name=$(echo $grp | tr ' ' '_' | cut -c1-40)
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$name -- $BENCH > /dev/null 2> $OUT/pmc_$name.err
 done
-python $OLDPWD/tools/pmc_extract.py $OUT rollout > $OUT/pmc_rollout.json
+BID=$(cd $OLDPWD && python -c "from cadm_amd import _lib; print(_lib.load().cadm_build_id().decode())")
+python $OLDPWD/tools/pmc_extract.py $OUT rollout $BID > $OUT/pmc_rollout.json
 cat $OUT/pmc_rollout.json
