@@ -174,6 +174,9 @@ int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, 
 int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs,
                         float* out, hipStream_t s);
 void cadm_train_free(cadm_ctx* ctx);
+// (developer library: dev/dev_api.hip) Adam moment buffers of one trained tensor; layer as in cadm_set_weights, is_bias 0 / 1;
+// layer == -1 / -2: max_logvar / min_logvar of the forward net.  Returns null pointers before cadm_train_configure.
+int cadm_train_adam_slot(cadm_ctx* ctx, int net, int layer, int is_bias, float** m, float** v, size_t* n);
 int cadm_dist_allgather(cadm_ctx* ctx, const float* send, float* recv, size_t count, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------

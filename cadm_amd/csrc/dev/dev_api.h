@@ -13,6 +13,11 @@ extern "C" {
 int cadm_dev_set_rollout(cadm_ctx* ctx, int kind, int row_tiles);
 /* device buffer of 8*24 uint64 that the CADM_PHASE_TIMING build (make timing) fills with per-phase s_memtime sums of workgroup 0 */
 int cadm_dev_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf);
+/* Copy one Adam moment buffer (second == 0: first moment m, 1: second moment v) of a trained tensor into dst (device, n_floats =
+ * the tensor's element count [E, in, out] / [E, out] / [D]).  layer as in cadm_set_weights; layer -1 / -2 = max / min_logvar
+ * (CADM_NET_FF).  With beta1 = 0 the first moment after a step IS that step's gradient (m = 0 m + 1 g, exact): the tests read
+ * dL/dW and dL/db element by element this way (tests/test_gpu_train.py) instead of differencing weights. */
+int cadm_dev_read_adam_moment(cadm_ctx* ctx, int net, int layer, int is_bias, int second, float* dst, long n_floats, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -65,3 +65,17 @@ extern "C" int cadm_dev_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf) {
     ctx->tbuf = (unsigned long long*)dev_u64_buf;
     return CADM_OK;
 }
+
+extern "C" int cadm_dev_read_adam_moment(cadm_ctx* ctx, int net, int layer, int is_bias, int second, float* dst, long n_floats,
+                                         void* stream) {
+    CADM_REQUIRE(ctx && dst, "cadm_dev_read_adam_moment: null argument");
+    CADM_ON_DEVICE(ctx);
+    float *m = nullptr, *v = nullptr;
+    size_t n = 0;
+    const int rc = cadm_train_adam_slot(ctx, net, layer, is_bias, &m, &v, &n);
+    CADM_REQUIRE(rc == CADM_OK, "cadm_dev_read_adam_moment: no Adam slot for net %d layer %d (%s) -- cadm_train_configure first", net, layer,
+                 is_bias ? "bias" : "weight");
+    CADM_REQUIRE((long)n == n_floats, "cadm_dev_read_adam_moment: tensor has %zu elements, caller expects %ld", n, n_floats);
+    CADM_CHECK_HIP(hipMemcpyAsync(dst, second ? v : m, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return CADM_OK;
+}

@@ -1305,6 +1305,24 @@ static int alloc_adam(cadm_ctx* ctx) {
     return CADM_OK;
 }
 
+int cadm_train_adam_slot(cadm_ctx* ctx, int net, int layer, int is_bias, float** m, float** v, size_t* n) {
+    *m = *v = nullptr; *n = 0;
+    TrainState* t = ctx->train;
+    if (!t || !t->adam_buf) return CADM_ESTATE;
+    const AdamSlot* s = nullptr;
+    if (layer < 0) {
+        if (net != CADM_NET_FF || layer < -2) return CADM_EINVAL;
+        s = layer == -1 ? &t->a_mx : &t->a_mn;
+    } else {
+        const std::vector<AdamSlot>& v_ = net == CADM_NET_FF ? t->a_ff : net == CADM_NET_BACK ? t->a_bk : t->a_cp;
+        const size_t i = 2 * (size_t)layer + (is_bias ? 1 : 0);
+        if (i >= v_.size()) return CADM_EINVAL;
+        s = &v_[i];
+    }
+    *m = s->m; *v = s->v; *n = s->n;
+    return CADM_OK;
+}
+
 static inline int kblocks(int k) { return (k + 15) >> 4; }
 static inline int even_tiles(int n) { return 2 * ((((n + 15) >> 4) + 1) / 2); }
 

@@ -510,6 +510,27 @@ class HipEngine:
         self._check(self.lib.cadm_dev_set_rollout(self._ctx, {"xdl": _lib.DEV_ROLLOUT_XDL, "f32": _lib.DEV_ROLLOUT_F32}[kind],
                                                   int(row_tiles)), "cadm_dev_set_rollout")
 
+    def dev_read_adam_moment(self, net, name, second=False):
+        """Adam's first (second=False) / second moment of one trained tensor, shaped like the tensor.  With beta1 = 0 the first
+        moment after ONE training step is that step's gradient exactly (m = 0 m + 1 g): how the tests read dL/dW, dL/db element
+        by element.  Developer library only."""
+        if not hasattr(self.lib, "cadm_dev_read_adam_moment"):
+            raise _lib.CadmError("dev_read_adam_moment needs the developer library (HipEngine(..., lib=_lib.load_dev()))")
+        nid = {"ff_model": _lib.NET_FF, "backward_model": _lib.NET_BACK, "context_model": _lib.NET_CTX}[net]
+        if name in ("max_logvar", "min_logvar"):
+            layer, is_bias = (-1 if name == "max_logvar" else -2), 0
+        else:
+            base, kind = name.rsplit("_", 1)
+            if net == "context_model":
+                layers = ["cp_hidden_%d" % i for i in range(len(self.cp_hidden_sizes))] + ["cp_output"]
+            else:
+                layers = ["hidden_%d" % i for i in range(self.NH)] + ["output_mu", "output_logvar"]
+            layer, is_bias = layers.index(base), int(kind == "bias")
+        out = torch.empty_like(self.nets[net][name])
+        self._check(self.lib.cadm_dev_read_adam_moment(self._ctx, nid, layer, is_bias, int(second), ptr(out), out.numel(), self.stream),
+                    "cadm_dev_read_adam_moment")
+        return out
+
     def profile_read_collective(self):
         """-> (total milliseconds, calls) of the in-library ncclAllGather since the last read (sharded planner)."""
         ms, cnt = ct.c_float(0.0), ct.c_int(0)

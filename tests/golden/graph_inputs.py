@@ -9,6 +9,13 @@ CASES = {   # name: dict(env, E, p, m, n, H, hidden, cp_hidden, C, Hh, seed)
                        C=10, Hh=3, B=2, seed=101),
     "hc_cadm_m3": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=5, m=3, n=52, H=4, hidden=(128,) * 4, cp_hidden=(16, 8),
                        C=10, Hh=2, B=2, seed=202),
+    # BASELINE.json configs[1] at FULL geometry -- the shape bench.py times (run_scripts/run_cadm_pets.py:118-140,201 defaults:
+    # hidden 200 x 4, context encoder 256/128/64 -> 10, history 10, 20 particles, 200 candidates, horizon 30) -- and its twin at the
+    # production launch shape m = 10 (10 envs planned for in one call; odd CEM iterations then take quirk Q2's scrambled context)
+    "hc_cadm_cfg2": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=20, m=1, n=200, H=30, hidden=(200,) * 4, cp_hidden=(256, 128, 64),
+                         C=10, Hh=10, B=2, seed=2201),
+    "hc_cadm_cfg2_m10": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=20, m=10, n=200, H=30, hidden=(200,) * 4,
+                             cp_hidden=(256, 128, 64), C=10, Hh=10, B=2, seed=2210),
     # random shooting (core/utils.py:490-561): the planner branch taken when no CEM initial distribution is fed
     # the vanilla PE-TS twin (create_plus_ensemble_cem_mlp, core/utils.py:5-248): no context encoder
     "hc_vanilla_m2": dict(env="halfcheetah", D=18, A=6, P=18, E=5, p=10, m=2, n=54, H=3, hidden=(128,) * 4, cp_hidden=(), C=0, Hh=2,

@@ -69,9 +69,14 @@ def build_tf(weights, draws):
             ex = np.exp(x)
         return np.where(x > -thr, x, np.where(x < thr, ex, np.log1p(ex))).astype(x.dtype)
 
+    topk_log = []          # (input, indices) of every tf.nn.top_k the graph builder calls: the candidate returns and elite sets
+
     def top_k(x, k, sorted=True):      # descending, ties -> lower index first
         idx = np.argsort(-_a(x), axis=-1, kind="stable")[..., :k]
+        topk_log.append((np.array(x, np.float32), idx.astype(np.int32)))
         return np.take_along_axis(_a(x), idx, axis=-1), idx.astype(np.int32)
+
+    tf._topk_log = topk_log
 
     tf.nn = types.SimpleNamespace(softplus=softplus, top_k=top_k, relu=lambda x: np.maximum(x, F32(0)),
                                   l2_loss=lambda w: np.sum(np.square(w), dtype=np.float32) / F32(2), softmax=None)
@@ -193,7 +198,8 @@ def run_case(case):
                 cem_init_mean_var=inp["init_mean"], cem_init_var_var=inp["init_var"], obs_preproc_fn=pre, obs_postproc_fn=post,
                 deterministic=False)
         (_, _, output_var, optimal_action, mu, logvar, max_lv, min_lv, l2_regs) = out
-        return {case + "/plan": np.asarray(optimal_action, np.float32), case + "/train_mu": np.asarray(mu, np.float32),
+        return {case + "/cand_returns": np.stack([x for x, _ in tf._topk_log]), case + "/elites": np.stack([i for _, i in tf._topk_log]),
+                case + "/plan": np.asarray(optimal_action, np.float32), case + "/train_mu": np.asarray(mu, np.float32),
                 case + "/train_logvar": np.asarray(logvar, np.float32), case + "/train_output": np.asarray(output_var, np.float32),
                 case + "/var_names": np.array([n for n, _ in weights.vars]),
                 case + "/var_shapes": np.array([",".join(map(str, v.shape)) for _, v in weights.vars]),
@@ -227,6 +233,9 @@ def run_case(case):
            case + "/var_shapes": np.array([",".join(map(str, v.shape)) for _, v in weights.vars]),
            case + "/draw_kinds": np.array([k for k, _ in draws.log]),
            case + "/draw_shapes": np.array([",".join(map(str, z.shape)) for _, z in draws.log])}
+    if tf._topk_log:         # CEM: per iteration the [m, n] particle-mean returns the graph ranked and the 50 indices it kept
+        res[case + "/cand_returns"] = np.stack([x for x, _ in tf._topk_log])
+        res[case + "/elites"] = np.stack([i for _, i in tf._topk_log])
     return res
 
 

@@ -45,16 +45,17 @@ def oracle_rollout(prob, dt, actions, eps, p, det, obs_rows=None, it=0, **kw):
                                     prob["E"], p, det, obs_rows=None if obs_rows is None else obs_rows.astype(dt), return_traj=True, **kw)
 
 
-def measure(engines, cfgname="cfg2", seed=77, H=30, n_traj=24):
+def measure(engines, cfgname="cfg2", seed=77, H=30, n_traj=24, hidden=200, n=None):
     """engines: dict name -> HipEngine factory(prob, p, H, det).  Returns {kernel name: {...}, "fp32_oracle": {...}}:
       one_step_*   every row of the FULL configuration advanced one teacher-forced step from its own random state
       traj_*       `n_traj` candidates x all particles over the whole horizon (next observation after every step)"""
     cfg = synth.CONFIGS[cfgname]
-    E, p, n, det = cfg["E"], cfg["p"], cfg["n"], cfg["deterministic"]
+    E, p, n, det = cfg["E"], cfg["p"], n or cfg["n"], cfg["deterministic"]
+    hs = (hidden,) * 4
     rng = np.random.default_rng(seed)
     out = {}
     # ---- one step, full size
-    prob1 = synth.make_problem(env=cfg["env"], context=cfg["context"], E=E, m=1, H=1, trained_like=True, seed=seed)
+    prob1 = synth.make_problem(env=cfg["env"], context=cfg["context"], E=E, m=1, H=1, trained_like=True, seed=seed, hidden_sizes=hs)
     D, A = prob1["D"], prob1["A"]
     obs_rows = rng.standard_normal((1, n, p, D))
     act1 = rng.uniform(-1, 1, (1, n, 1, A))
@@ -72,7 +73,7 @@ def measure(engines, cfgname="cfg2", seed=77, H=30, n_traj=24):
                      "one_step_obs_vs_fp32_oracle": err_stats(got1[name][1], t32)}
         eng.close()
     # ---- whole horizon, a slice of candidates
-    probH = synth.make_problem(env=cfg["env"], context=cfg["context"], E=E, m=1, H=H, trained_like=True, seed=seed + 1)
+    probH = synth.make_problem(env=cfg["env"], context=cfg["context"], E=E, m=1, H=H, trained_like=True, seed=seed + 1, hidden_sizes=hs)
     actH = rng.uniform(-1, 1, (1, n_traj, H, A))
     epsH = None if det else rng.standard_normal((H, 1, n_traj, p, D))
     R64, T64 = oracle_rollout(probH, np.float64, actH, epsH, p, det)
@@ -85,7 +86,7 @@ def measure(engines, cfgname="cfg2", seed=77, H=30, n_traj=24):
         rows, traj = rows.cpu().numpy(), traj.cpu().numpy()
         out[name].update({"traj_obs": err_stats(traj, T64), "traj_last_obs": err_stats(traj[-1], T64[-1]), "returns": err_stats(rows, R64)})
         eng.close()
-    out["_meta"] = dict(config=cfgname, env=cfg["env"], E=E, p=p, n=n, H=H, rows_one_step=n * p, traj_candidates=n_traj,
+    out["_meta"] = dict(config=cfgname, env=cfg["env"], E=E, p=p, n=n, H=H, hidden=hidden, rows_one_step=n * p, traj_candidates=n_traj,
                         weights="trained-like (synth.make_problem(trained_like=True))", seed=seed)
     return out
 
@@ -103,9 +104,9 @@ def f32_engine(prob, p, H, det):
 
 def markdown(res):
     m = res["_meta"]
-    lines = ["# Split-f16 rollout kernel: measured precision (round 3)", "",
-             "`%s` full size (%s, ens=%d part=%d cand=%d), %s.  Errors against the **fp64 numpy oracle** on identical inputs;"
-             % (m["config"], m["env"], m["E"], m["p"], m["n"], m["weights"]),
+    lines = ["# Split-f16 rollout kernel: measured precision -- %s, hidden %d" % (m["config"], m.get("hidden", 200)), "",
+             "`%s` full size (%s, ens=%d part=%d cand=%d, hidden 4 x %d), %s.  Errors against the **fp64 numpy oracle** on identical inputs;"
+             % (m["config"], m["env"], m["E"], m["p"], m["n"], m.get("hidden", 200), m["weights"]),
              "`xdl` = production kernel (3 f16 MFMA products of split operands, fp32 accumulate), `f32mfma` = the developer library's",
              "fp32-operand MFMA kernel, `fp32 oracle` = numpy float32 restatement.  one-step: %d rows, each from its own random state;"
              % m["rows_one_step"],

@@ -51,6 +51,28 @@ def test_trajectory_drift_in_the_fp32_band(measured):
     assert x["traj_obs"]["max_rel"] <= max(4 * o["traj_obs"]["max_rel"], 2e-6), (x["traj_obs"], o["traj_obs"])
 
 
+# Beyond HID 200.  The kernel evaluates a product with 3 f16 MFMA products for hidden widths <= 256 and with 4
+# above (xdl_geo.h); 256 is therefore the widest net on 3 products -- the most dropped w2 x2 terms per accumulator -- and
+# slim_humanoid (K0 = 72, D = 45: BASELINE cfg4) the widest input / head.  Same bars as cfg2: one-step PURE relative 1e-5 on
+# every element with |ref| >= 0.25 rms, against fp64 truth and against the fp32 oracle, and <= 2 x the fp32-operand MFMA
+# kernel's (or the fp32 oracle's own) error on every row of the table.
+@pytest.mark.parametrize("cfgname,hidden,n", [("cfg2", 256, None), ("cfg4", 200, None), ("cfg4", 256, 200)])
+def test_precision_beyond_hid200(gpu, cfgname, hidden, n):
+    res = precision.measure({"xdl": precision.product_engine, "f32mfma": precision.f32_engine}, cfgname=cfgname, hidden=hidden, n=n,
+                            n_traj=12)
+    print("\n" + precision.markdown(res))
+    x, f, o = res["xdl"], res["f32mfma"], res["fp32_oracle"]
+    assert x["one_step_obs"]["n_big"] >= 0.5 * x["one_step_obs"]["n"]
+    assert x["one_step_obs"]["pure_rel_big"] <= 1e-5, x["one_step_obs"]
+    assert x["one_step_obs_vs_fp32_oracle"]["pure_rel_big"] <= 1e-5, x["one_step_obs_vs_fp32_oracle"]
+    assert x["one_step_obs"]["max_rel"] <= 2e-6, x["one_step_obs"]
+    for q in ("one_step_obs", "one_step_reward", "traj_obs", "traj_last_obs", "returns"):
+        for met in ("max_rel", "max_over_rms"):
+            bound = 2.0 * max(f[q][met], o[q][met])
+            assert x[q][met] <= bound, "%s %s: xdl %.2e > 2 x max(f32mfma %.2e, fp32 oracle %.2e)" % (q, met, x[q][met], f[q][met], o[q][met])
+    assert x["traj_obs"]["max_rel"] <= max(4 * o["traj_obs"]["max_rel"], 2e-6), (x["traj_obs"], o["traj_obs"])
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # (iii) edges of the f16 range -- the kernel's DOCUMENTED behaviour (DESIGN.md numerics notes):
 #   * network inputs are clamped to +-65000 and hidden pre-activations to <= 60000 (the f16 operands of the matrix pipe

@@ -58,15 +58,49 @@ def test_losses_match_oracle(gpu, env, context, with_back, det, E, B):
         np.testing.assert_allclose(got, want, rtol=tol, atol=tol, err_msg="losses vs %s oracle" % dt)
 
 
+def _dev_engine(prob, p, **kw):
+    """An engine on the DEVELOPER library: the product's objects plus the hook that reads Adam's moment buffers."""
+    from cadm_amd import _lib
+    return make_engine(prob, p=p, lib=_lib.load_dev(), **kw)
+
+
+def _grad_report(g_hip, g_ref):
+    """(max |d| / max |ref|,  max elementwise |d| / |ref| over |ref| >= 0.25 rms(ref))"""
+    scale = max(np.abs(g_ref).max(), 1e-300)
+    d = np.abs(g_hip - g_ref)
+    big = np.abs(g_ref) >= 0.25 * np.sqrt(np.mean(g_ref ** 2))
+    return d.max() / scale, (d[big] / np.abs(g_ref[big])).max() if big.any() else 0.0
+
+
+def _check_gradients(eng, grads, what):
+    """Every gradient tensor the fused step produced, read back DIRECTLY (Adam's first moment after one step with beta1 = 0 is
+    the gradient, exactly: m = 0 m + 1 g) and compared element by element with torch.autograd on the fp64 oracle:
+    <= 1e-5 of the tensor's max, and <= 1e-4 PURE relative on every element with |g| >= 0.25 rms (fp32 forward / backward over a
+    256-row batch: roundoff-scale bars; a sign or scale error in any slice of any tensor fails them)."""
+    checked, worst = 0, (0.0, 0.0, "")
+    for net in eng.net_names():
+        for name in eng.nets[net]:
+            g_ref = grads[net][name]
+            if g_ref is None:      # TF skips variables without a gradient (backward model's logvar head, dynamics.py:213-240)
+                continue
+            g_hip = eng.dev_read_adam_moment(net, name).cpu().numpy().astype(np.float64)
+            assert np.isfinite(g_hip).all()
+            to_max, pure = _grad_report(g_hip, g_ref.numpy())
+            assert to_max <= 1e-5, "%s %s/%s gradient: max err %.2e of the tensor's max" % (what, net, name, to_max)
+            assert pure <= 1e-4, "%s %s/%s gradient: pure relative err %.2e on |g| >= 0.25 rms" % (what, net, name, pure)
+            if to_max > worst[0]:
+                worst = (to_max, pure, "%s/%s" % (net, name))
+            checked += 1
+    print("%s: %d gradient tensors, worst %.2e of max (pure-relative %.2e) at %s" % ((what, checked) + worst))
+    return checked
+
+
 @pytest.mark.parametrize("env,context,with_back,det,E,B", CASES)
-def test_gradients_via_linearised_adam(gpu, env, context, with_back, det, E, B):
-    """With beta1 = beta2 = 0, lr = eps = 1e6 the TF1 Adam update is  w -= g / (|g|/1e6 + 1) ~= g, so
-    one fused step exposes every gradient of the hand-written backward pass as (w_before - w_after).
-    Compared against torch.autograd on the fp64 oracle."""
+def test_gradients_elementwise_vs_fp64_autograd(gpu, env, context, with_back, det, E, B):
     prob = synth.make_problem(env=env, context=context, E=E, trained_like=True, with_back=with_back, seed=22)
-    eng = make_engine(prob, p=E, deterministic=det)
+    eng = _dev_engine(prob, E, deterministic=det)
     bc = 0.5 if with_back else 0.0
-    eng.train_configure(1e6, WD, CWD, 1.0, bc, max_batch=B, beta1=0.0, beta2=0.0, epsilon=1e6)
+    eng.train_configure(1e-3, WD, CWD, 1.0, bc, max_batch=B, beta1=0.0)
     batch = synth.make_train_batch(prob, B=B, seed=3)
     before = {n: {k: v.clone() for k, v in eng.nets[n].items()} for n in eng.net_names()}
     eng.train_step(_dev_batch(eng, batch, context, with_back), train=True)
@@ -74,53 +108,65 @@ def test_gradients_via_linearised_adam(gpu, env, context, with_back, det, E, B):
     tb = {k: torch.tensor(v, dtype=torch.float64) for k, v in batch.items()}
     out = otrain.train_losses(env, ff, back, cp, st, tb, _cfg(prob, det, bc))
     grads = otrain.grads_of(out["loss"], {"ff_model": ff, "backward_model": back, "context_model": cp})
-    checked = 0
-    for net in eng.net_names():
+    assert _check_gradients(eng, grads, "%s E=%d B=%d" % (env, E, B)) >= 8
+    for net in eng.net_names():       # variables without a gradient must not move (TF's minimize skips them)
         for name, w0 in before[net].items():
-            g_ref = grads[net][name]
-            g_hip = (w0 - eng.nets[net][name]).cpu().numpy().astype(np.float64)
-            if g_ref is None:      # TF skips variables without a gradient: they must not move
-                assert np.abs(g_hip).max() == 0.0, "%s/%s moved although it has no gradient" % (net, name)
-                continue
-            g_ref = g_ref.numpy()
-            scale = max(np.abs(g_ref).max(), 1e-12)
-            # fp32 forward/backward + recovering g from a difference of O(0.1) weights: 2e-3 of the tensor's scale
-            err = np.abs(g_hip - g_ref).max() / scale
-            assert err < 2e-3, "%s/%s gradient off: rel-to-max err %.3e (max |g| %.3e)" % (net, name, err, scale)
-            checked += 1
-    assert checked >= 10
+            if grads[net][name] is None:
+                assert torch.equal(w0, eng.nets[net][name]), "%s/%s moved although it has no gradient" % (net, name)
 
 
-def test_adam_trajectory_matches_tf1_semantics(gpu):
-    """10 real Adam steps on a fixed batch: losses and parameters track the fp32 oracle
-    (torch autograd + TF1 Adam closed form)."""
-    env, E, B = "halfcheetah", 5, 128
+def test_adam_steps_match_tf1_semantics_elementwise(gpu):
+    """6 real Adam steps (lr 1e-3, beta 0.9 / 0.999, eps 1e-8).  Before every step the oracle is set to the device's state -- weights
+    and both moment buffers, read through the developer hook -- takes the fp64 autograd gradient there and applies the TF1 closed
+    form (ApplyAdam: lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); w -= lr_t m / (sqrt(v) + eps)); the device's step must land on the same
+    weights element by element: |dw - dw_ref| <= 2e-3 lr wherever the update is well conditioned.  Adam's update m / sqrt(v) is a
+    SIGN-like function of the gradient history: for an element whose gradients are themselves at roundoff level (|g| < 1e-3 rms of
+    its tensor) it amplifies fp32 roundoff to O(lr), in TF as much as here; those elements (counted, bounded) are only required
+    to move by at most lr_t-scale, like every other."""
+    env, E, B, lr = "halfcheetah", 5, 128, 1e-3
     prob = synth.make_problem(env=env, context=True, E=E, trained_like=True, with_back=True, seed=30)
-    eng = make_engine(prob, p=E)
-    eng.train_configure(1e-3, WD, CWD, 1.0, 0.5, max_batch=B)
+    eng = _dev_engine(prob, E)
+    eng.train_configure(lr, WD, CWD, 1.0, 0.5, max_batch=B)
     batch = synth.make_train_batch(prob, B=B, seed=4)
     dev = _dev_batch(eng, batch, True, True)
-    ff, back, cp, st = _oracle_nets(prob, torch.float64)
     tb = {k: torch.tensor(v, dtype=torch.float64) for k, v in batch.items()}
-    nets = {"ff_model": ff, "backward_model": back, "context_model": cp}
-    opt = otrain.TF1Adam(1e-3)
-    hip_losses, ref_losses = [], []
-    for step in range(10):
-        hip_losses.append(eng.train_step(dev, train=True).cpu().numpy())
-        out = otrain.train_losses(env, ff, back, cp, st, tb, _cfg(prob, False, 0.5))
-        ref_losses.append([float(out["mse"]), float(out["back_mse"]), float(out["recon"])])
-        opt.step(nets, otrain.grads_of(out["loss"], nets))
-    hip_losses, ref_losses = np.array(hip_losses), np.array(ref_losses)
-    assert ref_losses[-1, 2] < ref_losses[0, 2], "oracle loss did not decrease"
-    np.testing.assert_allclose(hip_losses, ref_losses, rtol=2e-3, atol=2e-3)
-    for net in eng.net_names():
-        for name, w in eng.nets[net].items():
-            ref = nets[net][name].detach().numpy()
-            moved = np.abs(ref - prob[{"ff_model": "ff", "backward_model": "back", "context_model": "cp"}[net]][name]).max()
-            if moved == 0:
-                continue
-            # Adam's first steps are +-lr per element; a sign flip of a ~0 gradient costs at most ~2 lr per step
-            assert np.abs(w.cpu().numpy() - ref).max() <= 0.15 * moved + 2e-4, "%s/%s diverged from TF1 Adam" % (net, name)
+    st = otrain.to_torch(prob["stats"], torch.float64)
+    names = {"ff_model": "ff", "backward_model": "back", "context_model": "cp"}
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    losses, excluded, total = [], 0, 0
+    for step in range(1, 7):
+        state = {n: {k: (v.cpu().numpy().astype(np.float64), eng.dev_read_adam_moment(n, k).cpu().numpy().astype(np.float64),
+                         eng.dev_read_adam_moment(n, k, second=True).cpu().numpy().astype(np.float64)) for k, v in eng.nets[n].items()}
+                 for n in eng.net_names()}
+        nets = {n: otrain.to_torch({k: w for k, (w, _, _) in state[n].items()}, torch.float64, True) for n in eng.net_names()}
+        out = otrain.train_losses(env, nets["ff_model"], nets["backward_model"], nets["context_model"], st, tb, _cfg(prob, False, 0.5))
+        grads = otrain.grads_of(out["loss"], nets)
+        got = eng.train_step(dev, train=True).cpu().numpy()
+        losses.append(got)
+        np.testing.assert_allclose(got, [float(out["mse"]), float(out["back_mse"]), float(out["recon"])], rtol=5e-5, atol=5e-5)
+        lr_t = lr * np.sqrt(1.0 - b2 ** step) / (1.0 - b1 ** step)
+        for n in eng.net_names():
+            for k, (w0, m0, v0) in state[n].items():
+                w1 = eng.nets[n][k].cpu().numpy().astype(np.float64)
+                if grads[n][k] is None:
+                    assert np.array_equal(w1, w0), "%s/%s moved although it has no gradient" % (n, k)
+                    continue
+                g = grads[n][k].numpy()
+                m1, v1 = b1 * m0 + (1 - b1) * g, b2 * v0 + (1 - b2) * g * g
+                dw_ref = -lr_t * m1 / (np.sqrt(v1) + eps)
+                dw = w1 - w0
+                assert np.abs(dw).max() <= 1.001 * lr_t * max(1.0, np.abs(m1 / (np.sqrt(v1) + eps)).max()) + np.abs(w0).max() * 2.0 ** -22 + 1e-7     # no element runs away
+                ok = np.abs(g) >= 1e-3 * np.sqrt(np.mean(g ** 2))
+                excluded += int((~ok).sum())
+                total += g.size
+                # fp32 weights of magnitude |w| resolve a step to ulp(w) / 2: part of the bar
+                bar = 2e-3 * lr + np.abs(w0[ok]) * 2.0 ** -23
+                err = np.abs(dw[ok] - dw_ref[ok])
+                assert (err <= bar).all(), "step %d %s/%s: update off by %.3e (= %.2e lr) at the worst element" % (
+                    step, n, k, err.max(), err.max() / lr)
+    assert losses[-1][2] < losses[0][2], "training loss did not decrease"
+    assert excluded <= 0.01 * total, "%d of %d elements excluded as ill-conditioned" % (excluded, total)
+    print("adam: %d steps, %d of %d element-updates excluded (|g| < 1e-3 rms)" % (6, excluded, total))
 
 
 def test_train_then_plan_uses_updated_weights(gpu):
@@ -212,25 +258,14 @@ def test_chain_kernel_shapes(gpu, env, E, B, hid, cph):
     ref = otrain.train_losses(env, ff, back, cp, st, tb, cfg)
     want = np.array([float(ref["mse"]), float(ref["back_mse"]), float(ref["recon"])])
     np.testing.assert_allclose(got, want, rtol=5e-5, atol=5e-5)
-    # gradients through the linearised Adam step (see test_gradients_via_linearised_adam)
-    eng = make_engine(prob, p=E)
-    eng.train_configure(1e6, wd, cwd, 1.0, 0.5, max_batch=B, beta1=0.0, beta2=0.0, epsilon=1e6)
-    before = {n: {k: v.clone() for k, v in eng.nets[n].items()} for n in eng.net_names()}
+    # gradients, read back directly (see test_gradients_elementwise_vs_fp64_autograd)
+    eng = _dev_engine(prob, E)
+    eng.train_configure(1e-3, wd, cwd, 1.0, 0.5, max_batch=B, beta1=0.0)
     eng.train_step(_dev_batch(eng, batch, True, True), train=True)
     ff, back, cp, st = _oracle_nets(prob, torch.float64)
     out = otrain.train_losses(env, ff, back, cp, st, tb, cfg)
     grads = otrain.grads_of(out["loss"], {"ff_model": ff, "backward_model": back, "context_model": cp})
-    for net in eng.net_names():
-        for name, w0 in before[net].items():
-            g_ref = grads[net][name]
-            g_hip = (w0 - eng.nets[net][name]).cpu().numpy().astype(np.float64)
-            if g_ref is None:
-                assert np.abs(g_hip).max() == 0.0, "%s/%s moved although it has no gradient" % (net, name)
-                continue
-            g_ref = g_ref.numpy()
-            scale = max(np.abs(g_ref).max(), 1e-12)
-            err = np.abs(g_hip - g_ref).max() / scale
-            assert err < 2e-3, "%s/%s gradient off: rel-to-max err %.3e (max |g| %.3e)" % (net, name, err, scale)
+    _check_gradients(eng, grads, "%s E=%d B=%d hid=%s" % (env, E, B, hid))
 
 
 def test_first_adam_step_moves_every_trained_parameter_by_lr(gpu):

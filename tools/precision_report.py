@@ -12,13 +12,15 @@ import precision
 
 
 def main():
-    res = precision.measure({"xdl": precision.product_engine, "f32mfma": precision.f32_engine})
-    md = precision.markdown(res)
+    eng = {"xdl": precision.product_engine, "f32mfma": precision.f32_engine}
+    runs = [precision.measure(eng), precision.measure(eng, cfgname="cfg2", hidden=256, n_traj=12),
+            precision.measure(eng, cfgname="cfg4", hidden=200, n_traj=12), precision.measure(eng, cfgname="cfg4", hidden=256, n=200, n_traj=12)]
+    md = "\n".join(precision.markdown(r) for r in runs)
     print(md)
     if len(sys.argv) > 1:
         open(sys.argv[1], "w").write(md)
     if len(sys.argv) > 2:
-        json.dump(res, open(sys.argv[2], "w"), indent=1)
+        json.dump(runs, open(sys.argv[2], "w"), indent=1)
 
 
 if __name__ == "__main__":
