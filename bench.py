@@ -163,6 +163,33 @@ def train_step_bench(device, lib=None, steps=100, warmup=10, B=256):
             "workload": "halfcheetah CaDM ensemble + backward model, fwd/bwd/TF1-Adam, fp32"}
 
 
+def context_bench(device, lib=None, m=2048, steps=50, warmup=5):
+    """batched context inference -- `get_context_pred` on m histories per call (the PPO consumer's scale,
+    ppo_cadm.py:155-162) through `context_batched_kernel` (fp32 MFMA; weights reused across the rows of a member).  A row =
+    one (member, history) pair through the 240-256-128-64-10 encoder: 2 x 103 040 FLOP."""
+    from cadm_amd import synth
+    prob = synth.make_problem(env="halfcheetah", context=True, E=5, seed=0)
+    eng = synth.make_engine(prob, p=5, device=device, lib=lib)
+    rng = np.random.default_rng(1)
+    cp_obs = eng._t(0.1 * rng.standard_normal((m, prob["D"] * prob["Hh"])))
+    cp_act = eng._t(rng.uniform(-1, 1, (m, prob["A"] * prob["Hh"])))
+    for _ in range(warmup + 200):            # (+ clock ramp)
+        out = eng.context_forward(cp_obs, cp_act)
+    torch.cuda.synchronize(eng.device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = eng.context_forward(cp_obs, cp_act)
+    torch.cuda.synchronize(eng.device)
+    dt = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(out).all()
+    rows = 5 * m
+    flops = rows * 2 * (240 * 256 + 256 * 128 + 128 * 64 + 64 * 10)
+    eng.close()
+    return {"context_rows_per_s": rows / dt, "ms_per_call": dt * 1e3, "histories_per_call": m, "members": 5, "tflops": flops / dt / 1e12,
+            "frac_of_fp32_matrix_peak": flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "workload": "get_context_pred-shaped: %d histories x 5 members, encoder 240-256-128-64-10, fp32 (v_mfma_f32_16x16x4_f32)" % m}
+
+
 def self_launch(n_gpus, argv):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: run the N ranks ourselves, one process per GPU, as the
     driver's own multi-GPU form does (torch.distributed.run, rendezvous on 127.0.0.1).  Rank 0's JSON line passes through on
@@ -536,6 +563,7 @@ def main():
             out["parity"] = parity_block()
         if world == 1 and not args.no_extras and not args.dry_run:
             out["train_step"] = train_step_bench("cuda:%d" % local_rank, lib)
+            out["context_batched"] = context_bench("cuda:%d" % local_rank, lib)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -27,7 +27,7 @@ void cadm_set_error(const char* fmt, ...);
 #define CADM_HID_LIST 200              // the reference default --hidden_size (run_cadm_pets.py:129)
 #endif
 // bumped whenever cadm_ctx / RolloutArgs change: a side module built against another layout is refused
-#define CADM_CTX_LAYOUT_TAG 3001
+#define CADM_CTX_LAYOUT_TAG 3002
 
 #define CADM_CHECK_HIP(expr)                                                                   \
     do {                                                                                       \
@@ -130,6 +130,7 @@ struct cadm_ctx {
     size_t wstream_member_floats = 0, bstream_member_floats = 0;
     int n_cus = 256;
     std::unordered_set<const void*> attr_done;   // kernels whose dynamic-LDS attribute is set on THIS ctx's device
+    size_t chain_attr_lds = 0;      // training chain kernel: the dynamic-LDS size its attribute was last raised to on this ctx's device
     NormStats st;
     TrainState* train = nullptr;
     // scratch for the context encoder
@@ -170,7 +171,7 @@ int cadm_pack_xdl(cadm_ctx* ctx, hipStream_t s);
 int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, const float* ctx_vec,
                         const float* actions, const float* eps, int norm_actions, uint32_t seed,
                         uint32_t call, int it, int cand_offset, int n_global, int m, int n_local,
-                        float* returns_rows, float* traj_out, hipStream_t s, int dry_run = 0);
+                        float* returns_rows, float* traj_out, hipStream_t s, int dry_run = 0, int force_deterministic = -1);
 int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs,
                         float* out, hipStream_t s);
 void cadm_train_free(cadm_ctx* ctx);

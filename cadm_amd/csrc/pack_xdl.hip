@@ -61,13 +61,13 @@ __global__ void pack_xdl_kernel(const XdlPackArgs a) {
         // input feature of (chunk c, lane group grp, element i)
         int kin;
         if (layer == 0) { kin = 32 * c + 8 * grp + i; if (kin >= g.K0) kin = -1; }
-        else { kin = (2 * c + (i >> 2)) * 16 + 4 * grp + (i & 3); if (kin >= g.HID) kin = -1; }
-        const int K = layer == 0 ? g.K0 : g.HID;
+        else { kin = (2 * c + (i >> 2)) * 16 + 4 * grp + (i & 3); if (kin >= g.HIDR) kin = -1; }
+        const int K = layer == 0 ? g.K0 : g.HIDR;     // (master weights: the MODEL's width; units HIDR .. HID - 1 are zero padding)
         float v = 0.0f;
         if (kin >= 0 && tile >= 0) {
             if (layer < g.NH) {
                 const int u = 16 * tile + m;
-                if (u < g.HID) v = a.W[layer][((size_t)e * K + kin) * g.HID + u];
+                if (u < g.HIDR) v = a.W[layer][((size_t)e * K + kin) * g.HIDR + u];
             } else {
                 const int q = m >> 2, r = m & 3;
                 const int d = 8 * tile + 2 * q + (r & 1);
@@ -97,7 +97,7 @@ __global__ void pack_xdl_bias_kernel(const XdlPackArgs a) {
             const int layer = tile / g.NT;
             tile %= g.NT;
             const int u = 16 * tile + 4 * grp + r;
-            if (u < g.HID) v = a.b[layer][(size_t)e * g.HID + u];
+            if (u < g.HIDR) v = a.b[layer][(size_t)e * g.HIDR + u];
         } else {
             tile -= g.NH * g.NT;
             const int d = 8 * tile + 2 * grp + (r & 1);

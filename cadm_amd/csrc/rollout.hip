@@ -11,7 +11,7 @@ int cadm_rollout_env_pendulum(cadm_ctx*, const RolloutArgs&, int, hipStream_t);
 int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, const float* ctx_vec,
                         const float* actions, const float* eps, int norm_actions, uint32_t seed,
                         uint32_t call, int it, int cand_offset, int n_global, int m, int n_local,
-                        float* returns_rows, float* traj_out, hipStream_t s, int dry_run) {
+                        float* returns_rows, float* traj_out, hipStream_t s, int dry_run, int force_deterministic) {
     RolloutArgs a{};
     const size_t xbytes = (size_t)ctx->xg.member_frags() * CADM_XDL_FRAG_BYTES * ctx->E;
     if (xbytes >= (1ull << 31)) {
@@ -32,7 +32,7 @@ int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, 
     a.returns_rows = returns_rows; a.traj = traj_out;
     a.m = m; a.n_local = n_local; a.n_global = n_global; a.cand_offset = cand_offset;
     a.E = ctx->E; a.p = ctx->p; a.PE = ctx->p / ctx->E; a.H = ctx->H; a.NH = ctx->NH;
-    a.it = it; a.quirks = ctx->cfg.reference_quirks; a.deterministic = ctx->cfg.deterministic;
+    a.it = it; a.quirks = ctx->cfg.reference_quirks; a.deterministic = force_deterministic >= 0 ? force_deterministic : ctx->cfg.deterministic;   // (>= 0: cadm_rollout_check asks about a mode)
     a.norm_actions = norm_actions; a.seed = seed; a.call = call;
     a.tbuf = ctx->tbuf;
     const long long rows_total = (long long)m * n_global * ctx->p;
@@ -62,7 +62,7 @@ int cadm_rollout_builtin_env(cadm_ctx* ctx) {
     static const int ctxs[] = {CADM_CTX_LIST};
     if (ctx->NH != 4 || ctx->cfg.hidden_act != CADM_ACT_SWISH) return 0;
     bool h = false, c = false;
-    for (int v : hids) h = h || v == ctx->HID;
+    for (int v : hids) h = h || v == ctx->xg.HID;      // the kernel's width (narrow nets run zero-padded on 128: xdl_geo.h)
     for (int v : ctxs) c = c || v == ctx->C;
     return h && c ? 1 : 0;
 }

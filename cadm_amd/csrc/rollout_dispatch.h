@@ -22,7 +22,7 @@ template <int ENV, int... HIDS>
 int dispatch_hid(cadm_ctx* ctx, const RolloutArgs& a, int rpm, hipStream_t s) {
     int rc = CADM_ENOTBUILT;
     if (ctx->NH == CADM_BUILTIN_NH && ctx->cfg.hidden_act == CADM_BUILTIN_ACT)
-        ((ctx->HID == HIDS ? (rc = dispatch_ctx_list<ENV, HIDS, CADM_CTX_LIST>(ctx, a, rpm, s), 0) : 0), ...);
+        ((ctx->xg.HID == HIDS ? (rc = dispatch_ctx_list<ENV, HIDS, CADM_CTX_LIST>(ctx, a, rpm, s), 0) : 0), ...);
     if (rc == CADM_ENOTBUILT)
         cadm_set_error("rollout: no kernel for hidden=%d x %d layers, context_out_dim=%d, nonlinearity %d in this build of the library; "
                        "cadm_amd.jit builds it on demand (cadm_register_rollout)", ctx->HID, ctx->NH, ctx->C, ctx->cfg.hidden_act);

@@ -753,8 +753,10 @@ __device__ __forceinline__ void chain_loss_phase(const ChainArgs& a, float* bufs
                     const float s1 = sigmoidf_(u - mn), s2 = sigmoidf_(mx - lv0);         // softplus' = sigmoid
                     p.dMu[i] = 2.0f * s * diff * invvar;
                     p.dLv[i] = g_lvc * s1 * s2;
-                    tm[4] = g_lvc * s1 * (1.0f - s2);                                     // d / d max_logvar (without the 0.01 reg)
-                    tm[5] = g_lvc * (1.0f - s1);                                          // d / d min_logvar
+                    // 1 - sigmoid(x) = sigmoid(-x), evaluated as such: with min_logvar = -10 the factor is ~5e-5 and `1 - s1`
+                    // would keep 3 of its digits (the autodiff graph's g - g s1 does cancel like that; this is the exact value)
+                    tm[4] = g_lvc * s1 * sigmoidf_(lv0 - mx);                             // d / d max_logvar (without the 0.01 reg)
+                    tm[5] = g_lvc * sigmoidf_(mn - u);                                    // d / d min_logvar
                 }
             } else {
                 const float tb = tgt;
@@ -793,7 +795,12 @@ __device__ __forceinline__ void chain_loss_phase(const ChainArgs& a, float* bufs
     // a release fence writes back the XCD's whole L2, which at this point holds the megabytes of z / h the chain has just
     // stored (measured: + 48 us on the launch).  There the partials are device-coherent stores (sc1: written through, past
     // the non-coherent L2s) that have completed (vmcnt) before the arrival counter is bumped, and the last workgroup reads them
-    // with device-coherent loads.
+    // with device-coherent loads.  This is the "sc1 payload -> asm vmcnt(0) -> agent atomic flag / sc1 loads on the consumer" form
+    // MI355X_MICROARCH.md lists as valid for gfx950 (handoff-flag, "drained sc1"); it is a statement about THIS target, which is
+    // the only one the library is built for (Makefile: ARCH = gfx950), not about the HIP memory model in general.  Compiler side:
+    // the asm wait carries a "memory" clobber and both __syncthreads() are workgroup fences, so no access moves across them.
+    // tests/test_gpu_train.py::test_eval_losses_equal_the_training_steps_reduction pins the result (bit-equal to the two-launch
+    // reduction, under load, many repetitions).
     if (!a.loss_final) return;
     int* const flag = reinterpret_cast<int*>(scr + (6 * nel > CH_THREADS ? 6 * nel : CH_THREADS));     // (launch_chain sizes scr)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1689,10 +1696,9 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s, const Chai
     CADM_REQUIRE(lds <= 160 * 1024, "training chain: layer too wide for the LDS-resident activation tile");
     CADM_REQUIRE((long long)B * (t->chain_bufsz / CH_ROWS) * 4 < (1LL << 32),
                  "training chain: batch of %d rows too large for 32-bit per-member offsets", B);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
+    if (lds > ctx->chain_attr_lds) {      // per ctx = per device (a process-wide flag would leave a second GPU's attribute unset)
         CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
+        ctx->chain_attr_lds = lds;
     }
     hipLaunchKernelGGL(chain_kernel, dim3(8 * a.ips * rounds), dim3(CH_THREADS), lds, s, a);
     CADM_CHECK_HIP(hipGetLastError());

@@ -31,8 +31,16 @@
 #endif
 #define CADM_XDL_WAVES 8          // two waves per SIMD: one wave's waits (LDS, L2, epilogue chains) hide behind the other's MFMAs
 
+// Narrow nets: the 8-wave tile split needs at least 8 hidden tiles (113 units).  A narrower net (the reference accepts any
+// --hidden_size, e.g. 64) runs on the 128-wide instantiation with zero-padded units: a padded unit has zero weights and bias on
+// both sides, so whatever the nonlinearity makes of its zero pre-activation is multiplied by zero in the next layer.  HID is the
+// KERNEL's width (tiles, chunks, stream layout), HIDR the model's (bounds and strides of the master weights in the packer).
+#define CADM_XDL_MIN_HID 113
+#define CADM_XDL_NARROW_HID 128
+__host__ __device__ constexpr int xdl_kernel_hid(int hid) { return hid < CADM_XDL_MIN_HID ? CADM_XDL_NARROW_HID : hid; }
+
 struct XdlGeo {
-    int K0, HID, D, NH;
+    int K0, HID, D, NH, HIDR;
     int NC0, NT, NCH, NTO, BASE, EXTRA, NTOW;
     __host__ __device__ int ntw(int w) const { return BASE + (w < EXTRA ? 1 : 0); }
     __host__ __device__ int tstart(int w) const { return w * BASE + (w < EXTRA ? w : EXTRA); }
@@ -51,9 +59,10 @@ struct XdlGeo {
     __host__ __device__ int bias_tiles() const { return NH * NT + NTO; }
 };
 
-inline XdlGeo make_xdl_geo(int K0, int HID, int D, int NH) {
+inline XdlGeo make_xdl_geo(int K0, int hid_model, int D, int NH) {
     XdlGeo g;
-    g.K0 = K0; g.HID = HID; g.D = D; g.NH = NH;
+    const int HID = xdl_kernel_hid(hid_model);
+    g.K0 = K0; g.HID = HID; g.HIDR = hid_model; g.D = D; g.NH = NH;
     g.NC0 = (K0 + 31) / 32;
     g.NT = (HID + 15) / 16;
     g.NCH = (g.NT + 1) / 2;

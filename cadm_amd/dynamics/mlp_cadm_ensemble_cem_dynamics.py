@@ -14,9 +14,11 @@ Differences a caller can see (all opt-in except the first):
   * extra kwargs: `reference_quirks` (default True: reproduce the context-layout quirks Q1/Q2
     of core/utils.py:434-435), `seed` (device Philox key; the reference never seeds TF),
     `device`, `process_group` (OPT-IN: shard candidates over the ranks of that torch.distributed group; every
-    rank must then call get_action with the same observations -- None, the default, never shards; the first
-    `check_replicated_calls` sharded calls verify that with one extra all-reduce, later calls run only the path's own
-    collectives);
+    rank must then call get_action with the same observations -- None, the default, never shards.  The GUARD against ranks
+    that drift apart (different obs / history / warm start -> different elite sets -> silently different plans): the first
+    `check_replicated_calls` (2) sharded calls AND every `check_replicated_every`-th (256th) one after them compare a checksum
+    of the inputs with one extra all-reduce and raise on a mismatch; all other calls run only the path's own collectives.
+    `check_replicated_every=0` switches the periodic check OFF -- then nothing detects divergence after the first calls);
   * `predict(obs, act, cp_obs, cp_act)` -- thin alias the north-star asks for: one-step mean
     prediction of every ensemble member (the reference has no public predict).
 """
@@ -139,6 +141,7 @@ class MLPEnsembleCEMDynamicsModel(object):
                  device=None,
                  process_group=None,
                  check_replicated_calls=2,
+                 check_replicated_every=256,
                  engine_lib=None,
                  ):
         self.env = env
@@ -198,6 +201,8 @@ class MLPEnsembleCEMDynamicsModel(object):
         self._group = process_group
         self._shard1 = None
         self._check_replicated_left = int(check_replicated_calls)   # sharded get_action calls that still verify replicated inputs
+        self._check_replicated_every = int(check_replicated_every)  # ... and every N-th sharded call after those (0: never again)
+        self._sharded_calls = 0
         self.engine = HipEngine(self.env_kind, ensemble_size, n_particles, obs_space_dims, self.action_space_dims,
                                 self.proc_obs_space_dims, context_out_dim, hidden_sizes, n_forwards,
                                 deterministic=deterministic, discrete=self.discrete,
@@ -268,12 +273,23 @@ class MLPEnsembleCEMDynamicsModel(object):
                 logger.log("cadm_amd: a rank failed in-library RCCL init; all ranks use torch.distributed all_gather")
         return shard, (shard.world == 1 or self.engine.dist_world == shard.world)
 
+    def _replication_check_due(self, peek=False):
+        """Sharded calls only.  Counts the call (unless `peek`: the same call asking again further down) and says whether this one
+        verifies that every rank was fed the same inputs: the first `check_replicated_calls` calls, then every
+        `check_replicated_every`-th.  Every rank makes the same sequence of calls, so every rank takes the same decision."""
+        if not peek:
+            self._sharded_calls += 1
+        if self._check_replicated_left > 0:
+            return True
+        return self._check_replicated_every > 0 and self._sharded_calls % self._check_replicated_every == 0
+
     def get_action(self, obs, cp_obs, cp_act, cem_init_mean=None, cem_init_var=None):
         """reference :344-367.  CEM: returns the whole plan [m,H,A]; RS: the first action [m,A]
         (ints [m] for discrete envs).  Continuous outputs are clipped to [-1,1]."""
         if self._stats_dirty:
             self._push_stats()
         nd = np.ndarray
+        counted = False
         if (type(obs) is nd and type(cem_init_mean) is nd and type(cem_init_var) is nd and (cp_obs is None or type(cp_obs) is nd)
                 and (cp_act is None or type(cp_act) is nd) and obs.shape[0] > 0):
             # the samplers' call, shapes read off the arrays (np.shape / isinstance over five arguments cost ~4 us of a 0.9 ms call)
@@ -281,7 +297,8 @@ class MLPEnsembleCEMDynamicsModel(object):
                    cem_init_var.shape)
             if sig == self._checked_sig:
                 shard, fused = self._sharding()
-                if fused and not (shard.world > 1 and self._check_replicated_left > 0):
+                counted = shard.world > 1
+                if fused and not (counted and self._replication_check_due()):
                     self._call += 1
                     return self.engine.cem_plan_host((obs, cp_obs, cp_act, cem_init_mean, cem_init_var), self.n_candidates, seed=self.seed,
                                                      call=self._call & 0xFFFFFFFF, shapes=sig)
@@ -298,14 +315,15 @@ class MLPEnsembleCEMDynamicsModel(object):
             self._checked_sig = sig
         call = self._next_call()
         shard, fused = self._sharding()
-        if fused and host_in and cem_init_mean is not None and not (shard.world > 1 and self._check_replicated_left > 0):
+        check_due = shard.world > 1 and self._replication_check_due(peek=counted)
+        if fused and host_in and cem_init_mean is not None and not check_due:
             # the hot path of the samplers' loop: one library call from host arrays to the host plan (clipped in the last kernel)
             return self.engine.cem_plan_host((obs, cp_obs, cp_act, cem_init_mean, cem_init_var), self.n_candidates, seed=self.seed, call=call,
                                              shapes=sig)
         if host_in:
             obs, cp_obs, cp_act, cem_init_mean, cem_init_var = self.engine.stage((obs, cp_obs, cp_act, cem_init_mean, cem_init_var))
-        if shard.world > 1 and self._check_replicated_left > 0:      # first calls only: two blocking collectives + a host sync
-            self._check_replicated_left -= 1
+        if check_due:      # first calls + every N-th: one blocking all-reduce + a host sync
+            self._check_replicated_left = max(0, self._check_replicated_left - 1)
             _planner.check_replicated([self.engine._t(x) for x in (obs, cp_obs, cp_act, cem_init_mean) if x is not None], shard)
         if cem_init_mean is not None:
             if fused:

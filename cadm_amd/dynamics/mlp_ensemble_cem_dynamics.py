@@ -18,7 +18,8 @@ class MLPEnsembleCEMDynamicsModel(_CaDMModel):
                  optimizer=None, valid_split_ratio=0.2, rolling_average_persitency=0.99, n_forwards=30,
                  n_candidates=2500, ensemble_size=5, n_particles=20, use_cem=False, deterministic=False,
                  weight_decays=(0., 0., 0., 0., 0.), weight_decay_coeff=0.0,
-                 reference_quirks=True, seed=0, device=None, process_group=None, check_replicated_calls=2, engine_lib=None):
+                 reference_quirks=True, seed=0, device=None, process_group=None, check_replicated_calls=2,
+                 check_replicated_every=256, engine_lib=None):
         super().__init__(name, env, hidden_sizes=hidden_sizes, hidden_nonlinearity=hidden_nonlinearity,
                          output_nonlinearity=output_nonlinearity, batch_size=batch_size, learning_rate=learning_rate,
                          normalize_input=normalize_input, optimizer=optimizer, valid_split_ratio=valid_split_ratio,
@@ -28,7 +29,8 @@ class MLPEnsembleCEMDynamicsModel(_CaDMModel):
                          weight_decay_coeff=weight_decay_coeff, cp_hidden_sizes=(), context_weight_decays=(),
                          context_out_dim=0, history_length=0, future_length=1, state_diff=False, back_coeff=0.0,
                          reference_quirks=reference_quirks, seed=seed, device=device, process_group=process_group,
-                         check_replicated_calls=check_replicated_calls, engine_lib=engine_lib)
+                         check_replicated_calls=check_replicated_calls, check_replicated_every=check_replicated_every,
+                         engine_lib=engine_lib)
 
     def get_action(self, obs, cem_init_mean=None, cem_init_var=None):
         return super().get_action(obs, None, None, cem_init_mean, cem_init_var)

@@ -112,3 +112,22 @@ def test_check_replicated_is_nan_aware_and_order_sensitive(tmp_path):
     for r in range(2):
         got = dict(np.load(tmp_path / ("repl_%d.npy" % r)))
         assert got == {"same": "ok", "differs": "raised", "permuted": "raised", "nan_moved": "raised"}, got
+
+
+def test_replication_check_schedule():
+    """The sharded get_action's guard: the first `check_replicated_calls` calls AND every `check_replicated_every`-th
+    one after them verify the replicated inputs; 0 switches the periodic part off.  (The method only reads three counters, so it
+    is exercised here on a stand-in object: the class itself needs a GPU.)"""
+    import types
+    from cadm_amd.dynamics.mlp_cadm_ensemble_cem_dynamics import MLPEnsembleCEMDynamicsModel as M
+    me = types.SimpleNamespace(_check_replicated_left=2, _check_replicated_every=5, _sharded_calls=0)
+    due = []
+    for call in range(1, 13):
+        d = M._replication_check_due(me)
+        assert M._replication_check_due(me, peek=True) == d        # asking again for the same call neither counts nor changes the answer
+        if d and me._check_replicated_left > 0:
+            me._check_replicated_left -= 1                         # (what get_action does when it runs the check)
+        due.append(d)
+    assert due == [True, True, False, False, True, False, False, False, False, True, False, False]
+    off = types.SimpleNamespace(_check_replicated_left=0, _check_replicated_every=0, _sharded_calls=0)
+    assert not any(M._replication_check_due(off) for _ in range(600))

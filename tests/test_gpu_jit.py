@@ -53,6 +53,41 @@ def test_one_step_parity_of_jit_built_kernels(gpu, hidden, C, act):
     eng.close()
 
 
+NARROW = [  # hidden widths below the 8-wave tile split's 113 units: zero-padded onto the 128-wide kernel (xdl_geo.h)
+    ((64,) * 4, 10, "swish"),        # `--hidden_size 64`: served by the COMPILED-IN 128-wide kernel, no build
+    ((32,) * 4, 0, "swish"),         # vanilla PE-TS, 2 tiles of real units
+    ((100,) * 2, 10, "sigmoid"),     # sigmoid(0) = 0.5 on the padded units: only their zero outgoing weights silence them
+    ((17,) * 3, 5, "relu"),          # odd width, odd context width
+]
+
+
+@pytest.mark.parametrize("hidden,C,act", NARROW)
+def test_narrow_hidden_widths_run_zero_padded(gpu, hidden, C, act):
+    """The reference accepts any --hidden_size (run_cadm_pets.py:122); ADVICE r3: widths < 113 were refused."""
+    E, p, m, n = 5, 10, 2, 9
+    prob = synth.make_problem(env="halfcheetah", context=C > 0, E=E, m=m, H=3, hidden_sizes=hidden, C=C, trained_like=True, seed=62)
+    eng = make_engine(prob, p=p, H=3, hidden_nonlinearity=act)
+    assert bool(eng.lib.cadm_rollout_builtin(eng._ctx)) == (act == "swish" and len(hidden) == 4)
+    rng = np.random.default_rng(6)
+    actions = rng.uniform(-1, 1, (m, n, 3, prob["A"]))
+    eps = rng.standard_normal((3, m, n, p, prob["D"]))
+    ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"]) if C > 0 else None
+    rows, traj = eng.rollout_returns(prob["obs"], ctx, actions, eps=eps, want_traj=True)
+    o = oracle_problem(prob, np.float32)
+    T = oplanner.context_table_indexed(onets.context_forward(o["cp"], o["cp_obs"], o["cp_act"], o["st"]), 0) if C > 0 else None
+    r_ref, t_ref = oplanner.rollout_indexed(o["env"], o["ff"], o["st"], o["obs"], T, actions.astype(np.float32), eps.astype(np.float32), E, p,
+                                            False, return_traj=True, hidden_act=onets.ACTIVATIONS[act])
+    assert_close(traj.cpu().numpy(), t_ref, 2e-5, "3-step trajectory, hidden=%r C=%d act=%r" % (hidden, C, act))
+    assert_close(rows.cpu().numpy(), r_ref, 2e-5, "returns")
+    eng.close()
+    if C > 0:      # the drop-in class end to end at this width
+        model = MLPEnsembleCEMDynamicsModel("dyn_model", make_env_spec("halfcheetah"), hidden_sizes=hidden, hidden_nonlinearity=act,
+                                            n_forwards=5, n_candidates=64, ensemble_size=5, n_particles=10, use_cem=True, state_diff=1,
+                                            normalize_input=False, context_out_dim=C, history_length=prob["Hh"])
+        plan = model.get_action(prob["obs"], prob["cp_obs"], prob["cp_act"], np.zeros((m, 5, 6)), np.full((m, 5, 6), 0.25))
+        assert plan.shape == (m, 5, 6) and np.isfinite(plan).all()
+
+
 @pytest.mark.parametrize("hidden,C,act", GEOS[:5])
 def test_training_step_with_other_nonlinearities(gpu, hidden, C, act):
     E, B = 3, 48

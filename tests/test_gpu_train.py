@@ -119,10 +119,11 @@ def test_adam_steps_match_tf1_semantics_elementwise(gpu):
     """6 real Adam steps (lr 1e-3, beta 0.9 / 0.999, eps 1e-8).  Before every step the oracle is set to the device's state -- weights
     and both moment buffers, read through the developer hook -- takes the fp64 autograd gradient there and applies the TF1 closed
     form (ApplyAdam: lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); w -= lr_t m / (sqrt(v) + eps)); the device's step must land on the same
-    weights element by element: |dw - dw_ref| <= 2e-3 lr wherever the update is well conditioned.  Adam's update m / sqrt(v) is a
-    SIGN-like function of the gradient history: for an element whose gradients are themselves at roundoff level (|g| < 1e-3 rms of
-    its tensor) it amplifies fp32 roundoff to O(lr), in TF as much as here; those elements (counted, bounded) are only required
-    to move by at most lr_t-scale, like every other."""
+    weights ELEMENT BY ELEMENT, every element of every tensor: |dw - dw_ref| <= 2e-4 lr + |du/dg| * (1e-5 max|g|) + ulp(w)/2.
+    The middle term is the gradient bar of test_gradients_elementwise_vs_fp64_autograd carried through the update u(g) = lr_t m /
+    (sqrt(v) + eps): Adam's update is a sign-like function of the gradient history, so for an element whose gradients are at
+    roundoff level du/dg is large (in TF as much as here) and the bound says by how much; everywhere else it vanishes against
+    2e-4 lr.  No element is excluded."""
     env, E, B, lr = "halfcheetah", 5, 128, 1e-3
     prob = synth.make_problem(env=env, context=True, E=E, trained_like=True, with_back=True, seed=30)
     eng = _dev_engine(prob, E)
@@ -133,17 +134,21 @@ def test_adam_steps_match_tf1_semantics_elementwise(gpu):
     st = otrain.to_torch(prob["stats"], torch.float64)
     names = {"ff_model": "ff", "backward_model": "back", "context_model": "cp"}
     b1, b2, eps = 0.9, 0.999, 1e-8
-    losses, excluded, total = [], 0, 0
+    losses, loose, total, worst = [], 0, 0, 0.0
     for step in range(1, 7):
-        state = {n: {k: (v.cpu().numpy().astype(np.float64), eng.dev_read_adam_moment(n, k).cpu().numpy().astype(np.float64),
-                         eng.dev_read_adam_moment(n, k, second=True).cpu().numpy().astype(np.float64)) for k, v in eng.nets[n].items()}
+        # (the backward model's logvar bounds are never trained -- no gradient, no Adam slot: dynamics.py:213-240)
+        untrained = lambda n, k: n == "backward_model" and k in ("max_logvar", "min_logvar")
+        mom = lambda n, k, second: (np.zeros(tuple(eng.nets[n][k].shape)) if untrained(n, k)
+                                    else eng.dev_read_adam_moment(n, k, second=second).cpu().numpy().astype(np.float64))
+        state = {n: {k: (v.cpu().numpy().astype(np.float64), mom(n, k, False), mom(n, k, True)) for k, v in eng.nets[n].items()}
                  for n in eng.net_names()}
         nets = {n: otrain.to_torch({k: w for k, (w, _, _) in state[n].items()}, torch.float64, True) for n in eng.net_names()}
         out = otrain.train_losses(env, nets["ff_model"], nets["backward_model"], nets["context_model"], st, tb, _cfg(prob, False, 0.5))
         grads = otrain.grads_of(out["loss"], nets)
         got = eng.train_step(dev, train=True).cpu().numpy()
         losses.append(got)
-        np.testing.assert_allclose(got, [float(out["mse"]), float(out["back_mse"]), float(out["recon"])], rtol=5e-5, atol=5e-5)
+        np.testing.assert_allclose(got, [float(out["mse"].detach()), float(out["back_mse"].detach()), float(out["recon"].detach())],
+                                   rtol=5e-5, atol=5e-5)
         lr_t = lr * np.sqrt(1.0 - b2 ** step) / (1.0 - b1 ** step)
         for n in eng.net_names():
             for k, (w0, m0, v0) in state[n].items():
@@ -156,17 +161,48 @@ def test_adam_steps_match_tf1_semantics_elementwise(gpu):
                 dw_ref = -lr_t * m1 / (np.sqrt(v1) + eps)
                 dw = w1 - w0
                 assert np.abs(dw).max() <= 1.001 * lr_t * max(1.0, np.abs(m1 / (np.sqrt(v1) + eps)).max()) + np.abs(w0).max() * 2.0 ** -22 + 1e-7     # no element runs away
-                ok = np.abs(g) >= 1e-3 * np.sqrt(np.mean(g ** 2))
-                excluded += int((~ok).sum())
+                sv = np.sqrt(v1)
+                dudg = lr_t * np.abs((1 - b1) / (sv + eps) - m1 * (1 - b2) * g / (np.maximum(sv, 1e-300) * (sv + eps) ** 2))
+                bar = 2e-4 * lr + dudg * 1e-5 * np.abs(g).max() + np.abs(w0) * 2.0 ** -23
+                err = np.abs(dw - dw_ref)
+                loose += int((bar > 2e-3 * lr).sum())
                 total += g.size
-                # fp32 weights of magnitude |w| resolve a step to ulp(w) / 2: part of the bar
-                bar = 2e-3 * lr + np.abs(w0[ok]) * 2.0 ** -23
-                err = np.abs(dw[ok] - dw_ref[ok])
-                assert (err <= bar).all(), "step %d %s/%s: update off by %.3e (= %.2e lr) at the worst element" % (
-                    step, n, k, err.max(), err.max() / lr)
+                worst = max(worst, float((err / lr).max()))
+                assert (err <= bar).all(), "step %d %s/%s: update off by %.2e lr at the worst element (its bar %.2e lr)" % (
+                    step, n, k, (err / lr)[np.argmax(err - bar)], (bar / lr)[np.argmax(err - bar)])
     assert losses[-1][2] < losses[0][2], "training loss did not decrease"
-    assert excluded <= 0.01 * total, "%d of %d elements excluded as ill-conditioned" % (excluded, total)
-    print("adam: %d steps, %d of %d element-updates excluded (|g| < 1e-3 rms)" % (6, excluded, total))
+    assert loose <= 0.02 * total, "%d of %d element-updates had a propagated bar above 2e-3 lr" % (loose, total)
+    print("adam: 6 steps, %d element-updates, worst deviation %.2e lr; %d (%.2f %%) were ill-conditioned enough for a bar above 2e-3 lr"
+          % (total, worst, loose, 100.0 * loose / total))
+
+
+@pytest.mark.parametrize("B", [256, 37, 1024])
+def test_eval_losses_equal_the_training_steps_reduction(gpu, B):
+    """An evaluation step hands its loss partials to the LAST-arriving workgroup inside the forward launch (device-coherent sc1
+    stores, drained, then an agent-scope atomic; sc1 loads on the reader -- train.hip, closing phase); a training step leaves
+    them to a workgroup of the NEXT launch (kernel boundary).  Same partials, two hand-offs: the sums must agree to fp32
+    reduction-order roundoff.  Two very different batches alternate for 300 rounds, so a partial read stale (the previous
+    round's) would move the sum by orders of magnitude more than the bar; lr = 0 keeps the weights where they are."""
+    env, E = "halfcheetah", 5
+    prob = synth.make_problem(env=env, context=True, E=E, trained_like=True, with_back=True, seed=61)
+    eng = make_engine(prob, p=E)
+    eng.train_configure(0.0, WD, CWD, 1.0, 0.5, max_batch=B)
+    b1 = synth.make_train_batch(prob, B=B, seed=8)
+    b2 = synth.make_train_batch(prob, B=B, seed=9)
+    for k in ("delta", "back_delta"):
+        b2[k] = 7.0 * b2[k]
+    devs = [_dev_batch(eng, b, True, True) for b in (b1, b2)]
+    want = [eng.train_step(d, train=True).cpu().numpy() for d in devs]          # reduction across the kernel boundary
+    assert abs(want[0][2] - want[1][2]) > 0.5 * abs(want[0][2])                  # the two batches are told apart easily
+    outs = []
+    for r in range(300):
+        outs.append(eng.train_step(devs[r & 1], train=False))                    # no sync in between: back-to-back launches
+    outs = torch.stack(outs).cpu().numpy()
+    for r in range(300):
+        np.testing.assert_allclose(outs[r], want[r & 1], rtol=3e-6, atol=0, err_msg="evaluation step %d" % r)
+    again = [eng.train_step(d, train=True).cpu().numpy() for d in devs]
+    for w, a in zip(want, again):
+        np.testing.assert_array_equal(w, a)                                      # lr = 0: nothing moved, the reduction is deterministic
 
 
 def test_train_then_plan_uses_updated_weights(gpu):
