@@ -118,6 +118,9 @@ __global__ __launch_bounds__(CP_THREADS) void context_kernel(const CpArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------------
 #define CPB_THREADS 256
 #define CPB_WAVES 4
+#ifndef CPB_MAX_RT
+#define CPB_MAX_RT 2                   // row tiles per workgroup tried first (developer builds: -DCPB_MAX_RT=1)
+#endif
 #define CPB_PF 6                       // k-steps of weight fragments in flight per wave
 struct CpbArgs {
     CpArgs a;
@@ -126,85 +129,119 @@ struct CpbArgs {
     int in_stride;                     // row stride of the input tile (odd)
 };
 
-template <int RT>
-__device__ __forceinline__ void cpb_layer(const float* __restrict__ W, const float* __restrict__ bias, int K, int N, bool relu, bool in_rowmajor,
-                                          int in_stride, const float* xin, float* xout, float* gout, int gld, int grow0, int grows,
-                                          int wave, int lane) {
+// One work item of a layer: 64 output units x NRT row tiles, the whole K.  Everything the k loop branches on is a template
+// parameter (hipcc waits for ALL outstanding loads at every use once a uniform branch sits between a load and its use: the
+// ring would be worth nothing), the loop body is straight-line code: one ring slot consumed, one refilled, NRT LDS reads,
+// 4 NRT MFMAs.  K is walked in steps of 4 up to the next multiple of 4: the LDS tiles are zero-padded there and the weight
+// rows clamped, so the tail needs no predicate.
+template <int RT, int NRT, bool VEC, bool ROWMAJOR>
+__device__ __forceinline__ void cpb_item(const float* __restrict__ W, const float* __restrict__ bias, int K, int N, bool relu, int in_stride,
+                                         const float* xin, float* xout, float* gout, int grow0, int grows, int g, int rt0, int lane) {
     constexpr int R = 16 * RT;
     const int i = lane & 15, q = lane >> 4;
-    const int NG = (N + 63) >> 6;                                 // groups of 64 output units
-    const int split = NG >= CPB_WAVES ? 1 : RT;                   // few groups: the row tiles of a group go to different waves
-    const int nitems = NG * split;
+    const int u0 = g * 64 + 4 * i;                                // this lane's 4 consecutive units (tile t: unit u0 + t)
     const int nsteps = (K + 3) >> 2;
-    const bool vec = (N & 3) == 0;
-    for (int item = wave; item < nitems; item += CPB_WAVES) {
-        const int g = item % NG, rt0 = split == 1 ? 0 : item / NG, nrt = split == 1 ? RT : 1;
-        const int u0 = g * 64 + 4 * i;                            // this lane's 4 consecutive units (tile t: unit u0 + t)
-        floatx4 acc[4][RT];
+    // the bias is the accumulators' initial value (requested first, it arrives under the ring's first loads)
+    floatx4 acc[4][NRT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        floatx4 b4;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { const int unit = g * 64 + 4 * (4 * q + rr) + t; b4[rr] = bias[unit < N ? unit : N - 1]; }
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) acc[t][r] = b4;
+    }
+    // A operand of k-step s: row k = 4 s + q of W, units u0 .. u0 + 3 (clamped into the matrix: the B operand is zero for
+    // k >= K, and units >= N are never stored)
+    const int uc = VEC ? (u0 < N ? u0 : N - 4) : 0;
+    int ucs[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ucs[t] = u0 + t < N ? u0 + t : N - 1;
+    auto fetch = [&](int s) -> floatx4 {
+        int k = 4 * s + q;
+        k = k < K ? k : K - 1;
+        const float* row = W + (size_t)k * N;
+        if (VEC) return *reinterpret_cast<const floatx4*>(row + uc);
+        floatx4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = row[ucs[t]];
+        return v;
+    };
+    // B operand of k-step s for row tile r: X[row = 16 (rt0 + r) + i][k = 4 s + q]
+    int boff[NRT];
+#pragma unroll
+    for (int r = 0; r < NRT; ++r) {
+        const int row = 16 * (rt0 + r) + i;
+        boff[r] = ROWMAJOR ? row * in_stride + q : q * R + (row ^ (RT == 2 ? 16 * (q & 1) : 0));      // (k & 1 == q & 1: k = 4 s + q)
+    }
+    const int bstep = ROWMAJOR ? 4 : 4 * R;
+    auto bread = [&](float (&bv)[NRT], int s) {
+#pragma unroll
+        for (int r = 0; r < NRT; ++r) bv[r] = xin[boff[r] + s * bstep];
+    };
+    auto mfmas = [&](const floatx4& av, const float (&bv)[NRT]) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < RT; ++r) acc[t][r] = floatx4{0.f, 0.f, 0.f, 0.f};
-        // A operand of k-step s: row k = 4 s + q of W, units u0 .. u0 + 3 (rows / units past the matrix: clamped loads -- the
-        // B operand is zero for k >= K, and units >= N are never stored)
-        auto fetch = [&](int s) -> floatx4 {
-            int k = 4 * s + q;
-            k = k < K ? k : K - 1;
-            if (vec) {
-                const int u = u0 < N ? u0 : N - 4;
-                return *reinterpret_cast<const floatx4*>(W + (size_t)k * N + u);
-            }
-            floatx4 v;
+            for (int r = 0; r < NRT; ++r) acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[r], acc[t][r], 0, 0, 0);
+    };
+    floatx4 ring[CPB_PF];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) v[t] = W[(size_t)k * N + (u0 + t < N ? u0 + t : N - 1)];
-            return v;
-        };
-        floatx4 ring[CPB_PF];
+    for (int u = 0; u < CPB_PF; ++u) ring[u] = fetch(u < nsteps ? u : nsteps - 1);
+    int s0 = 0;
+    for (; s0 + CPB_PF <= nsteps; s0 += CPB_PF) {
+        float bv[CPB_PF][NRT];
 #pragma unroll
-        for (int u = 0; u < CPB_PF; ++u) ring[u] = fetch(u < nsteps ? u : nsteps - 1);
-        for (int s0 = 0; s0 < nsteps; s0 += CPB_PF) {
+        for (int u = 0; u < CPB_PF; ++u) bread(bv[u], s0 + u);    // the B operands of the whole group first: one LDS latency per PF steps
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < CPB_PF; ++u) {
-                const int s = s0 + u;
-                if (s < nsteps) {                                 // (uniform)
-                    const floatx4 av = ring[u];
-                    const int sn = s + CPB_PF;
-                    ring[u] = fetch(sn < nsteps ? sn : nsteps - 1);
-                    const int k = 4 * s + q;
-                    float bv[RT];
+        for (int u = 0; u < CPB_PF; ++u) {
+            // consume the slot, THEN refill it, and keep hipcc from moving the refill in front of the MFMAs: a load hoisted
+            // above the last use of its destination needs a second register and a copy at the loop's end -- behind a vmcnt(0)
+            mfmas(ring[u], bv[u]);
+            const int sn = s0 + u + CPB_PF;
+            ring[u] = fetch(sn < nsteps ? sn : nsteps - 1);      // (past the end: a re-read of the last step, never consumed)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 #pragma unroll
-                    for (int r = 0; r < RT; ++r) {
-                        if (r < nrt) {
-                            const int row = 16 * (rt0 + r) + i;
-                            bv[r] = k < K ? (in_rowmajor ? xin[row * in_stride + k] : xin[k * R + (row ^ (16 * (k & 1) * (RT - 1)))]) : 0.0f;
-                        }
-                    }
+    for (int u = 0; u < CPB_PF - 1; ++u)                          // the last nsteps % PF steps are already in the ring
+        if (s0 + u < nsteps) { float bv[NRT]; bread(bv, s0 + u); mfmas(ring[u], bv); }
+    // D layout: lane (col = i -> data row, q), register rr -> A-row 4 q + rr -> unit g * 64 + 4 (4 q + rr) + t.  Units up to
+    // the next multiple of 4 behind N are written as zeros (the next layer walks K in steps of 4).
+    const int N4 = (N + 3) & ~3;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-                        for (int r = 0; r < RT; ++r)
-                            if (r < nrt) acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[r], acc[t][r], 0, 0, 0);
-                }
+        for (int rr = 0; rr < 4; ++rr) {
+            const int unit = g * 64 + 4 * (4 * q + rr) + t;
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) {
+                float v = acc[t][r][rr];
+                if (relu) v = fmaxf(v, 0.0f);                                        // ReLU hidden (layers.py:34), identity output
+                const int row = 16 * (rt0 + r) + i;
+                if (gout) { if (unit < N && row < grows) gout[(size_t)(grow0 + row) * N + unit] = v; }
+                else if (unit < N4) xout[unit * R + (row ^ (RT == 2 ? 16 * (unit & 1) : 0))] = unit < N ? v : 0.0f;
             }
         }
-        // D layout: lane (col = i -> data row, q), register rr -> A-row 4 q + rr -> unit g * 64 + 4 (4 q + rr) + t
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int unit = g * 64 + 4 * (4 * q + rr) + t;
-                const float bsv = bias[unit < N ? unit : N - 1];
-#pragma unroll
-                for (int r = 0; r < RT; ++r) {
-                    if (r < nrt && unit < N) {
-                        float v = acc[t][r][rr] + bsv;
-                        if (relu) v = fmaxf(v, 0.0f);                                    // ReLU hidden (layers.py:34), identity output
-                        const int row = 16 * (rt0 + r) + i;
-                        if (gout) { if (row < grows) gout[(size_t)(grow0 + row) * gld + unit] = v; }
-                        else xout[unit * R + (row ^ (16 * (unit & 1) * (RT - 1)))] = v;
-                    }
-                }
-            }
+}
+
+template <int RT, bool ROWMAJOR>
+__device__ __forceinline__ void cpb_layer(const float* __restrict__ W, const float* __restrict__ bias, int K, int N, bool relu, int in_stride,
+                                          const float* xin, float* xout, float* gout, int grow0, int grows, int wave, int lane) {
+    const int NG = (N + 63) >> 6;                                 // groups of 64 output units
+    const bool vec = (N & 3) == 0;
+    if (RT == 1 || NG >= CPB_WAVES) {                             // a wave takes whole groups, all row tiles (weights reused RT times)
+        for (int g = wave; g < NG; g += CPB_WAVES) {
+            if (vec) cpb_item<RT, RT, true, ROWMAJOR>(W, bias, K, N, relu, in_stride, xin, xout, gout, grow0, grows, g, 0, lane);
+            else cpb_item<RT, RT, false, ROWMAJOR>(W, bias, K, N, relu, in_stride, xin, xout, gout, grow0, grows, g, 0, lane);
+        }
+    } else {                                                      // few groups: the row tiles of a group go to different waves
+        for (int item = wave; item < NG * RT; item += CPB_WAVES) {
+            const int g = item % NG, rt0 = item / NG;
+            if (vec) cpb_item<RT, 1, true, ROWMAJOR>(W, bias, K, N, relu, in_stride, xin, xout, gout, grow0, grows, g, rt0, lane);
+            else cpb_item<RT, 1, false, ROWMAJOR>(W, bias, K, N, relu, in_stride, xin, xout, gout, grow0, grows, g, rt0, lane);
+        }
     }
 }
 
@@ -219,17 +256,28 @@ __global__ __launch_bounds__(CPB_THREADS) void context_batched_kernel(const CpbA
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* reg0 = cpb_smem;
     float* reg1 = cpb_smem + p.region0;
-    // input tile [row][k], normalised on the way in (core/utils.py:403-404); rows past the batch are zeros
-    const int K0 = a.dims[0], ist = p.in_stride;
-    for (int idx = tid; idx < R * K0; idx += CPB_THREADS) {
-        const int row = idx / K0, k = idx - row * K0;
-        float v = 0.0f;
-        if (row < rows) {
-            const size_t in_row = a.bs ? ((size_t)e * a.m + row0 + row) : (size_t)(row0 + row);     // tile(.., [E,1,1]) unless already [E,m,.]
-            v = k < a.n_obs ? (a.cp_obs[in_row * a.n_obs + k] - a.obs_mean[k]) / (a.obs_std[k] + 1e-10f)
-                            : (a.cp_act[in_row * a.n_act + (k - a.n_obs)] - a.act_mean[k - a.n_obs]) / (a.act_std[k - a.n_obs] + 1e-10f);
+    // input tile [row][k], normalised on the way in (core/utils.py:403-404); rows past the batch and the columns up to the next
+    // multiple of 4 behind K0 are zeros.  A thread takes column k = tid of EVERY row (K0 <= CPB_THREADS: the reference's 240) or
+    // walks (row, k) pairs; the loads of a thread are independent and issued together.
+    const int K0 = a.dims[0], ist = p.in_stride, K04 = (K0 + 3) & ~3;
+    for (int kb = 0; kb < K04; kb += CPB_THREADS) {
+        const int k = kb + tid;
+        const bool kin = k < K0, isobs = k < a.n_obs;
+        const int kk = kin ? (isobs ? k : k - a.n_obs) : 0;
+        const float* src = isobs ? a.cp_obs : a.cp_act;
+        const int ldsrc = isobs ? a.n_obs : a.n_act;
+        const float mu = (isobs ? a.obs_mean : a.act_mean)[kk], sd = (isobs ? a.obs_std : a.act_std)[kk] + 1e-10f;
+        const size_t base = a.bs ? (size_t)e * a.m + row0 : (size_t)row0;                 // tile(.., [E,1,1]) unless already [E,m,.]
+        if (k < K04) {
+            float v[R];
+#pragma unroll
+            for (int row = 0; row < R; ++row) v[row] = src[(base + (row < rows ? row : rows - 1)) * ldsrc + kk];
+#pragma unroll
+            for (int row = 0; row < R; ++row) {
+                const float x = (v[row] - mu) / sd;
+                reg0[row * ist + k] = (kin && row < rows) ? x : 0.0f;
+            }
         }
-        reg0[row * ist + k] = v;
     }
     __syncthreads();
     const float* xin = reg0;
@@ -237,8 +285,11 @@ __global__ __launch_bounds__(CPB_THREADS) void context_batched_kernel(const CpbA
         const int K = a.dims[l], N = a.dims[l + 1];
         const bool last = l + 1 == a.nlayers;
         float* xout = (l & 1) ? reg0 : reg1;
-        cpb_layer<RT>(a.W[l] + (size_t)e * K * N, a.b[l] + (size_t)e * N, K, N, !last, l == 0, ist, xin, xout,
-                      last ? a.out : nullptr, N, e * p.rows_per_member + row0, rows, wave, lane);
+        const float* W = a.W[l] + (size_t)e * K * N;
+        const float* bl = a.b[l] + (size_t)e * N;
+        float* gout = last ? a.out + (size_t)e * p.rows_per_member * N : nullptr;
+        if (l == 0) cpb_layer<RT, true>(W, bl, K, N, !last, ist, xin, xout, gout, row0, rows, wave, lane);
+        else cpb_layer<RT, false>(W, bl, K, N, !last, ist, xin, xout, gout, row0, rows, wave, lane);
         __syncthreads();
         xin = xout;
     }
@@ -249,13 +300,18 @@ static int launch_context_batched(cadm_ctx* ctx, const CpArgs& a, int m, hipStre
     CpbArgs p{};
     p.a = a;
     p.rows_per_member = m;
-    p.in_stride = a.dims[0] | 1;
-    for (int RT = 2; RT >= 1; --RT) {
+    p.in_stride = ((a.dims[0] + 3) & ~3) | 1;      // odd: the coalesced input store and the [row][k] operand reads spread over the banks
+    // Two row tiles per workgroup halve the weight stream per row, one tile doubles the workgroups: measured (E = 5, 1 x MI355X)
+    // m = 256 / 1024 / 2048 / 4096 / 8192: RT 2 30.7 / 30.9 / 51.0 / 77.7 / 125.6 us, RT 1 23.7 / 33.9 / 42.7 / 77.5 / 146.8 us --
+    // one tile wins while the two-tile grid would leave the chip between one and two workgroups per CU (uneven rounds).
+    const int wg2 = ctx->E * ((m + 31) / 32);
+    const int rt_first = (wg2 > ctx->n_cus && wg2 < 2 * ctx->n_cus + ctx->n_cus / 2) || wg2 <= ctx->n_cus / 4 ? 1 : CPB_MAX_RT;
+    for (int RT = rt_first; RT >= 1; --RT) {
         const int R = 16 * RT;
         // region 0: the input tile, later the outputs of the odd layers; region 1: the outputs of the even layers
         size_t r0 = (size_t)R * p.in_stride, r1 = 0;
         for (int l = 0; l + 1 < a.nlayers; ++l) {
-            const size_t need = (size_t)R * a.dims[l + 1];
+            const size_t need = (size_t)R * ((a.dims[l + 1] + 3) & ~3);
             if (l & 1) r0 = need > r0 ? need : r0; else r1 = need > r1 ? need : r1;
         }
         r0 = (r0 + 3) & ~(size_t)3;
