@@ -217,6 +217,7 @@ class DryRunPlanner:
         self.n_per_gpu, self.n, self.p, self.E, self.H = n_per_gpu, n_per_gpu * world, cfg["p"], cfg["E"], cfg["H"]
         self.prob = {"K0": 34, "D": 18, "env": cfg["env"], "m": m, "H": self.H}
         self.collective, self.rccl_nranks = ("gloo all-gather (dry run)", world) if world > 1 else ("none", 1)
+        self.degraded = False
         self.iters = 5
 
     def _step(self):
@@ -246,6 +247,16 @@ class DryRunPlanner:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed
+
+    def plan_device(self, c):
+        """One planner call on HBM-resident inputs.  Sharded: the model's own negotiation (`_sharding`: in-library RCCL communicator
+        on every rank, or -- all ranks together -- torch.distributed's all-gather per CEM iteration) decides the path."""
+        cp_obs, cp_act = (self.cp_obs, self.cp_act) if self.cfg["context"] else (None, None)
+        shard, fused = self.model._sharding()
+        if fused:
+            return self.eng.cem_plan(self.obs, cp_obs, cp_act, self.init_mean, self.init_var, self.n, seed=0, call=c)
+        from cadm_amd import planner as hplanner
+        return hplanner.cem_plan(self.eng, self.obs, cp_obs, cp_act, self.init_mean, self.init_var, self.n, seed=0, call=c, shard=shard)
 
     def run_api(self, steps, warmup):
         return self._timed(steps, warmup)
@@ -294,7 +305,7 @@ class Planner:
         eng.set_stats(st)       # the synthetic statistics verbatim (state_diff would zero the history statistics)
         self.obs, self.cp_obs, self.cp_act = eng._t(prob["obs"]), eng._t(prob["cp_obs"]), eng._t(prob["cp_act"])
         self.init_mean, self.init_var = eng._t(prob["init_mean"]), eng._t(prob["init_var"])
-        self.collective, self.rccl_nranks = "none", 1
+        self.collective, self.rccl_nranks, self.degraded = "none", 1, False
         self.iters = eng.num_cem_iters
 
     # ---- numpy in -> numpy out through the class (the reference's call, dynamics.py:344-367 / vanilla :191-207)
@@ -306,13 +317,18 @@ class Planner:
 
     def check_rccl(self):
         if self.world > 1:
-            # RCCL communicator inside libcadm_hip.so: one ncclAllGather per CEM iteration, all on-stream.  No fallback:
-            # a SCALE run that silently used another path would not measure north_star's design -- fail loudly instead.
+            # RCCL communicator inside libcadm_hip.so: one ncclAllGather per CEM iteration, all on-stream -- north_star's design.
+            # If it could not be created on some rank (the model's ranks then agree on torch.distributed.all_gather_into_tensor,
+            # _sharding()), the run still measures, but the line SAYS SO: `collective` names the fallback, `rccl_nranks` is 0 and
+            # `degraded` is set -- never a silent substitution.
             self.rccl_nranks, rccl_rank = self.eng.dist_info()
-            if self.eng.dist_world != self.world or self.rccl_nranks != self.world or rccl_rank != self.rank:
-                raise RuntimeError("in-library RCCL communicator reports nranks=%d rank=%d, expected %d / %d"
-                                   % (self.rccl_nranks, rccl_rank, self.world, self.rank))
-            self.collective = "rccl all-gather in libcadm_hip.so"
+            if self.eng.dist_world == self.world and self.rccl_nranks == self.world and rccl_rank == self.rank:
+                self.collective = "rccl all-gather in libcadm_hip.so"
+            else:
+                self.collective = ("FALLBACK: torch.distributed all_gather per CEM iteration (in-library RCCL communicator unavailable: "
+                                   "dist_world=%d rccl nranks=%d rank=%d, expected %d / %d)" % (self.eng.dist_world, self.rccl_nranks, rccl_rank, self.world, self.rank))
+                self.rccl_nranks = 0
+                self.degraded = True
 
     def barrier(self):
         if self.dist is not None:
@@ -334,11 +350,8 @@ class Planner:
         construction can sit in a low clock state for the whole default run (one run in ~10 measured 2.2 ms per get_action with
         the kernels' own times unchanged); this is not one of the W or K steps."""
         eng = self.eng
-        if self.world > 1 and eng.dist_world == 1:
-            eng.dist_init(self.dist.group.WORLD)
         for c in range(self.RAMP_PLANS):
-            eng.cem_plan(self.obs, self.cp_obs if self.cfg["context"] else None, self.cp_act if self.cfg["context"] else None,
-                         self.init_mean, self.init_var, self.n, seed=0, call=c)
+            self.plan_device(c)
         torch.cuda.synchronize(eng.device)
 
     def run_api(self, steps, warmup):
@@ -365,11 +378,9 @@ class Planner:
         per get_action, so the wall time of THIS pass is not the device-resident figure); profile=False: no events, wall time only.
         -> dict(elapsed [s, max over ranks], kern_ms, kern_launches, ag_*)."""
         eng = self.eng
-        if self.world > 1 and eng.dist_world == 1:
-            eng.dist_init(self.dist.group.WORLD)
+        step = self.plan_device
+        step(0)                  # (negotiates the sharded path on first use)
         self.check_rccl()
-        step = lambda c: eng.cem_plan(self.obs, self.cp_obs if self.cfg["context"] else None, self.cp_act if self.cfg["context"] else None,
-                                      self.init_mean, self.init_var, self.n, seed=0, call=c)
         for w in range(warmup):
             step(w)
         if profile:
@@ -513,7 +524,7 @@ def main():
         "dtype": "f32 (each fp32 product as 3 f16 MFMA products of 2-way split operands, fp32 accumulate; error <= 2^-22 per product; "
                  "measured parity: see `parity`)",
         "data": "dry-run (placeholders: no planner ran)" if args.dry_run else "synthetic",
-        "build_id": build_id,
+        "build_id": build_id, "degraded": bool(head.degraded),
         "config": {"workload": "%s: %s PE-TS+CaDM get_action, ens=%d part=%d cand=%d (%d/GPU) H=%d m=%d, random-init weights"
                                % (args.config, cfg["env"], cfg["E"], cfg["p"], head.n, head.n_per_gpu, cfg["H"], m),
                    "global_candidates": head.n, "parallelism": "candidate-shard x%d" % world, "collective": head.collective,

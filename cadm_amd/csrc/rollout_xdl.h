@@ -36,6 +36,11 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 #ifndef CADM_XDL_RING
 #define CADM_XDL_RING 4
 #endif
+#ifdef CADM_XDL_EXPERIMENT_NOBAR     // TIMING EXPERIMENT ONLY (wrong results): what the layer barriers cost
+#define XDL_LAYER_SYNC() ((void)0)
+#else
+#define XDL_LAYER_SYNC() __syncthreads()
+#endif
 
 // MT = row tiles (of 16 rows) a workgroup advances together.  2 for large batches: every weight fragment then feeds two sets
 // of MFMAs (half the weight stream, half the barriers and sweep start-ups per row), all 512 threads hold rollout state.
@@ -850,7 +855,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                                               hidden_epi(0, act_out), nullptr TS_ARGS);
                 }
                 TS(2)
-                __syncthreads();
+                XDL_LAYER_SYNC();
                 TS(3)
                 // hidden layers 1 .. NH-1: the first three are unrolled (distinct resident registers), the rest loop
                 auto hidden = [&](int l, auto res_c, auto base_c, auto lq_c) {
@@ -868,7 +873,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                         if (l == 1 && nhead) gen_noise(t);
                     }
                     if (l == 1) { TS(4) } else if (l == 2) { TS(8) } else { TS(9) }
-                    __syncthreads();
+                    XDL_LAYER_SYNC();
                     TS(5)
                 };
                 using IC0 = std::integral_constant<int, 0>;
