@@ -248,16 +248,6 @@ class DryRunPlanner:
             elapsed = float(t.item())
         return elapsed
 
-    def plan_device(self, c):
-        """One planner call on HBM-resident inputs.  Sharded: the model's own negotiation (`_sharding`: in-library RCCL communicator
-        on every rank, or -- all ranks together -- torch.distributed's all-gather per CEM iteration) decides the path."""
-        cp_obs, cp_act = (self.cp_obs, self.cp_act) if self.cfg["context"] else (None, None)
-        shard, fused = self.model._sharding()
-        if fused:
-            return self.eng.cem_plan(self.obs, cp_obs, cp_act, self.init_mean, self.init_var, self.n, seed=0, call=c)
-        from cadm_amd import planner as hplanner
-        return hplanner.cem_plan(self.eng, self.obs, cp_obs, cp_act, self.init_mean, self.init_var, self.n, seed=0, call=c, shard=shard)
-
     def run_api(self, steps, warmup):
         return self._timed(steps, warmup)
 
@@ -353,6 +343,16 @@ class Planner:
         for c in range(self.RAMP_PLANS):
             self.plan_device(c)
         torch.cuda.synchronize(eng.device)
+
+    def plan_device(self, c):
+        """One planner call on HBM-resident inputs.  Sharded: the model's own negotiation (`_sharding`: in-library RCCL communicator
+        on every rank, or -- all ranks together -- torch.distributed's all-gather per CEM iteration) decides the path."""
+        cp_obs, cp_act = (self.cp_obs, self.cp_act) if self.cfg["context"] else (None, None)
+        shard, fused = self.model._sharding()
+        if fused:
+            return self.eng.cem_plan(self.obs, cp_obs, cp_act, self.init_mean, self.init_var, self.n, seed=0, call=c)
+        from cadm_amd import planner as hplanner
+        return hplanner.cem_plan(self.eng, self.obs, cp_obs, cp_act, self.init_mean, self.init_var, self.n, seed=0, call=c, shard=shard)
 
     def run_api(self, steps, warmup):
         """K get_action calls through the class, warm start shifted between calls (sampler.py:118-120)."""
