@@ -51,10 +51,21 @@ class HipEngine:
         self._check = lambda rc, what="": check(rc, what, self.lib)
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         hs = tuple(int(h) for h in hidden_sizes)
-        if len(set(hs)) != 1:
-            raise ValueError("hidden_sizes must all be equal, got %r" % (hs,))
+        if len(hs) < 1 or min(hs) < 1:
+            raise ValueError("hidden_sizes must be positive, got %r" % (hs,))
+        # Unequal hidden widths (the reference accepts any tuple, dynamics.py:28): the library works on ONE width, the widest
+        # layer's, and the narrower layers are ZERO-PADDED to it -- a padded unit has zero weights and bias on both sides, so it
+        # contributes nothing to any layer, its pre-activation is 0 and (for every nonlinearity with act(0) = 0) so is its
+        # output: all its gradients are exactly 0, weight decay included, and Adam leaves an exact zero where it is.  The
+        # padded tensors are what the library sees; `param_shapes_true` / `params_list` / `load_params_list` speak the model's
+        # own shapes (checkpoints are the reference's).  sigmoid(0) = 0.5 would put gradient on the padded weights: refused.
+        self.hidden_sizes = hs
+        self._padded = len(set(hs)) != 1
+        if self._padded and hidden_nonlinearity == "sigmoid":
+            raise NotImplementedError("unequal hidden_sizes %r with hidden_nonlinearity='sigmoid': zero-padded units would train "
+                                      "(sigmoid(0) != 0); use equal widths or swish / relu / tanh / None" % (hs,))
         self.env_kind, self.E, self.p, self.D, self.A, self.P, self.C = env_kind, E, p, D, A, P, C
-        self.H, self.NH, self.HID = H, len(hs), hs[0]
+        self.H, self.NH, self.HID = H, len(hs), max(hs)
         self.Hh = history_length
         self.cp_hidden_sizes = tuple(cp_hidden_sizes)
         self.deterministic, self.discrete = bool(deterministic), bool(discrete)
@@ -141,6 +152,34 @@ class HipEngine:
             names.append("backward_model")
         return names   # = variable-scope creation order (dynamics.py:140,159,213)
 
+    def param_shapes_true(self, net):
+        """The model's own tensor shapes (the reference's checkpoint layout) -- differ from `param_shapes` (what the library
+        holds) only for unequal hidden widths, which are zero-padded to the widest layer."""
+        shapes = self.param_shapes(net)
+        if net == "context_model" or not self._padded:
+            return shapes
+        E, hs = self.E, self.hidden_sizes
+        sizes = [self.K0] + list(hs)
+        for i in range(self.NH):
+            shapes["hidden_%d_weight" % i] = (E, sizes[i], sizes[i + 1])
+            shapes["hidden_%d_bias" % i] = (E, 1, sizes[i + 1])
+        for head in ("output_mu", "output_logvar"):
+            shapes[head + "_weight"] = (E, hs[-1], self.D)
+        return shapes
+
+    def _pad(self, net, name, arr):
+        """Model-shaped array -> library-shaped (zero-padded) array; library-shaped input passes through."""
+        want, true = self.param_shapes(net)[name], self.param_shapes_true(net)[name]
+        a = np.asarray(arr) if not isinstance(arr, torch.Tensor) else arr
+        if tuple(a.shape) == tuple(want) or tuple(a.shape) != tuple(true):
+            return arr
+        if isinstance(a, torch.Tensor):
+            out = torch.zeros(want, dtype=a.dtype, device=a.device)
+        else:
+            out = np.zeros(want, dtype=a.dtype)
+        out[tuple(slice(0, n) for n in true)] = a
+        return out
+
     def param_shapes(self, net):
         E = self.E
         shapes = OrderedDict()
@@ -168,7 +207,7 @@ class HipEngine:
         (core/utils.py:338-339,636-641)."""
         for net in self.net_names():
             params = OrderedDict()
-            for name, shape in self.param_shapes(net).items():
+            for name, shape in self.param_shapes_true(net).items():      # (true fan-in for the initialiser; set_net pads)
                 if name == "max_logvar":
                     v = np.ones(shape) / 2.0
                 elif name == "min_logvar":
@@ -192,7 +231,7 @@ class HipEngine:
         cur = self.nets.get(net)
         out = OrderedDict()
         for name, shape in shapes.items():
-            t = self._t(params[name])
+            t = self._t(self._pad(net, name, params[name]))
             if tuple(t.shape) != tuple(shape):
                 raise ValueError("%s/%s: shape %r != %r" % (net, name, tuple(t.shape), tuple(shape)))
             if cur is not None:     # keep registered device pointers stable
@@ -228,8 +267,10 @@ class HipEngine:
         (context_model, ff_model, backward_model; dynamics.py:266)."""
         out = []
         for net in self.net_names():
-            for t in self.nets[net].values():
-                out.append(t.detach().cpu().numpy().copy())
+            true = self.param_shapes_true(net)
+            for name, t in self.nets[net].items():
+                a = t.detach().cpu().numpy()
+                out.append(a[tuple(slice(0, n) for n in true[name])].copy())      # (padding of unequal hidden widths stripped)
         return out
 
     def load_params_list(self, arrays):
