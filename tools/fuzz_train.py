@@ -5,8 +5,9 @@ python tools/fuzz_train.py [seconds] [seed]
 Every round draws a random configuration (env kind, context encoder and its widths, backward model, deterministic /
 probabilistic, ensemble size, ragged batch size, hidden width incl. widths the planner is not compiled for, history length) and
 checks (i) the forward losses [mse, back_mse, recon] against the fp64 oracle, (ii) every gradient tensor of the hand-written
-backward pass -- exposed as (w_before - w_after) by one linearised Adam step -- against torch.autograd on the oracle, and
-that variables without a gradient do not move.  Same bars as tests/test_gpu_train.py."""
+backward pass -- read back directly (Adam's first moment after one step with beta1 = 0, developer library) -- element by
+element against torch.autograd on the oracle (<= 1e-5 of the tensor's max), and that variables without a gradient do not move.
+Hidden widths are drawn per layer now and then (zero-padded in the engine).  Same bars as tests/test_gpu_train.py."""
 import os
 import sys
 import time
@@ -17,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
 
-from cadm_amd import synth
+from cadm_amd import _lib, synth
 from oracle import train as otrain
 
 ENVS = ["halfcheetah", "cripple_halfcheetah", "ant", "slim_humanoid", "pendulum", "cartpole"]
@@ -35,15 +36,16 @@ def main():
         det = bool(rng.integers(3) == 0)
         E, B = int(rng.choice([1, 2, 3, 5])), int(rng.integers(1, 300))
         hid = int(rng.choice([64, 96, 128, 200, 256]))
+        hids = (hid,) * 4 if rng.integers(4) else tuple(int(rng.choice([48, 64, 96, 128, 200])) for _ in range(4))      # unequal now and then
         ncp = int(rng.integers(1, 4))
         cph = tuple(int(rng.choice([8, 24, 64, 130])) for _ in range(ncp))
         Hh = int(rng.integers(1, 6))
-        prob = synth.make_problem(env=env, context=context, E=E, trained_like=True, with_back=with_back, hidden_sizes=(hid,) * 4,
+        prob = synth.make_problem(env=env, context=context, E=E, trained_like=True, with_back=with_back, hidden_sizes=hids,
                                   cp_hidden_sizes=cph, Hh=Hh, seed=int(rng.integers(1 << 30)))
         cwd = tuple(0.00003 * (i + 1) for i in range(ncp + 1))
         cfg = dict(deterministic=det, back_coeff=0.5 if with_back else 0.0, weight_decay_coeff=1.0, weight_decays=WD,
                    context_weight_decays=cwd, n_hidden=4, n_cp_hidden=ncp)
-        tag = "%s ctx=%d back=%d det=%d E=%d B=%d hid=%d cp=%s Hh=%d" % (env, context, with_back, det, E, B, hid, cph, Hh)
+        tag = "%s ctx=%d back=%d det=%d E=%d B=%d hid=%s cp=%s Hh=%d" % (env, context, with_back, det, E, B, hids, cph, Hh)
         batch = synth.make_train_batch(prob, B=B, seed=int(rng.integers(1 << 30)))
         keys = ["obs", "act", "delta"] + (["obs_next", "back_delta"] if with_back else []) + (["cp_obs", "cp_act"] if context else [])
         nets64 = lambda rg: (otrain.to_torch(prob["ff"], torch.float64, rg),
@@ -62,24 +64,25 @@ def main():
         assert el <= 1e-4, "%s: losses %r vs %r" % (tag, got, want)
         worst_l = max(worst_l, el)
         eng.close()
-        # (ii) gradients through one linearised Adam step
-        eng = synth.make_engine(prob, p=E, deterministic=det)
-        eng.train_configure(1e6, WD, cwd, 1.0, cfg["back_coeff"], max_batch=B, beta1=0.0, beta2=0.0, epsilon=1e6)
+        # (ii) gradients, read back directly
+        eng = synth.make_engine(prob, p=E, deterministic=det, lib=_lib.load_dev())
+        eng.train_configure(1e-3, WD, cwd, 1.0, cfg["back_coeff"], max_batch=B, beta1=0.0)
         before = {n: {k: v.clone() for k, v in eng.nets[n].items()} for n in eng.net_names()}
         eng.train_step({k: eng._t(batch[k]) for k in keys}, train=True)
         ff, back, cp = nets64(True)
         out = otrain.train_losses(env, ff, back, cp, st, tb, cfg)
         grads = otrain.grads_of(out["loss"], {"ff_model": ff, "backward_model": back, "context_model": cp})
         for net in eng.net_names():
+            true = eng.param_shapes_true(net)
             for name, w0 in before[net].items():
                 g_ref = grads[net][name]
-                g_hip = (w0 - eng.nets[net][name]).cpu().numpy().astype(np.float64)
                 if g_ref is None:
-                    assert np.abs(g_hip).max() == 0.0, "%s: %s/%s moved although it has no gradient" % (tag, net, name)
+                    assert torch.equal(w0, eng.nets[net][name]), "%s: %s/%s moved although it has no gradient" % (tag, net, name)
                     continue
+                g_hip = eng.dev_read_adam_moment(net, name).cpu().numpy().astype(np.float64)[tuple(slice(0, k) for k in true[name])]
                 g_ref = g_ref.numpy()
-                err = float(np.abs(g_hip - g_ref).max() / max(np.abs(g_ref).max(), 1e-12))
-                assert err < 2e-3, "%s: %s/%s gradient off: %.3e" % (tag, net, name, err)
+                err = float(np.abs(g_hip - g_ref).max() / max(np.abs(g_ref).max(), 1e-300))
+                assert err <= 1e-5, "%s: %s/%s gradient off: %.3e of the tensor's max" % (tag, net, name, err)
                 worst_g = max(worst_g, err)
         eng.close()
         rounds += 1
