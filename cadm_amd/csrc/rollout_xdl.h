@@ -36,7 +36,12 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 #ifndef CADM_XDL_RING
 #define CADM_XDL_RING 4
 #endif
-#ifdef CADM_XDL_EXPERIMENT_NOBAR     // TIMING EXPERIMENT ONLY (wrong results): what the layer barriers cost
+// TIMING EXPERIMENTS ONLY (tools/build_variant.sh; wrong results, never in the product build): what a part of the kernel costs.
+//   CADM_XDL_EXPERIMENT_NOBAR   no barriers between the dense layers (an upper bound for any finer-grained layer hand-off)
+//   CADM_XDL_EXPERIMENT_NOMFMA  the sweeps issue no MFMAs (everything else -- streams, LDS traffic, epilogues, state phase -- stays)
+//   CADM_XDL_EXPERIMENT_NOSTREAM the streamed weight fragments are not loaded (the ring keeps stale registers)
+//   CADM_XDL_EXPERIMENT_NOEPI   the hidden tiles' epilogue arithmetic is skipped (stages 0-4: nonlinearity and f16 split; the LDS store stays)
+#ifdef CADM_XDL_EXPERIMENT_NOBAR
 #define XDL_LAYER_SYNC() ((void)0)
 #else
 #define XDL_LAYER_SYNC() __syncthreads()
@@ -128,6 +133,14 @@ struct XC {
     // (one row tile: a lookahead of 2 chunks bought nothing measurable, and its 8 registers are worth one more resident
     //  fragment: every streamed fragment costs ~0.6 us per launch at cfg2 -- the L2 -> CU weight stream is what the one-tile kernel waits for)
     static constexpr int XDEPTH = 2;                       // B-operand chunks in registers (lookahead XDEPTH - 1)
+    // One-tile sweeps (the head tile; the hidden tiles of the waves that own one): a chunk is 3 MFMAs = 48 cycles of this wave's
+    // own work against ~130 cycles of LDS latency, so with one chunk of lookahead the sweep runs at the LDS latency (7 x 130
+    // cycles where the MFMAs need 336) -- and the HEAD sweep is on the step's critical path (every other wave waits for it:
+    // profiles/r4_phase_timing_skeleton.txt).  They keep more operand chunks in flight.
+#ifndef CADM_XDL_XD1
+#define CADM_XDL_XD1 2      // (measured, same box: 3 / 4 chunks +-0, 7 chunks +1 %: the head is not waiting for its operands)
+#endif
+    static constexpr int XDEPTH1 = MT > 1 ? 2 : CADM_XDL_XD1;
     // LDS-resident weight fragments: what is left of the 160 KiB (at horizons <= 128; one row tile per workgroup) holds the LAST
     // LQ_SLOTS fragments of hidden layers 1..3 of every wave with two or more tiles -- the waves a layer waits for.  The one-tile
     // kernel is bound by the L2 -> CU weight stream (every streamed fragment costs ~0.6 us per launch at cfg2).
@@ -150,8 +163,12 @@ struct XRing {
 
 template <int SLOT, class G>
 __device__ __forceinline__ void xring_load(XRing<G>& ring, __amdgpu_buffer_rsrc_t rsrc, unsigned soff, int lane) {
+#ifdef CADM_XDL_EXPERIMENT_NOSTREAM      // (timing experiment: the L2 -> CU weight stream is not issued; the ring holds whatever it held)
+    asm volatile("" : "+v"(ring.w[SLOT][0]), "+v"(ring.w[SLOT][1]));
+#else
     ring.w[SLOT][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, soff, 0);
     ring.w[SLOT][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16 + 1024, soff, 0);
+#endif
 }
 
 __device__ __forceinline__ floatx4 xmfma(uintx4 a, f16x8 b, floatx4 c) {
@@ -171,7 +188,11 @@ __device__ __forceinline__ void xres_load(uintx4& dst, __amdgpu_buffer_rsrc_t rs
                  : "=a"(dst) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
 }
 __device__ __forceinline__ void xmfma_res(floatx4& acc, const uintx4& w, const f16x8& x) {
+#ifdef CADM_XDL_EXPERIMENT_NOMFMA
+    asm volatile("" : "+v"(acc) : "a"(w), "v"(x));
+#else
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+#endif
 }
 // Streamed fragments (ring registers, VGPRs) go through the same asm form so that ALL MFMAs of a sweep keep their
 // accumulators in VGPRs: a mix of asm and builtin MFMAs makes hipcc shuttle accumulators between VGPRs and AGPRs
@@ -185,8 +206,12 @@ __device__ __forceinline__ void xmfma_res(floatx4& acc, const uintx4& w, const f
 // cycles hide behind the SIMD's other wave: measured neutral.
 template <bool ASM>
 __device__ __forceinline__ void xmfma_ring(floatx4& acc, const uintx4& w, const f16x8& x) {
+#ifdef CADM_XDL_EXPERIMENT_NOMFMA
+    asm volatile("" : "+v"(acc) : "v"(w), "v"(x));
+#else
     if constexpr (ASM) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
     else acc = xmfma(w, x, acc);
+#endif
 }
 // Hazard padding the compiler cannot place for asm MFMAs.  The accumulators are "+v" operands of the padding statement,
 // so every instruction that defines them (the zeroing moves) stays before it and every reader (the epilogue) after it.
@@ -235,6 +260,12 @@ struct XHiddenEpi {
     static __device__ __forceinline__ floatx2 hi2(const floatx4& x) { return __builtin_shufflevector(x, x, 2, 3); }
     template <int S>
     __device__ __forceinline__ void stage(int ti, int hh, const floatx4& hi, const floatx4& lo, const floatx4& ll, State& st) const {
+#ifdef CADM_XDL_EXPERIMENT_NOEPI
+        if constexpr (S < 5) {      // (one compare keeps the wait for the accumulators; the stored activations are zeros)
+            if constexpr (S == 0) { const _Float16 z = (_Float16)((hi[0] == 12345.678f && lo[0] == 1.5f) ? 1.0f : 0.0f); st.h1 = f16x4{z, z, z, z}; st.h2 = st.h1; }
+            return;
+        }
+#endif
         if constexpr (S == 0) {            // pre-activation (hi + 2^-11 lo), f16-range clamp, exp2 argument
             const floatx2 c11 = {4.8828125e-4f, 4.8828125e-4f}, c22 = {2.384185791015625e-7f, 2.384185791015625e-7f};
             constexpr float KE = G::ACT == CADM_ACT_TANH ? -2.0f * 1.4426950408889634f : -1.4426950408889634f;
@@ -343,7 +374,8 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
     constexpr int R = G::R, NF = NTW * NCHL, NFS = NF - NRES, NFSPAD = rup(NFS, R);
     static_assert(NRES >= 0 && NRES <= NF, "bad resident fragment count");
     static_assert(NLDS == 0 || NFS - NLDS >= R, "the first R ring fragments of a layer are streamed");
-    constexpr int MT = G::MT, XD = NCHL < G::XDEPTH ? NCHL : G::XDEPTH;
+    constexpr int MT = G::MT, XDW = (NTW == 1 && GS == 1 && !SIDE) ? G::XDEPTH1 : G::XDEPTH,      // (the head sweep)
+                   XD = NCHL < XDW ? NCHL : XDW;
     constexpr int IN_T = 2 * NCHL * 1024;                  // bytes of one row tile's operand block
     f16x8 X1[XD][MT], X2[XD][MT];
     auto xload = [&](auto cc) {
@@ -836,7 +868,10 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
             // One row tile: made here by the twin thread in waves 4-7, which have nothing else to do while waves 0-3 update
             // the state.  Two row tiles: every thread owns state and makes its own noise, but not here, where it would
             // lengthen the state phase that everything waits for -- see the hidden layers / the head below.
-            if constexpr (NOISE != CADM_NOISE_NONE && MT == 1) {
+#ifndef CADM_XDL_NOISE_IN_HIDDEN
+#define CADM_XDL_NOISE_IN_HIDDEN 0
+#endif
+            if constexpr (NOISE != CADM_NOISE_NONE && MT == 1 && !CADM_XDL_NOISE_IN_HIDDEN) {
                 if (ONED ? nzt : !feat) gen_noise(t);
             }
             TS(0)
@@ -871,6 +906,9 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                     // wait at this barrier anyway) make their noise now
                     if constexpr (NOISE != CADM_NOISE_NONE && MT > 1) {
                         if (l == 1 && nhead) gen_noise(t);
+                    }
+                    if constexpr (NOISE != CADM_NOISE_NONE && MT == 1 && CADM_XDL_NOISE_IN_HIDDEN) {      // (experiment: noise in the one-tile waves' slack)
+                        if (l == CADM_XDL_NOISE_IN_HIDDEN && (ONED ? nzt : !feat)) gen_noise(t);
                     }
                     if (l == 1) { TS(4) } else if (l == 2) { TS(8) } else { TS(9) }
                     XDL_LAYER_SYNC();

@@ -26,8 +26,8 @@ def main():
     cfg = synth.CONFIGS[cfgname]
     prob = synth.make_problem(env=cfg["env"], context=cfg["context"], E=cfg["E"], m=1, H=cfg["H"], seed=0)
     f32 = len(sys.argv) > 2 and sys.argv[2] == "f32"
-    eng = make_engine(prob, p=cfg["p"], deterministic=cfg["deterministic"],
-                      lib=_lib.load_dev(os.path.join(ROOT, "cadm_amd", "libcadm_hip_timing.so")))
+    libname = sys.argv[3] if len(sys.argv) > 3 else "libcadm_hip_timing.so"      # (a CADM_PHASE_TIMING build of an experiment variant)
+    eng = make_engine(prob, p=cfg["p"], deterministic=cfg["deterministic"], lib=_lib.load_dev(os.path.join(ROOT, "cadm_amd", libname)))
     if f32:
         eng.dev_set_rollout("f32")
     NW = 4 if f32 else 8
