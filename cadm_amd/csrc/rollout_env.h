@@ -7,17 +7,29 @@
 
 #ifdef CADM_PHASE_TIMING
 #define NPH 24
-#define TS_DECL unsigned long long ts_acc[NPH] = {}; unsigned long long ts_last = __builtin_amdgcn_s_memtime();
+#define TS_DECL unsigned long long ts_acc[NPH] = {}; unsigned long long ts_last = __builtin_amdgcn_s_memtime(); unsigned long long* ts_tr = nullptr;
 #define TS(i) { const unsigned long long ts_now = __builtin_amdgcn_s_memtime(); ts_acc[i] += ts_now - ts_last; ts_last = ts_now; }
 #define TS_DUMP if (a.tbuf && blockIdx.x == 0 && lane == 0) { for (int i = 0; i < NPH; ++i) a.tbuf[wave * NPH + i] = ts_acc[i]; }
-#define TS_PARAMS , unsigned long long (&ts_acc)[NPH], unsigned long long& ts_last
-#define TS_ARGS , ts_acc, ts_last
+#define TS_PARAMS , unsigned long long (&ts_acc)[NPH], unsigned long long& ts_last, unsigned long long* ts_tr
+#define TS_ARGS , ts_acc, ts_last, ts_tr
+// raw time stamps of ONE sweep (tools/sweep_trace.py): ts_tr points at this wave's 16 slots while that sweep runs
+// (stamps stay in SGPRs until the sweep ends: reading one back costs an lgkmcnt(0), which would also drain the LDS operand loads in flight)
+#define TR_DECL unsigned long long trv[12] = {};
+#define TR(i) { trv[i] = __builtin_amdgcn_s_memtime(); }
+#define TR_FLUSH { if (ts_tr) { _Pragma("unroll") for (int i_ = 0; i_ < 11; ++i_) ts_tr[i_] = trv[i_]; } }
+#define TR_LATE(i) { if (ts_tr) ts_tr[i] = __builtin_amdgcn_s_memtime(); }
+#define TR_ON(cond, w) { ts_tr = (a.tbuf && blockIdx.x == 0 && (cond)) ? a.tbuf + 8 * 24 + (w) * 16 : nullptr; }
 #else
 #define TS_DECL
 #define TS(i)
 #define TS_DUMP
 #define TS_PARAMS
 #define TS_ARGS
+#define TR(i)
+#define TR_DECL
+#define TR_FLUSH
+#define TR_LATE(i)
+#define TR_ON(cond, w)
 #endif
 
 namespace {

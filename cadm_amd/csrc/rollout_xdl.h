@@ -406,6 +406,8 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
     // stage s of the side epilogue goes to chunks >= 1, i.e. at least one chunk of MFMAs after the accumulators were
     // last written (the compiler cannot see asm MFMA latency)
     auto stage_chunk = [](int st) constexpr { return NCHL == 1 ? 0 : NST == 1 ? 1 : 1 + st * (NCHL - 2) / (NST - 1); };
+    TR_DECL
+    TR(0)
     static_for(std::make_integer_sequence<int, NG>{}, [&](auto gc) {
         constexpr int g = decltype(gc)::value, gp = g & 1, pp = gp ^ 1;
         constexpr int gs = (NTW - GS * g) < GS ? (NTW - GS * g) : GS;
@@ -451,6 +453,7 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
                     }
                 });
             }
+            if constexpr (g == NG - 1 && c < 8) { TR(1 + c) }
             __builtin_amdgcn_sched_barrier(0);      // pin the software pipeline: no load hoisting across chunks
         });
         if constexpr (g == NG - 1 || !SIDE) {       // the last group's epilogue has no MFMAs of this wave left to hide behind
@@ -469,6 +472,8 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
         }
     });
     TS(12)
+    TR(10)
+    TR_FLUSH
     static_for(std::make_integer_sequence<int, NFSPAD - NFS>{}, [&](auto jc) {
         prefetch(std::integral_constant<int, NFS + decltype(jc)::value>{});
     });
@@ -900,6 +905,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                     const int nx = next_streamed(l);
                     // (layers 1..3: distinct instantiations with their LDS-resident tail; deeper layers stream everything)
                     constexpr int NL = decltype(lq_c)::value ? LQ : 0;
+                    TR_ON(t == 10 && l == 2, wave)      // (CADM_PHASE_TIMING builds: raw stamps of this one sweep, tools/sweep_trace.py)
                     xdl_sweep<G, NTW, NCH, NRES, GSZ, !SEQ, NL>(ring, resH + RBASE, rsrc, lay_off(l), lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
                                                  hidden_epi(l, act_out), xsmem + lq_off + (l - 1) * LQ * CADM_XDL_FRAG_BYTES TS_ARGS);
                     // two row tiles: the waves that have a head tile (and one hidden tile less than the others: they would
@@ -912,6 +918,8 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                     }
                     if (l == 1) { TS(4) } else if (l == 2) { TS(8) } else { TS(9) }
                     XDL_LAYER_SYNC();
+                    TR_LATE(11)
+                    TR_ON(false, 0)
                     TS(5)
                 };
                 using IC0 = std::integral_constant<int, 0>;
