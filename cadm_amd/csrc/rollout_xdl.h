@@ -498,6 +498,11 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     const int sd = tid >> 4;                                    // ONED: dim slot 0..31 of this thread (arow = its row)
     const bool feat = ONED ? sd < D : (MT > 1 || wave < 4);
     const bool nzt = ONED && sd >= 32 - NP;                     // ONED: noise thread of pair sd - (32 - NP)
+    // ONED: the action features of x_in are not written in the state phase (where they lengthened the chain of the waves that
+    // own dims 0..A-1 -- the slowest waves of the phase every other wave waits for: 1640-1780 cycles against 1250 for the waves
+    // without them, profiles/r4_phase_timing_skeleton.txt) but one step AHEAD, by the last A dim slots (waves 6-7: one-tile
+    // waves) in the slack behind their hidden-layer-1 sweep: x_in is free from the barrier behind layer 0 on.
+    const bool actt = ONED && sd >= 32 - A;
     const int rt = MT > 1 ? (wave >> 2) : 0;                   // row tile of this thread's state
     const int ntiles = a.tile_count;                            // row tiles of this launch: [tile0, tile0 + tile_count) of the member
     float* stats = reinterpret_cast<float*>(xsmem + G::STATS);
@@ -523,6 +528,8 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         // one float4 per (tile, lane group): the copy of data row 0
         for (int i = tid; i < (XNH * G::NT + NTO) * 4; i += G::NTHR) reinterpret_cast<uintx4*>(xsmem + bias_off)[i] = src[(i >> 2) * 64 + (i & 3) * 16];
     }
+
+    __syncthreads();      // (the tile prologue writes context / action features into x_in from OTHER threads than the ones that zeroed it, and reads stats)
 
     // byte offset (part 0) of input feature f of row 0 inside x_in; row arow adds arow * 16
     auto xin_base = [&](int f) { return ((f >> 5) * 64 + ((f & 31) >> 3) * 16) * 16 + (f & 7) * 2; };
@@ -691,13 +698,26 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         else ctx_off = (ep * a.m + mi) * C;                              // Q1: encoder j % E
 
         float po[NPI][2], areg[NAI];
+        // ONED action threads: write step tt's (normalised, split) action feature from areg, then fetch step tt + 1's.
+        // (everything is recomputed from an opaque copy of the dim slot: nothing of it is hoisted out of the step loop to sit in
+        //  registers through the sweeps, where there are none to spare)
+        auto act_put = [&](int tt) {
+            int sda = tid >> 4;
+            asm volatile("" : "+v"(sda));
+            const int ai = sda - (32 - A);
+            float v = areg[0];
+            if (a.norm_actions) v = (v - stats[G::ST_ACT_MEAN + ai]) * stats[G::ST_ACT_DEN + ai];   // :443
+            put_x(xin_off(P + ai), v);
+            if (tt + 1 < H) areg[0] = a.actions[abase + (tt + 1) * A + ai];
+        };
         if constexpr (ONED) {
             po[0][0] = feat ? (a.obs_rows ? a.obs_rows[(size_t)lr * D + sd] : a.obs[mi * D + sd]) : 0.0f;      // :432
             po[0][1] = 0.0f;
-            areg[0] = sd < A ? a.actions[abase + sd] : 0.0f;
+            areg[0] = actt ? a.actions[abase + sd - (32 - A)] : 0.0f;
             if constexpr (C > 0) {
                 for (int f = P + A + sd; f < K0; f += 32) put_x(xin_off(f), a.ctx_vec[ctx_off + f - P - A]);      // static: context (:433-439)
             }
+            if (actt) act_put(0);      // step 0's action features; areg then holds step 1's
             for (int t = sd; t < H; t += 32) ctrl_s[arow * H + t] = ctrl_term<ENV>(a.actions + abase + t * A, A);
         } else {
 #pragma unroll
@@ -779,12 +799,6 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                                 const float pv = op == 1 ? sn : op == 2 ? cs : po[0][0];
                                 put_x(off + arow16, (pv - tv(5 + i)) * tv(7 + i));               // :450-451
                             }
-                        }
-                        if (sd < A) {
-                            float v = areg[0];
-                            if (a.norm_actions) v = (v - stats[G::ST_ACT_MEAN + sd]) * stats[G::ST_ACT_DEN + sd];   // :443
-                            put_x(xin_off(P + sd), v);
-                            if (t + 1 < H) areg[0] = a.actions[abase + (t + 1) * A + sd];
                         }
                     }
                 }
@@ -916,6 +930,9 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                     if constexpr (NOISE != CADM_NOISE_NONE && MT == 1 && CADM_XDL_NOISE_IN_HIDDEN) {      // (experiment: noise in the one-tile waves' slack)
                         if (l == CADM_XDL_NOISE_IN_HIDDEN && (ONED ? nzt : !feat)) gen_noise(t);
                     }
+                    if constexpr (ONED) {      // next step's action features (see actt)
+                        if (l == 1 && actt && t + 1 < H) act_put(t + 1);
+                    }
                     if (l == 1) { TS(4) } else if (l == 2) { TS(8) } else { TS(9) }
                     XDL_LAYER_SYNC();
                     TR_LATE(11)
@@ -985,6 +1002,16 @@ __global__ __launch_bounds__(G::NTHR) void rollout_xdl_kernel(const RolloutArgs 
     // and waves 4-7 go tile by tile (xdl_geo.h: xdl_group)
     constexpr int HALF = G::NW / 2;
     const bool seq = CADM_XDL_SEQ && wave >= HALF;
+    // Static issue priority for the second-dispatched wave of every SIMD (waves 4-7): VALU issue between the two waves of a SIMD is
+    // arbitrated by priority, then AGE, so the younger wave loses every contested slot and is the last to reach each layer's barrier
+    // (profiles/r3_c_phase_timing_cfg3.txt: wave 4).  Measured, same box, interleaved (profiles/r4_s3_experiments.md): two row tiles
+    // -1.5 % (1343 -> 1322 us at cfg3), one row tile +-0.3 % (left alone there); priority for the OLDER half instead: +0.5 % / -0.2 %.
+#ifndef CADM_XDL_PRIO
+#define CADM_XDL_PRIO (G::MT > 1 ? 1 : 0)
+#endif
+    if constexpr ((CADM_XDL_PRIO) != 0) {
+        if ((CADM_XDL_PRIO) > 0 ? wave >= HALF : wave < HALF) __builtin_amdgcn_s_setprio((CADM_XDL_PRIO) > 0 ? (CADM_XDL_PRIO) : -(CADM_XDL_PRIO));
+    }
     if (wave < G::EXTRA) {
         if constexpr (G::EXTRA > 0) {
             if (!seq) xdl_run<G, NOISE, G::BASE + 1, false>(a, xsmem_raw);
