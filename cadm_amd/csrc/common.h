@@ -27,7 +27,7 @@ void cadm_set_error(const char* fmt, ...);
 #define CADM_HID_LIST 200              // the reference default --hidden_size (run_cadm_pets.py:129)
 #endif
 // bumped whenever cadm_ctx / RolloutArgs change: a side module built against another layout is refused
-#define CADM_CTX_LAYOUT_TAG 3002
+#define CADM_CTX_LAYOUT_TAG 3003
 
 #define CADM_CHECK_HIP(expr)                                                                   \
     do {                                                                                       \
@@ -149,6 +149,9 @@ struct cadm_ctx {
     // RCCL communicator for candidate-sharded planning (dist.hip)
     void* comm = nullptr;
     int nranks = 1, rank = 0;
+    // second packed copy of the planner weights for the wave-tile kernel (rollout_wt.h): ONE consumption order for every wave
+    XdlGeo xg1;
+    unsigned short* xw1 = nullptr;  // [E][member_frags of xg1] fragments of 2 KB
 };
 
 // Entry points launch on the ctx's device whatever device the caller's thread has current (two engines on different GPUs in

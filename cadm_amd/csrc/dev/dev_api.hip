@@ -46,7 +46,7 @@ static int rollout_f32(cadm_ctx* ctx, const RolloutArgs& a0, int rpm, hipStream_
 extern "C" int cadm_dev_set_rollout(cadm_ctx* ctx, int kind, int row_tiles) {
     CADM_REQUIRE(ctx, "cadm_dev_set_rollout: null ctx");
     CADM_REQUIRE(kind == CADM_DEV_ROLLOUT_XDL || kind == CADM_DEV_ROLLOUT_F32, "cadm_dev_set_rollout: unknown kind %d", kind);
-    CADM_REQUIRE(row_tiles >= 0 && row_tiles <= 2, "cadm_dev_set_rollout: row_tiles must be 0 (launcher's choice), 1 or 2");
+    CADM_REQUIRE(row_tiles >= 0 && row_tiles <= 4, "cadm_dev_set_rollout: row_tiles must be 0 (launcher's choice), 1 or 2 (cooperative kernel), 3 / 4 (wave-tile kernel, 8 / 4 tiles per workgroup)");
     ctx->dev_force_mt = row_tiles;
     if (kind == CADM_DEV_ROLLOUT_F32) {
         ctx->dev_rollout = rollout_f32;

@@ -120,6 +120,13 @@ int cadm_pack_xdl(cadm_ctx* ctx, hipStream_t s) {
     CADM_CHECK_HIP(hipMemsetAsync(ctx->xflag, 0, sizeof(int), s));
     const size_t total = (size_t)ctx->xg.member_frags() * 1024 * ctx->E;
     hipLaunchKernelGGL(pack_xdl_kernel, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, s, a);
+    {      // the same weights in the wave-tile kernel's order (one wave owns every tile: rollout_wt.h)
+        XdlPackArgs a1 = a;
+        a1.dst = ctx->xw1;
+        a1.g = ctx->xg1;
+        const size_t total1 = (size_t)ctx->xg1.member_frags() * 1024 * ctx->E;
+        hipLaunchKernelGGL(pack_xdl_kernel, dim3((unsigned)((total1 + 255) / 256 < 8192 ? (total1 + 255) / 256 : 8192)), dim3(256), 0, s, a1);
+    }
     const size_t btotal = (size_t)ctx->xg.bias_tiles() * 256 * ctx->E;
     hipLaunchKernelGGL(pack_xdl_bias_kernel, dim3((unsigned)((btotal + 255) / 256)), dim3(256), 0, s, a);
     CADM_CHECK_HIP(hipGetLastError());

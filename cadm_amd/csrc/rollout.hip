@@ -23,6 +23,8 @@ int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, 
     a.xw_member_b = (unsigned)((size_t)ctx->xg.member_frags() * CADM_XDL_FRAG_BYTES);
     for (int w = 0, off = 0; w < CADM_XDL_WAVES; ++w) { a.xw_wave_b[w] = (unsigned)off; off += ctx->xg.wave_frags(w) * CADM_XDL_FRAG_BYTES; }
     a.xb = ctx->xb;
+    a.xw1 = ctx->xw1;
+    a.xw1_member_b = (unsigned)((size_t)ctx->xg1.member_frags() * CADM_XDL_FRAG_BYTES);
     a.xb_member = (size_t)ctx->xg.bias_tiles() * 256;
     a.obs = obs; a.obs_rows = obs_rows; a.ctx_vec = ctx_vec; a.actions = actions; a.eps = eps;
     a.obs_mean = ctx->st.obs_mean; a.obs_std = ctx->st.obs_std;

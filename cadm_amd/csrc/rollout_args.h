@@ -23,4 +23,7 @@ struct RolloutArgs {
     int bias_lds;                     // xdl kernel: bias tiles staged in LDS
     int dry_run;                      // launcher: validate the geometry (LDS, instantiation) without launching
     unsigned long long* tbuf;   // CADM_PHASE_TIMING builds only
+    const unsigned short* xw1;        // wave-tile kernel (rollout_wt.h): the fragment stream in its one-wave order
+    unsigned xw1_member_b;
+    int wt_waves;                     // wave-tile kernel: row tiles (= active waves) per workgroup and round
 };

@@ -1065,34 +1065,101 @@ int xdl_launch_mt(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, hipS
     }
 }
 
-// Two row tiles per workgroup once every workgroup has at least two tiles to walk over.  The member's tiles are then cut
-// in two launches so that no workgroup idles through a whole two-tile round: the first takes as many FULL rounds of tile
-// pairs as there are (every workgroup the same number), the second the remainder -- as single tiles (one-tile flavour) if
-// they fit one round, else as one more round of pairs.  Rows are independent, so the cut does not change any result.
+}  // namespace
+
+#include "rollout_wt.h"
+
+namespace {
+
+// A member's row tiles are cut between the kernel flavours, launch after launch (rows are independent and the flavours agree bit
+// for bit, so the cut changes no result):
+//   cooperative, one row tile per workgroup  (cap = one tile per CU of the member's share: cfg2)         cost 1
+//   cooperative, two row tiles per workgroup (cap 2x)                                                    cost CADM_COST_MT2
+//   wave-tile, 4 tiles per workgroup (one wave per SIMD; cap 4x)                                         cost CADM_COST_WT4
+//   wave-tile, 8 tiles per workgroup (cap 8x, any number of rounds)                                      cost CADM_COST_WT8 per round
+// (costs in units of the one-tile launch, measured at the cfg2 / cfg3 geometry, halfcheetah, 51 workgroups per member: 158 / 265 / 730 /
+// 920 us -- profiles/r4_wave_tile.md; one wave per SIMD does not hide its own LDS and VALU latencies, so the 4-tile form never wins and
+// exists for the tests).  The cheapest cover of the member's tiles is a small dynamic programme over units of one CU share.
+#ifndef CADM_COST_MT2
+#define CADM_COST_MT2 1.68f
+#endif
+#ifndef CADM_COST_WT4
+#define CADM_COST_WT4 4.6f
+#endif
+#ifndef CADM_COST_WT8
+#define CADM_COST_WT8 5.85f
+#endif
 template <int ENV, int C, int HID, int NH, int ACT, int NOISE = -1>
 int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a0, int rows_per_member, hipStream_t s) {
     using G1 = XC<ENV, C, HID, 1, NH, ACT>;
     using G2 = XC<ENV, C, HID, 2, NH, ACT>;
+    using W = WT<G1>;
     RolloutArgs a = a0;
     const int tiles = (rows_per_member + 15) / 16;
     int per_member = ctx->n_cus / ctx->E;
     if (per_member < 1) per_member = 1;
+    // (wide layers / long horizons: two tiles' activation buffers / the wave-tile kernel's ring do not fit the 160 KiB of LDS)
+    const bool mt2_ok = G2::lds_bytes(a0.H) <= 160 * 1024;
+    const bool wt_ok = W::AVAILABLE && W::lds_bytes(a0.H) <= 160 * 1024;
     a.tile0 = 0;
     a.tile_count = tiles;
-    int flavour = tiles >= 2 * per_member ? 2 : 1;
-    if (ctx->dev_force_mt) flavour = ctx->dev_force_mt == 2 ? -2 : -1;       // developer library only (dev/dev_api.hip): one launch, forced flavour
-    // (wide layers / long horizons: two tiles' activation buffers do not fit the 160 KiB of LDS -- one tile per workgroup then)
-    if (G2::lds_bytes(a0.H) > 160 * 1024) flavour = flavour < 0 ? -1 : 1;
-    if (flavour == 1 || flavour == -1) return xdl_launch_mt<G1, NOISE>(ctx, a, rows_per_member, s);
-    if (flavour == -2) return xdl_launch_mt<G2, NOISE>(ctx, a, rows_per_member, s);
-    const int full = (tiles / (2 * per_member)) * 2 * per_member;         // tiles in full rounds of pairs
-    a.tile_count = full;
-    int rc = xdl_launch_mt<G2, NOISE>(ctx, a, rows_per_member, s);
-    if (rc || full == tiles) return rc;
-    a.tile0 = full;
-    a.tile_count = tiles - full;
-    return a.tile_count <= per_member ? xdl_launch_mt<G1, NOISE>(ctx, a, rows_per_member, s)
-                                      : xdl_launch_mt<G2, NOISE>(ctx, a, rows_per_member, s);
+    if (ctx->dev_force_mt) {            // developer library only (dev/dev_api.hip): ONE launch of the forced flavour
+        const int f = ctx->dev_force_mt;
+        if (f >= 3) {
+            if constexpr (W::AVAILABLE) { if (wt_ok) return wt_launch<G1, NOISE>(ctx, a, rows_per_member, f == 3 ? 8 : 4, s); }
+            cadm_set_error("rollout: the wave-tile kernel does not exist for this geometry (hidden %d, horizon %d)", HID, a0.H);
+            return CADM_EINVAL;
+        }
+        if (f == 2 && mt2_ok) return xdl_launch_mt<G2, NOISE>(ctx, a, rows_per_member, s);
+        return xdl_launch_mt<G1, NOISE>(ctx, a, rows_per_member, s);
+    }
+    if (a0.dry_run) {                   // cadm_rollout_check: every flavour the launcher may pick must exist and fit
+        int rc = xdl_launch_mt<G1, NOISE>(ctx, a, rows_per_member, s);
+        if (!rc && mt2_ok) rc = xdl_launch_mt<G2, NOISE>(ctx, a, rows_per_member, s);
+        if constexpr (W::AVAILABLE) { if (!rc && wt_ok) rc = wt_launch<G1, NOISE>(ctx, a, rows_per_member, 8, s); }
+        return rc;
+    }
+    // cheapest cover of the member's tiles, in units of per_member tiles: f(u) = min over flavours (cost + f(u - cap))
+    const int units = (tiles + per_member - 1) / per_member;
+    const int capu[4] = {1, mt2_ok ? 2 : 0, wt_ok ? 4 : 0, wt_ok ? 8 : 0};
+    const float cost[4] = {1.0f, CADM_COST_MT2, CADM_COST_WT4, CADM_COST_WT8};
+    int count[4] = {0, 0, 0, 0};
+    {
+        // beyond 64 units the answer is "8-tile rounds of the best flavour" plus the plan of the rest
+        const int big = capu[3] ? 3 : capu[1] ? 1 : 0;
+        int u = units;
+        if (u > 64) { const int k = (u - 56) / capu[big]; count[big] += k; u -= k * capu[big]; }
+        float f[65];
+        int pick[65];
+        f[0] = 0.0f;
+        pick[0] = -1;
+        for (int v = 1; v <= u; ++v) {
+            f[v] = 1e30f;
+            for (int o = 0; o < 4; ++o) {
+                if (!capu[o]) continue;
+                const float c = cost[o] + f[v > capu[o] ? v - capu[o] : 0];
+                if (c < f[v] - 1e-6f) { f[v] = c; pick[v] = o; }
+            }
+        }
+        for (int v = u; v > 0; v -= capu[pick[v]]) ++count[pick[v]];
+    }
+    int rem = tiles, t0 = 0;
+    for (int o = 3; o >= 0 && rem > 0; --o) {      // biggest flavour first: the last launch takes the ragged rest
+        if (!count[o]) continue;
+        const int cover = rem < count[o] * capu[o] * per_member ? rem : count[o] * capu[o] * per_member;
+        a.tile0 = t0;
+        a.tile_count = cover;
+        int rc = CADM_EINVAL;
+        if (o == 0) rc = xdl_launch_mt<G1, NOISE>(ctx, a, rows_per_member, s);
+        else if (o == 1) rc = xdl_launch_mt<G2, NOISE>(ctx, a, rows_per_member, s);
+        else {
+            if constexpr (W::AVAILABLE) rc = wt_launch<G1, NOISE>(ctx, a, rows_per_member, o == 2 ? 4 : 8, s);
+        }
+        if (rc) return rc;
+        t0 += cover;
+        rem -= cover;
+    }
+    return CADM_OK;
 }
 
 }  // namespace

@@ -42,9 +42,10 @@ __host__ __device__ constexpr int xdl_kernel_hid(int hid) { return hid < CADM_XD
 struct XdlGeo {
     int K0, HID, D, NH, HIDR;
     int NC0, NT, NCH, NTO, BASE, EXTRA, NTOW;
+    int NW;      // waves the tiles are dealt to: CADM_XDL_WAVES (cooperative kernel), 1 (wave-tile kernel, rollout_wt.h: every wave owns ALL tiles)
     __host__ __device__ int ntw(int w) const { return BASE + (w < EXTRA ? 1 : 0); }
     __host__ __device__ int tstart(int w) const { return w * BASE + (w < EXTRA ? w : EXTRA); }
-    __host__ __device__ int head_tile(int w, int s) const { return (CADM_XDL_WAVES - 1 - w) + CADM_XDL_WAVES * s; }          // slot s of wave w (valid if < NTO)
+    __host__ __device__ int head_tile(int w, int s) const { return (NW - 1 - w) + NW * s; }          // slot s of wave w (valid if < NTO)
     __host__ __device__ int nhead(int w) const {
         int n = 0;
         for (int s = 0; s < NTOW; ++s) n += head_tile(w, s) < NTO ? 1 : 0;
@@ -53,23 +54,24 @@ struct XdlGeo {
     __host__ __device__ int wave_frags(int w) const { return ntw(w) * NC0 + (NH - 1) * ntw(w) * NCH + nhead(w) * NCH; }
     __host__ __device__ int member_frags() const {
         int n = 0;
-        for (int w = 0; w < CADM_XDL_WAVES; ++w) n += wave_frags(w);
+        for (int w = 0; w < NW; ++w) n += wave_frags(w);
         return n;
     }
     __host__ __device__ int bias_tiles() const { return NH * NT + NTO; }
 };
 
-inline XdlGeo make_xdl_geo(int K0, int hid_model, int D, int NH) {
+inline XdlGeo make_xdl_geo(int K0, int hid_model, int D, int NH, int nw = CADM_XDL_WAVES) {
     XdlGeo g;
+    g.NW = nw;
     const int HID = xdl_kernel_hid(hid_model);
     g.K0 = K0; g.HID = HID; g.HIDR = hid_model; g.D = D; g.NH = NH;
     g.NC0 = (K0 + 31) / 32;
     g.NT = (HID + 15) / 16;
     g.NCH = (g.NT + 1) / 2;
     g.NTO = (D + 7) / 8;
-    g.BASE = g.NT / CADM_XDL_WAVES;
-    g.EXTRA = g.NT % CADM_XDL_WAVES;
-    g.NTOW = (g.NTO + CADM_XDL_WAVES - 1) / CADM_XDL_WAVES;
+    g.BASE = g.NT / nw;
+    g.EXTRA = g.NT % nw;
+    g.NTOW = (g.NTO + nw - 1) / nw;
     return g;
 }
 

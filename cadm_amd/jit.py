@@ -21,7 +21,7 @@ from . import _lib
 
 ARCH = "gfx950"           # the one target of this library (csrc/Makefile: ARCH); the kernels are written for its MFMA / LDS
 MIN_HID, NARROW_HID = 113, 128     # xdl_geo.h: narrower nets run zero-padded on the compiled-in 128-wide kernel (no build needed)
-_SRC = ("rollout_jit.hip", "rollout_xdl.h", "rollout_env.h", "rollout_args.h", "common.h", "xdl_geo.h")
+_SRC = ("rollout_jit.hip", "rollout_xdl.h", "rollout_wt.h", "rollout_env.h", "rollout_args.h", "common.h", "xdl_geo.h")
 _loaded = {}
 _memo = {}
 

@@ -1,7 +1,9 @@
-"""The rollout kernel exists in two flavours -- one or two 16-row tiles per workgroup (rollout_xdl.h: XC<.., MT>); the
-launcher picks by batch size.  A row's arithmetic is the same in both, so they must agree BIT FOR BIT on any input; this
-forces each flavour (developer library: cadm_dev_set_rollout) on ragged problem sizes: row counts that are not a multiple of 16,
-odd tile counts (the last workgroup's second tile is empty), single-tile members, every noise mode."""
+"""The rollout kernel exists in several flavours -- the cooperative kernel with one or two 16-row tiles per workgroup
+(rollout_xdl.h: XC<.., MT>) and the wave-tile kernel for large batches (rollout_wt.h: every wave its own tile, 8 or 4 per
+workgroup); the launcher cuts a batch between them by size.  A row's arithmetic is the same in all of them, so they must agree
+BIT FOR BIT on any input; this forces each flavour (developer library: cadm_dev_set_rollout, 1 / 2 = cooperative, 3 / 4 =
+wave-tile) on ragged problem sizes: row counts that are not a multiple of 16, odd tile counts, single-tile members, more tiles
+than one round of workgroups holds, every noise mode."""
 import numpy as np
 import pytest
 import torch
@@ -29,6 +31,8 @@ def _run(eng, prob, ctx, acts, eps, flavour, **kw):
     ("slim_humanoid", True, 5, 20, 9, 1),      # two pair slots of state per thread
     ("pendulum", True, 5, 5, 50, 3),
     ("cartpole", True, 5, 5, 33, 1),
+    ("ant", True, 5, 20, 11, 1),               # four pair slots per lane in the wave-tile kernel, two layer-0 chunks
+    ("halfcheetah", True, 1, 4, 2100, 4),      # 33600 rows of one member: 2100 tiles > one 8-tile round of 256 workgroups
 ])
 def test_one_and_two_row_tiles_per_workgroup_agree_bitwise(gpu, env, context, E, p, n, m):
     H = 12
@@ -40,11 +44,28 @@ def test_one_and_two_row_tiles_per_workgroup_agree_bitwise(gpu, env, context, E,
     eps = torch.randn((H, m, n, p, prob["D"]), device=eng.device)
     for kw, e in (({}, eps), ({"seed": 5, "call": 3, "it": 1}, None)):      # injected noise, device Philox (odd iteration: Q2)
         r1, t1 = _run(eng, prob, ctx, acts, e, "1", **kw)
-        r2, t2 = _run(eng, prob, ctx, acts, e, "2", **kw)
         assert np.isfinite(r1).all()
-        np.testing.assert_array_equal(r2, r1)
-        np.testing.assert_array_equal(t2, t1)
+        for flavour in ("2", "3", "4"):
+            r2, t2 = _run(eng, prob, ctx, acts, e, flavour, **kw)
+            np.testing.assert_array_equal(r2, r1, err_msg="flavour " + flavour)
+            np.testing.assert_array_equal(t2, t1, err_msg="flavour " + flavour)
     eng.close()
+
+
+def test_launcher_cut_between_flavours_changes_nothing(gpu):
+    """Sizes at which the launcher's plan mixes flavours (wave-tile rounds + a cooperative remainder): same bits as one flavour."""
+    H = 6
+    for n in (260, 700, 1300):      # 20 rows per candidate and 5 members: 65 / 175 / 325 tiles per member
+        prob = synth.make_problem(env="halfcheetah", context=True, E=5, m=1, H=H, trained_like=True, seed=n)
+        eng = make_engine(prob, p=20, lib=_lib.load_dev())
+        acts = eng._t(np.random.default_rng(n).uniform(-1, 1, (1, n, H, prob["A"])).astype(np.float32))
+        ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"])
+        kw = {"seed": 11, "call": 2, "it": 0}
+        r0, t0 = _run(eng, prob, ctx, acts, None, "0", **kw)      # the launcher's own plan
+        r1, t1 = _run(eng, prob, ctx, acts, None, "1", **kw)
+        np.testing.assert_array_equal(r0, r1)
+        np.testing.assert_array_equal(t0, t1)
+        eng.close()
 
 
 def test_deterministic_model_both_flavours(gpu):
@@ -52,7 +73,8 @@ def test_deterministic_model_both_flavours(gpu):
     eng = make_engine(prob, p=1, deterministic=True, lib=_lib.load_dev())
     acts = eng._t(np.random.default_rng(0).uniform(-1, 1, (1, 45, 8, prob["A"])).astype(np.float32))
     r1, t1 = _run(eng, prob, None, acts, None, "1")
-    r2, t2 = _run(eng, prob, None, acts, None, "2")
-    np.testing.assert_array_equal(r2, r1)
-    np.testing.assert_array_equal(t2, t1)
+    for flavour in ("2", "3", "4"):
+        r2, t2 = _run(eng, prob, None, acts, None, flavour)
+        np.testing.assert_array_equal(r2, r1, err_msg="flavour " + flavour)
+        np.testing.assert_array_equal(t2, t1, err_msg="flavour " + flavour)
     eng.close()

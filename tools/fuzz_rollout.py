@@ -3,7 +3,7 @@
 
 Every round draws a random problem (env kind, context / vanilla, hidden width, ensemble size, particles, candidates, batch of
 envs m, horizon, noise mode, CEM iteration parity) and checks
-  * the one-tile and the two-tile flavour of the production kernel agree BIT FOR BIT (returns and trajectories),
+  * the one-tile and the two-tile flavour of the cooperative kernel and both wave-tile flavours agree BIT FOR BIT (returns and trajectories),
   * both agree with the fp32-MFMA comparison kernel of round 1 to 2e-5 of the trajectory scale,
   * a second launch reproduces the first bit for bit.
 The hazards inline-asm MFMAs can hide from the compiler are timing- and allocation-dependent; this sweeps many
@@ -77,10 +77,15 @@ def fuzz(seconds=60.0, seed=0, hids=(128, 200, 200, 256, 512)):
             else:
                 out["mt1"] = run(eng, prob, ctx, a_dev, eps, "1", **extra)
                 out["mt2"] = run(eng, prob, ctx, a_dev, eps, "2", **extra)
+                if hid <= 256:      # the wave-tile kernel (rollout_wt.h) exists for 3-product widths
+                    out["wt8"] = run(eng, prob, ctx, a_dev, eps, "3", **extra)
+                    out["wt4"] = run(eng, prob, ctx, a_dev, eps, "4", **extra)
                 out["mt1b"] = run(eng, prob, ctx, a_dev, eps, "1", **extra)
             eng.close()
         tag = "%s ctx=%d hid=%d E=%d p=%d m=%d n=%d H=%d det=%d" % (env, context, hid, E, p, m, n, H, det)
-        for a, b in (("mt1", "mt2"), ("mt1", "mt1b")):
+        for a, b in (("mt1", "mt2"), ("mt1", "mt1b"), ("mt1", "wt8"), ("mt1", "wt4")):
+            if b not in out:
+                continue
             for x, y in zip(out[a], out[b]):
                 assert np.array_equal(x, y, equal_nan=True), "%s: %s vs %s differ" % (tag, a, b)
         if out["f32"] is None or (not det and eps_np is None and hid == 128):
