@@ -78,6 +78,7 @@ struct WTRing {
     int par;
 };
 
+
 // this wave's share of a block of nf fragments (= 2 nf pieces of 1 KB, piece i to wave i mod 8) into slot `slot_idx`
 // (NF is a template parameter: whether piece i exists is then decided at compile time for all but the last round of pieces -- with a
 //  run-time block size hipcc emitted a compare and a branch per piece and block, 6 % of the launch)
@@ -407,26 +408,33 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
 
             // ================= dense layers: activations stay in registers =================
             f16x8 Y1[NCH], Y2[NCH];
+            // One block: barrier, transport of the NEXT block (NFN fragments), GS tiles accumulated over NCHL chunks of XA / XB from the
+            // current slot, epilogue.
+            auto run_block = [&](auto nfn_c, auto gs_c, auto nchl_c, auto head_c, const f16x8 (&XA)[NCH], const f16x8 (&XB)[NCH], int bias_tile,
+                                 auto&& epilogue) __attribute__((always_inline)) {
+                constexpr int NFN = decltype(nfn_c)::value, GS = decltype(gs_c)::value, NCHL = decltype(nchl_c)::value;
+                constexpr bool HEAD = decltype(head_c)::value;
+                const unsigned char* slot = wt_block_boundary<G, NFN>(rg, sm, wave, lane);
+                if (active) {
+                    floatx4 hi[2], lo[2];
+#pragma unroll
+                    for (int k = 0; k < GS; ++k) {
+                        hi[k] = *reinterpret_cast<const floatx4*>(sm + W::BIAS + (bias_tile + k) * 64 + fg * 16);
+                        lo[k] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    wt_accumulate<GS, NCHL, HEAD, W::DBUF>(slot, lane, XA, XB, hi, lo);
+                    epilogue(hi, lo);
+                }
+            };
+            using TrueT = std::integral_constant<bool, true>;
+            using FalseT = std::integral_constant<bool, false>;
             // one hidden-type layer: NCHL input chunks in X, all NT output tiles into Y, pair by pair
             auto hidden_layer = [&](auto nchl_c, int layer) __attribute__((always_inline)) {
                 constexpr int NCHL = decltype(nchl_c)::value;
                 static_for(std::make_integer_sequence<int, W::NG>{}, [&](auto gc) {
                     constexpr int g = decltype(gc)::value, GS = W::gs_hidden(g);
-                    // fragments of the block behind this one: the layer's next pair; behind a layer's last pair the next layer's first
-                    // (the head's first behind the last hidden layer's)
-                    static_assert(W::SLOTS == 2, "the requests below name the block right behind the current one");
-                    const unsigned char* slot;
-                    if constexpr (g + 1 < W::NG) slot = wt_block_boundary<G, W::gs_hidden(g + 1 < W::NG ? g + 1 : 0) * NCHL>(rg, sm, wave, lane);
-                    else if (layer + 1 < XNH) slot = wt_block_boundary<G, W::gs_hidden(0) * NCH>(rg, sm, wave, lane);
-                    else slot = wt_block_boundary<G, W::gs_head(0) * NCH>(rg, sm, wave, lane);
-                    if (active) {
-                        floatx4 hi[2], lo[2];
-#pragma unroll
-                        for (int k = 0; k < GS; ++k) {
-                            hi[k] = *reinterpret_cast<const floatx4*>(sm + W::BIAS + (layer * NT + 2 * g + k) * 64 + fg * 16);
-                            lo[k] = floatx4{0.f, 0.f, 0.f, 0.f};
-                        }
-                        wt_accumulate<GS, NCHL, false, W::DBUF>(slot, lane, X1, X2, hi, lo);
+                    static_assert(W::SLOTS == 2, "a block boundary names the block right behind the current one");
+                    auto epilogue = [&](floatx4 (&hi)[2], floatx4 (&lo)[2]) __attribute__((always_inline)) {
                         const XHiddenEpi<G> epi{nullptr, nullptr, 0, 0, 0, 0, 0};
                         typename XHiddenEpi<G>::State st[2];
                         const floatx4 zero = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -437,7 +445,15 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
                         const f16x4 z4 = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
                         Y1[g] = __builtin_shufflevector(st[0].h1, GS > 1 ? st[1].h1 : z4, 0, 1, 2, 3, 4, 5, 6, 7);
                         Y2[g] = __builtin_shufflevector(st[0].h2, GS > 1 ? st[1].h2 : z4, 0, 1, 2, 3, 4, 5, 6, 7);
-                    }
+                    };
+                    using GSc = std::integral_constant<int, GS>;
+                    const int bt = layer * NT + 2 * g;
+                    // the block behind this one: the layer's next pair; behind a layer's last pair the next layer's first (the head's
+                    // first behind the last hidden layer's)
+                    if constexpr (g + 1 < W::NG)
+                        run_block(std::integral_constant<int, W::gs_hidden(g + 1 < W::NG ? g + 1 : 0) * NCHL>{}, GSc{}, nchl_c, FalseT{}, X1, X2, bt, epilogue);
+                    else if (layer + 1 < XNH) run_block(std::integral_constant<int, W::gs_hidden(0) * NCH>{}, GSc{}, nchl_c, FalseT{}, X1, X2, bt, epilogue);
+                    else run_block(std::integral_constant<int, W::gs_head(0) * NCH>{}, GSc{}, nchl_c, FalseT{}, X1, X2, bt, epilogue);
                 });
             };
             // layer 0
@@ -455,20 +471,14 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
             static_for(std::make_integer_sequence<int, W::NGH>{}, [&](auto gc) {
                 constexpr int g = decltype(gc)::value, GS = W::gs_head(g);
                 constexpr int q = XNH * W::NG + g;
-                const unsigned char* slot = wt_block_boundary<G, W::block_frags(q + W::SLOTS - 1)>(rg, sm, wave, lane);
-                if (active) {
-                    floatx4 hi[2], lo[2];
-#pragma unroll
-                    for (int k = 0; k < GS; ++k) {
-                        hi[k] = *reinterpret_cast<const floatx4*>(sm + W::BIAS + (XNH * NT + 2 * g + k) * 64 + fg * 16);
-                        lo[k] = floatx4{0.f, 0.f, 0.f, 0.f};
-                    }
-                    wt_accumulate<GS, NCH, true, W::DBUF>(slot, lane, Y1, Y2, hi, lo);
+                auto epilogue = [&](floatx4 (&hi)[2], floatx4 (&lo)[2]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int k = 0; k < GS; ++k)
 #pragma unroll
                         for (int qq = 0; qq < 4; ++qq) hv[2 * g + k][qq] = fmaf(lo[k][qq], 4.8828125e-4f, hi[k][qq]);
-                }
+                };
+                run_block(std::integral_constant<int, W::block_frags(q + 1)>{}, std::integral_constant<int, GS>{}, std::integral_constant<int, NCH>{}, TrueT{},
+                          Y1, Y2, XNH * NT + 2 * g, epilogue);
             });
         }
 
@@ -499,8 +509,9 @@ int wt_launch_noise(cadm_ctx* ctx, const RolloutArgs& a, int rows_per_member, in
     RolloutArgs args = a;
     int per_member = ctx->n_cus / ctx->E;
     if (per_member < 1) per_member = 1;
-    const int wgs_needed = (a.tile_count + waves - 1) / waves;
-    args.wgs_per_member = wgs_needed < per_member ? wgs_needed : per_member;
+    // the member's whole CU share, however few tiles there are: a partly filled round then has fewer active waves per workgroup (a
+    // SIMD with one wave finishes its step in less than half the time of one with two), not fewer workgroups
+    args.wgs_per_member = a.tile_count < per_member ? a.tile_count : per_member;
     args.rows_per_member = rows_per_member;
     args.wt_waves = waves;
     const size_t lds = W::lds_bytes(a.H);

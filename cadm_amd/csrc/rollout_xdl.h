@@ -1081,13 +1081,13 @@ namespace {
 // 920 us -- profiles/r4_wave_tile.md; one wave per SIMD does not hide its own LDS and VALU latencies, so the 4-tile form never wins and
 // exists for the tests).  The cheapest cover of the member's tiles is a small dynamic programme over units of one CU share.
 #ifndef CADM_COST_MT2
-#define CADM_COST_MT2 1.68f
+#define CADM_COST_MT2 1.6f
 #endif
 #ifndef CADM_COST_WT4
-#define CADM_COST_WT4 4.6f
+#define CADM_COST_WT4 3.9f
 #endif
 #ifndef CADM_COST_WT8
-#define CADM_COST_WT8 5.85f
+#define CADM_COST_WT8 5.55f
 #endif
 template <int ENV, int C, int HID, int NH, int ACT, int NOISE = -1>
 int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a0, int rows_per_member, hipStream_t s) {

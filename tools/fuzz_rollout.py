@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised differential test of the rollout kernels (developer tool; needs a GPU):  python tools/fuzz_rollout.py [seconds] [seed]
+"""Randomised differential test of the rollout kernels (developer tool; needs a GPU):  python tools/fuzz_rollout.py [seconds] [seed] [variant library]
 
 Every round draws a random problem (env kind, context / vanilla, hidden width, ensemble size, particles, candidates, batch of
 envs m, horizon, noise mode, CEM iteration parity) and checks
@@ -30,7 +30,7 @@ def run(eng, prob, ctx, acts, eps, flavour, **kw):
     return rows.cpu().numpy(), traj.cpu().numpy()
 
 
-def fuzz(seconds=60.0, seed=0, hids=(128, 200, 200, 256, 512)):
+def fuzz(seconds=60.0, seed=0, hids=(128, 200, 200, 256, 512), lib_path=None):
     """-> (rounds, worst xdl-vs-fp32 deviation); raises AssertionError on the first failing problem."""
     t_end = time.time() + seconds
     rng = np.random.default_rng(seed)
@@ -55,7 +55,7 @@ def fuzz(seconds=60.0, seed=0, hids=(128, 200, 200, 256, 512)):
         kw = dict(norm_actions=not discrete, it=int(rng.integers(2)))
         out = {}
         for kind in ("f32", "xdl"):
-            eng = synth.make_engine(prob, p=p, deterministic=det, lib=_lib.load_dev())
+            eng = synth.make_engine(prob, p=p, deterministic=det, lib=_lib.load_dev(lib_path) if lib_path else _lib.load_dev())
             if kind == "f32":
                 eng.dev_set_rollout("f32")
             ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"]) if context else None
@@ -102,7 +102,10 @@ def fuzz(seconds=60.0, seed=0, hids=(128, 200, 200, 256, 512)):
 
 
 def main():
-    rounds, worst = fuzz(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    # (argv[3]: a variant build of the developer library, tools/build_variant.sh -- built for HID 200 only unless told otherwise)
+    lib_path = os.path.join(ROOT, "cadm_amd", sys.argv[3]) if len(sys.argv) > 3 else None
+    rounds, worst = fuzz(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+                         hids=(200,) if lib_path else (128, 200, 200, 256, 512), lib_path=lib_path)
     print("fuzz OK: %d random problems; worst xdl-vs-fp32 trajectory deviation %.2e of the rms" % (rounds, worst))
 
 
