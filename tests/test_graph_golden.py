@@ -120,11 +120,28 @@ def check_iterations(case, cand_returns, elites, rtol, who):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", sorted(gi.CASES))
 def test_hip_planner_reproduces_the_reference_graph(gpu, case):
+    _hip_case(case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["hc_cadm_cfg2", "hc_cadm_cfg2_m10"])
+@pytest.mark.parametrize("flavour", [2, 3])
+def test_hip_planner_reproduces_the_reference_graph_on_every_rollout_flavour(gpu, case, flavour):
+    """The launcher picks the large-batch flavours of the rollout kernel (two row tiles per workgroup; the wave-tile kernel) only
+    from sizes no reference-executed golden has; forced here (developer library) on the timed geometry's goldens."""
+    from cadm_amd import _lib
+    _hip_case(case, lib=_lib.load_dev(), flavour=flavour)
+
+
+def _hip_case(case, lib=None, flavour=0):
     from cadm_amd import planner as hplanner
     from cadm_amd.engine import HipEngine
     c, nets, inp, z, eps, _ = rebuild(case)
+    kw = {} if lib is None else {"lib": lib}
     eng = HipEngine(c["env"], c["E"], c["p"], c["D"], c["A"], c["P"], c["C"], c["hidden"], c["H"], history_length=c["Hh"],
-                    cp_hidden_sizes=c["cp_hidden"], discrete=bool(c.get("discrete")))
+                    cp_hidden_sizes=c["cp_hidden"], discrete=bool(c.get("discrete")), **kw)
+    if flavour:
+        eng.dev_set_rollout("xdl", row_tiles=flavour)
     vanilla = c["C"] == 0
     if not vanilla:
         eng.set_net("context_model", nets["context_model"])

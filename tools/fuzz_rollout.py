@@ -42,6 +42,8 @@ def fuzz(seconds=60.0, seed=0, hids=(128, 200, 200, 256, 512), lib_path=None):
         E = int(rng.choice([1, 2, 5]))
         p = E * int(rng.integers(1, 5))
         m, n, H = int(rng.integers(1, 4)), int(rng.integers(1, 120)), int(rng.integers(1, 12))
+        if rng.integers(5) == 0:      # a big batch now and then: full workgroups and several rounds of the wave-tile kernel, mixed launcher plans
+            n, H = int(rng.integers(500, 4000)), int(rng.integers(1, 4))
         det = bool(rng.integers(4) == 0)
         prob = synth.make_problem(env=env, context=context, E=E, m=m, H=H, hidden_sizes=(hid,) * 4, trained_like=True,
                                   seed=int(rng.integers(1 << 30)))
@@ -81,9 +83,10 @@ def fuzz(seconds=60.0, seed=0, hids=(128, 200, 200, 256, 512), lib_path=None):
                     out["wt8"] = run(eng, prob, ctx, a_dev, eps, "3", **extra)
                     out["wt4"] = run(eng, prob, ctx, a_dev, eps, "4", **extra)
                 out["mt1b"] = run(eng, prob, ctx, a_dev, eps, "1", **extra)
+                out["plan"] = run(eng, prob, ctx, a_dev, eps, "0", **extra)      # whatever mix of flavours the launcher picks
             eng.close()
         tag = "%s ctx=%d hid=%d E=%d p=%d m=%d n=%d H=%d det=%d" % (env, context, hid, E, p, m, n, H, det)
-        for a, b in (("mt1", "mt2"), ("mt1", "mt1b"), ("mt1", "wt8"), ("mt1", "wt4")):
+        for a, b in (("mt1", "mt2"), ("mt1", "mt1b"), ("mt1", "wt8"), ("mt1", "wt4"), ("mt1", "plan")):
             if b not in out:
                 continue
             for x, y in zip(out[a], out[b]):
