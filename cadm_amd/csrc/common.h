@@ -123,7 +123,7 @@ struct cadm_ctx {
     int (*dev_rollout)(cadm_ctx*, const struct RolloutArgs&, int rows_per_member, hipStream_t) = nullptr;
     int (*dev_pack)(cadm_ctx*, hipStream_t) = nullptr;
     void (*dev_free)(cadm_ctx*) = nullptr;
-    int dev_force_mt = 0;           // 0: launcher's choice; 1 / 2: one launch with that many row tiles per workgroup
+    int dev_force_mt = 0;           // 0: launcher's plan; 1 / 2: ONE launch of the cooperative kernel with that many row tiles per workgroup; 3 / 4: of the wave-tile kernel (8 / 4 tiles per workgroup)
     LayerGeo g0, gh, go;            // fp32 fragment stream of the comparison kernel (allocated and packed by dev_pack only)
     float* wstream = nullptr;
     float* bstream = nullptr;

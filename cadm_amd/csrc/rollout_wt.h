@@ -16,7 +16,7 @@
 //     tile pair by tile pair) goes L2 -> LDS once per workgroup and step by LDS-DMA (global_load_lds_dwordx4, no registers), in
 //     BLOCKS of one tile pair (28 KB at HID = 200), double-buffered: at every block boundary one barrier says "block b has
 //     landed, block b-1 is no longer read", then the waves request block b+1 and compute block b from LDS.
-//     L2 -> CU traffic per row drops 8x against the one-tile cooperative kernel (640 KB per step for 128 rows instead of 404 KB for 16).
+//     L2 -> CU traffic per row drops 5x against the one-tile cooperative kernel (640 KB per step for 128 rows instead of 404 KB for 16).
 // A row's arithmetic -- MFMA order per accumulator, epilogue, head, state update, noise counters, reward summation order -- is that
 // of the cooperative kernel: the flavours agree BIT FOR BIT (tests/test_gpu_rowtiles.py, tools/fuzz_rollout.py), so the launcher
 // may cut a batch between them freely (xdl_launch).
@@ -24,7 +24,8 @@
 // Included by rollout_xdl.h (uses its geometry class XC, epilogue arithmetic XHiddenEpi and helpers).
 
 // TIMING EXPERIMENTS ONLY (tools/build_variant.sh; wrong results): CADM_WT_EXPERIMENT_NOMFMA / _NOFRAG (fragments not read from LDS) /
-// _NOSTATE (no state update, noise, input assembly) / _NORING (no barriers, no weight requests); CADM_XDL_EXPERIMENT_NOEPI also applies.
+// _NOSTATE (no state update, noise, input assembly) / _NOBAR (no block barriers) / _NOGLDS (no weight requests);
+// CADM_XDL_EXPERIMENT_NOEPI also applies (profiles/r4_wave_tile.md).
 namespace {
 
 template <class G>
@@ -41,10 +42,7 @@ struct WT {
     // wide observation spaces keep more rollout state and head output per lane (slim humanoid: 6 pair slots)
     static constexpr bool DBUF = !(NTO > 4 || (NTO > 3 && NCH > 7));
     // LDS carve (bytes)
-#ifndef CADM_WT_SLOTS
-#define CADM_WT_SLOTS 2
-#endif
-    static constexpr int SLOTS = CADM_WT_SLOTS;      // ring depth: the block requested at a boundary is SLOTS - 1 blocks ahead of the one computed
+    static constexpr int SLOTS = 2;                                      // ring depth: the block requested at a boundary is the one right behind the block computed
     static constexpr int RING = 0;                                       // [SLOTS][BLK]
     static constexpr int BIAS = RING + SLOTS * BLK;                          // one float4 per (tile, lane group): 64 B per tile
     static constexpr int BIAS_BYTES = (NH * NT + NTO) * 64;

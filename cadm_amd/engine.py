@@ -544,7 +544,8 @@ class HipEngine:
 
     # ------------------------------------------------------------------ developer hooks (libcadm_hip_dev.so only)
     def dev_set_rollout(self, kind="xdl", row_tiles=0):
-        """Select the fp32-MFMA comparison kernel ("f32") / force a row-tile flavour of the production kernel on THIS engine.
+        """Select the fp32-MFMA comparison kernel ("f32") / force a flavour of the production kernel on THIS engine (row_tiles: 0 = the
+        launcher's plan, 1 / 2 = cooperative kernel with one / two row tiles per workgroup, 3 / 4 = wave-tile kernel with 8 / 4 tiles).
         Exists only when the engine was built on the developer library (HipEngine(..., lib=_lib.load_dev()))."""
         if not hasattr(self.lib, "cadm_dev_set_rollout"):
             raise _lib.CadmError("dev_set_rollout needs the developer library (HipEngine(..., lib=_lib.load_dev()))")
