@@ -381,10 +381,16 @@ class Planner:
         step = self.plan_device
         step(0)                  # (negotiates the sharded path on first use)
         self.check_rccl()
-        for w in range(warmup):
+        if profile:
+            # the warmup steps run bracketed too: the library creates its hipEvent pairs on first use, and a host that is busy creating
+            # events falls behind the GPU -- the start event is then stamped before the kernel's dispatch packet has even arrived and the
+            # bracket reads 10-15 us long (driver's command, 20 steps: 172 us per rollout against 162 with 50 steps; rocprofv3: 157-163)
+            eng.profile_enable(True)
+        for w in range(max(warmup, 10 if profile else 0)):
             step(w)
         if profile:
-            eng.profile_enable(True)
+            torch.cuda.synchronize(eng.device)
+            eng.profile_enable(True)      # (resets the counters; the event pool stays)
         self.barrier()
         t0 = time.perf_counter()
         for k in range(steps):
