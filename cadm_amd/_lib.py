@@ -102,6 +102,7 @@ DEV_SIGNATURES = {
     "cadm_dev_set_rollout": (_i, [_P, _i, _i]),
     "cadm_dev_set_timing_buffer": (_i, [_P, _P]),
     "cadm_dev_read_adam_moment": (_i, [_P, _i, _i, _i, _i, _P, C.c_long, _P]),
+    "cadm_dev_rollout_plan": (_i, [_i, _i, _i, C.POINTER(_i)]),
 }
 DEV_ROLLOUT_XDL, DEV_ROLLOUT_F32 = 0, 1
 

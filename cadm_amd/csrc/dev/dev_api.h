@@ -8,8 +8,9 @@ extern "C" {
 #endif
 #define CADM_DEV_ROLLOUT_XDL 0   /* the production split-f16 kernel (rollout_xdl.h) */
 #define CADM_DEV_ROLLOUT_F32 1   /* round 1's fp32-MFMA kernel (dev/rollout_f32.h): comparison only */
-/* kind: which kernel cadm_rollout_returns / the planners launch on this ctx; row_tiles: 0 = launcher's choice,
- * 1 / 2 = one launch of the production kernel with that many 16-row tiles per workgroup. */
+/* kind: which kernel cadm_rollout_returns / the planners launch on this ctx; row_tiles: 0 = the launcher's plan,
+ * 1 / 2 = ONE launch of the cooperative kernel with that many 16-row tiles per workgroup, 3 / 4 = of the wave-tile kernel
+ * (8 / 4 tiles per workgroup). */
 int cadm_dev_set_rollout(cadm_ctx* ctx, int kind, int row_tiles);
 /* device buffer of 8*24 uint64 that the CADM_PHASE_TIMING build (make timing) fills with per-phase s_memtime sums of workgroup 0 */
 int cadm_dev_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf);
@@ -17,6 +18,9 @@ int cadm_dev_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf);
  * the tensor's element count [E, in, out] / [E, out] / [D]).  layer as in cadm_set_weights; layer -1 / -2 = max / min_logvar
  * (CADM_NET_FF).  With beta1 = 0 the first moment after a step IS that step's gradient (m = 0 m + 1 g, exact): the tests read
  * dL/dW and dL/db element by element this way (tests/test_gpu_train.py) instead of differencing weights. */
+/* The launcher's plan for a member of `units` CU shares of row tiles (csrc/xdl_geo.h: xdl_plan_units): count_out[4] = launches
+ * (rounds) of {cooperative one tile, cooperative two tiles, wave-tile 4, wave-tile 8}.  Host logic only: no ctx, no device. */
+int cadm_dev_rollout_plan(int units, int two_tile_ok, int wave_tile_ok, int* count_out);
 int cadm_dev_read_adam_moment(cadm_ctx* ctx, int net, int layer, int is_bias, int second, float* dst, long n_floats, void* stream);
 #ifdef __cplusplus
 }

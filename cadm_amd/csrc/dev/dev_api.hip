@@ -60,6 +60,14 @@ extern "C" int cadm_dev_set_rollout(cadm_ctx* ctx, int kind, int row_tiles) {
     return CADM_OK;
 }
 
+extern "C" int cadm_dev_rollout_plan(int units, int two_tile_ok, int wave_tile_ok, int* count_out) {
+    CADM_REQUIRE(units >= 0 && count_out, "cadm_dev_rollout_plan: bad argument");
+    int count[4];
+    xdl_plan_units(units, two_tile_ok != 0, wave_tile_ok != 0, count);
+    for (int o = 0; o < 4; ++o) count_out[o] = count[o];
+    return CADM_OK;
+}
+
 extern "C" int cadm_dev_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf) {
     CADM_REQUIRE(ctx, "cadm_dev_set_timing_buffer: null ctx");
     ctx->tbuf = (unsigned long long*)dev_u64_buf;

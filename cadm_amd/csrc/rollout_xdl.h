@@ -1077,18 +1077,7 @@ namespace {
 //   cooperative, two row tiles per workgroup (cap 2x)                                                    cost CADM_COST_MT2
 //   wave-tile, 4 tiles per workgroup (one wave per SIMD; cap 4x)                                         cost CADM_COST_WT4
 //   wave-tile, 8 tiles per workgroup (cap 8x, any number of rounds)                                      cost CADM_COST_WT8 per round
-// (costs in units of the one-tile launch, measured at the cfg2 / cfg3 geometry, halfcheetah, 51 workgroups per member: 158 / 265 / 730 /
-// 920 us -- profiles/r4_wave_tile.md; one wave per SIMD does not hide its own LDS and VALU latencies, so the 4-tile form never wins and
-// exists for the tests).  The cheapest cover of the member's tiles is a small dynamic programme over units of one CU share.
-#ifndef CADM_COST_MT2
-#define CADM_COST_MT2 1.6f
-#endif
-#ifndef CADM_COST_WT4
-#define CADM_COST_WT4 3.9f
-#endif
-#ifndef CADM_COST_WT8
-#define CADM_COST_WT8 5.55f
-#endif
+// (xdl_geo.h: xdl_plan_units -- costs in units of the one-tile launch, a small dynamic programme over units of one CU share.)
 template <int ENV, int C, int HID, int NH, int ACT, int NOISE = -1>
 int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a0, int rows_per_member, hipStream_t s) {
     using G1 = XC<ENV, C, HID, 1, NH, ACT>;
@@ -1119,30 +1108,11 @@ int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a0, int rows_per_member, hipStr
         if constexpr (W::AVAILABLE) { if (!rc && wt_ok) rc = wt_launch<G1, NOISE>(ctx, a, rows_per_member, 8, s); }
         return rc;
     }
-    // cheapest cover of the member's tiles, in units of per_member tiles: f(u) = min over flavours (cost + f(u - cap))
+    // cheapest cover of the member's tiles, in units of per_member tiles (xdl_geo.h: xdl_plan_units)
     const int units = (tiles + per_member - 1) / per_member;
-    const int capu[4] = {1, mt2_ok ? 2 : 0, wt_ok ? 4 : 0, wt_ok ? 8 : 0};
-    const float cost[4] = {1.0f, CADM_COST_MT2, CADM_COST_WT4, CADM_COST_WT8};
-    int count[4] = {0, 0, 0, 0};
-    {
-        // beyond 64 units the answer is "8-tile rounds of the best flavour" plus the plan of the rest
-        const int big = capu[3] ? 3 : capu[1] ? 1 : 0;
-        int u = units;
-        if (u > 64) { const int k = (u - 56) / capu[big]; count[big] += k; u -= k * capu[big]; }
-        float f[65];
-        int pick[65];
-        f[0] = 0.0f;
-        pick[0] = -1;
-        for (int v = 1; v <= u; ++v) {
-            f[v] = 1e30f;
-            for (int o = 0; o < 4; ++o) {
-                if (!capu[o]) continue;
-                const float c = cost[o] + f[v > capu[o] ? v - capu[o] : 0];
-                if (c < f[v] - 1e-6f) { f[v] = c; pick[v] = o; }
-            }
-        }
-        for (int v = u; v > 0; v -= capu[pick[v]]) ++count[pick[v]];
-    }
+    const int capu[4] = {1, 2, 4, 8};
+    int count[4];
+    xdl_plan_units(units, mt2_ok, wt_ok, count);
     int rem = tiles, t0 = 0;
     for (int o = 3; o >= 0 && rem > 0; --o) {      // biggest flavour first: the last launch takes the ragged rest
         if (!count[o]) continue;

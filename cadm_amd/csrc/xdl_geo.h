@@ -84,3 +84,44 @@ __host__ __device__ constexpr int xdl_frag_index(int ntw, int nchl, int ti, int 
     const int gs = (ntw - gsz * g) < gsz ? (ntw - gsz * g) : gsz;
     return gsz * g * nchl + c * gs + (ti - gsz * g);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The launcher's plan (rollout_xdl.h: xdl_launch): how a member's row tiles are cut between the kernel flavours.
+//   flavour 0: cooperative kernel, one row tile per workgroup   cap 1 unit   cost 1
+//           1: cooperative kernel, two row tiles per workgroup  cap 2        CADM_COST_MT2
+//           2: wave-tile kernel, 4 tiles per workgroup           cap 4        CADM_COST_WT4   (one wave per SIMD: never wins, exists for the tests)
+//           3: wave-tile kernel, 8 tiles per workgroup           cap 8        CADM_COST_WT8   (per round)
+// 1 unit = one CU share of the member (n_cus / E tiles); costs in units of the one-tile launch, measured at the cfg2 / cfg3 geometry
+// (halfcheetah, 51 workgroups per member: 168 / 269 / 643 / 938 us, profiles/r4_s3_flavour_table.txt).  The cheapest cover is a small
+// dynamic programme, f(u) = min over flavours (cost + f(u - cap)); count[o] = launches (rounds) of flavour o.
+#ifndef CADM_COST_MT2
+#define CADM_COST_MT2 1.6f
+#endif
+#ifndef CADM_COST_WT4
+#define CADM_COST_WT4 3.9f
+#endif
+#ifndef CADM_COST_WT8
+#define CADM_COST_WT8 5.55f
+#endif
+inline void xdl_plan_units(int units, bool mt2_ok, bool wt_ok, int (&count)[4]) {
+    const int capu[4] = {1, mt2_ok ? 2 : 0, wt_ok ? 4 : 0, wt_ok ? 8 : 0};
+    const float cost[4] = {1.0f, CADM_COST_MT2, CADM_COST_WT4, CADM_COST_WT8};
+    for (int o = 0; o < 4; ++o) count[o] = 0;
+    // beyond 64 units the answer is "rounds of the biggest flavour" plus the plan of the rest
+    const int big = capu[3] ? 3 : capu[1] ? 1 : 0;
+    int u = units;
+    if (u > 64) { const int k = (u - 56) / capu[big]; count[big] += k; u -= k * capu[big]; }
+    float f[65];
+    int pick[65];
+    f[0] = 0.0f;
+    pick[0] = -1;
+    for (int v = 1; v <= u; ++v) {
+        f[v] = 1e30f;
+        for (int o = 0; o < 4; ++o) {
+            if (!capu[o]) continue;
+            const float c = cost[o] + f[v > capu[o] ? v - capu[o] : 0];
+            if (c < f[v] - 1e-6f) { f[v] = c; pick[v] = o; }
+        }
+    }
+    for (int v = u; v > 0; v -= capu[pick[v]]) ++count[pick[v]];
+}
