@@ -42,7 +42,9 @@ def test_one_and_two_row_tiles_per_workgroup_agree_bitwise(gpu, env, context, E,
     acts = eng._t(rng.uniform(-1, 1, (m, n, H, prob["A"])).astype(np.float32))
     ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"]) if context else None
     eps = torch.randn((H, m, n, p, prob["D"]), device=eng.device)
-    for kw, e in (({}, eps), ({"seed": 5, "call": 3, "it": 1}, None)):      # injected noise, device Philox (odd iteration: Q2)
+    obs_rows = rng.standard_normal((m, n, p, prob["D"])).astype(np.float32)      # per-row initial observations (the teacher-forced form)
+    for kw, e in (({}, eps), ({"seed": 5, "call": 3, "it": 1}, None), ({"obs_rows": obs_rows, "seed": 9, "call": 1, "it": 0}, None)):
+        # injected noise; device Philox (odd iteration: Q2); per-row initial observations
         r1, t1 = _run(eng, prob, ctx, acts, e, "1", **kw)
         assert np.isfinite(r1).all()
         for flavour in ("2", "3", "4"):
