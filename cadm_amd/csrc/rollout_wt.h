@@ -33,7 +33,7 @@ struct WT {
     static constexpr int NW = 8, NTHR = NW * 64;
     static constexpr int NT = G::NT, NCH = G::NCH, NC0 = G::NC0, NTO = G::NTO, NH = G::NHC;
     static constexpr int NG = (NT + 1) / 2, NGH = (NTO + 1) / 2;       // tile pairs of a hidden-type layer / of the head
-    static constexpr bool AVAILABLE = G::NPROD == 3 && NCH <= 8 && NC0 <= NCH;
+    static constexpr bool AVAILABLE = G::NPROD == 3 && NCH <= 8 && NC0 <= NCH && NH <= 5;      // (the layer loop is unrolled: code size)
     static constexpr int BLK = 2 * NCH * CADM_XDL_FRAG_BYTES;            // bytes of the largest block (one pair of hidden tiles)
     static constexpr int NJ = NTO;                                       // pair slots per lane: slot j <-> head tile j, pair 4 j + (lane >> 4)
     static constexpr int NAJ = (G::A + 3) / 4;                           // action slots per lane
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
             using TrueT = std::integral_constant<bool, true>;
             using FalseT = std::integral_constant<bool, false>;
             // one hidden-type layer: NCHL input chunks in X, all NT output tiles into Y, pair by pair
-            auto hidden_layer = [&](auto nchl_c, int layer) __attribute__((always_inline)) {
+            auto hidden_layer = [&](auto nchl_c, int layer, const f16x8 (&IN1)[NCH], const f16x8 (&IN2)[NCH], f16x8 (&OUT1)[NCH], f16x8 (&OUT2)[NCH]) __attribute__((always_inline)) {
                 constexpr int NCHL = decltype(nchl_c)::value;
                 static_for(std::make_integer_sequence<int, W::NG>{}, [&](auto gc) {
                     constexpr int g = decltype(gc)::value, GS = W::gs_hidden(g);
@@ -441,30 +441,31 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
                             for (int k = 0; k < GS; ++k) epi.template stage<decltype(sc)::value>(0, 0, hi[k], lo[k], zero, st[k]);
                         });
                         const f16x4 z4 = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
-                        Y1[g] = __builtin_shufflevector(st[0].h1, GS > 1 ? st[1].h1 : z4, 0, 1, 2, 3, 4, 5, 6, 7);
-                        Y2[g] = __builtin_shufflevector(st[0].h2, GS > 1 ? st[1].h2 : z4, 0, 1, 2, 3, 4, 5, 6, 7);
+                        OUT1[g] = __builtin_shufflevector(st[0].h1, GS > 1 ? st[1].h1 : z4, 0, 1, 2, 3, 4, 5, 6, 7);
+                        OUT2[g] = __builtin_shufflevector(st[0].h2, GS > 1 ? st[1].h2 : z4, 0, 1, 2, 3, 4, 5, 6, 7);
                     };
                     using GSc = std::integral_constant<int, GS>;
                     const int bt = layer * NT + 2 * g;
                     // the block behind this one: the layer's next pair; behind a layer's last pair the next layer's first (the head's
                     // first behind the last hidden layer's)
                     if constexpr (g + 1 < W::NG)
-                        run_block(std::integral_constant<int, W::gs_hidden(g + 1 < W::NG ? g + 1 : 0) * NCHL>{}, GSc{}, nchl_c, FalseT{}, X1, X2, bt, epilogue);
-                    else if (layer + 1 < XNH) run_block(std::integral_constant<int, W::gs_hidden(0) * NCH>{}, GSc{}, nchl_c, FalseT{}, X1, X2, bt, epilogue);
-                    else run_block(std::integral_constant<int, W::gs_head(0) * NCH>{}, GSc{}, nchl_c, FalseT{}, X1, X2, bt, epilogue);
+                        run_block(std::integral_constant<int, W::gs_hidden(g + 1 < W::NG ? g + 1 : 0) * NCHL>{}, GSc{}, nchl_c, FalseT{}, IN1, IN2, bt, epilogue);
+                    else if (layer + 1 < XNH) run_block(std::integral_constant<int, W::gs_hidden(0) * NCH>{}, GSc{}, nchl_c, FalseT{}, IN1, IN2, bt, epilogue);
+                    else run_block(std::integral_constant<int, W::gs_head(0) * NCH>{}, GSc{}, nchl_c, FalseT{}, IN1, IN2, bt, epilogue);
                 });
             };
             // layer 0
-            hidden_layer(std::integral_constant<int, NC0>{}, 0);
-            // hidden layers 1 .. NH-1 (one body: the input is moved into X)
-#pragma unroll 1
-            for (int l = 1; l < XNH; ++l) {
-                if (active) {
-#pragma unroll
-                    for (int c = 0; c < NCH; ++c) { X1[c] = Y1[c]; X2[c] = Y2[c]; }
-                }
-                hidden_layer(std::integral_constant<int, NCH>{}, l);
-            }
+            hidden_layer(std::integral_constant<int, NC0>{}, 0, X1, X2, Y1, Y2);
+            // hidden layers 1 .. NH-1, unrolled: the two activation register sets swap roles from layer to layer (a rolled loop had to move
+            // 2 x NCH x 4 registers per layer: -2.7 % of a full round, profiles/r4_wave_tile.md; nets deeper than 5 layers stay on the
+            // cooperative kernel, WT::AVAILABLE)
+            static_for(std::make_integer_sequence<int, XNH - 1>{}, [&](auto lc) {
+                constexpr int l = decltype(lc)::value + 1;
+                if constexpr (l & 1) hidden_layer(std::integral_constant<int, NCH>{}, l, Y1, Y2, X1, X2);
+                else hidden_layer(std::integral_constant<int, NCH>{}, l, X1, X2, Y1, Y2);
+            });
+            f16x8 (&H1)[NCH] = ((XNH - 1) & 1) ? X1 : Y1;      // the last hidden layer's output: the head's input
+            f16x8 (&H2)[NCH] = ((XNH - 1) & 1) ? X2 : Y2;
             // head: (mu | logvar) of 8 dims per tile, recombined in-lane
             static_for(std::make_integer_sequence<int, W::NGH>{}, [&](auto gc) {
                 constexpr int g = decltype(gc)::value, GS = W::gs_head(g);
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
                         for (int qq = 0; qq < 4; ++qq) hv[2 * g + k][qq] = fmaf(lo[k][qq], 4.8828125e-4f, hi[k][qq]);
                 };
                 run_block(std::integral_constant<int, W::block_frags(q + 1)>{}, std::integral_constant<int, GS>{}, std::integral_constant<int, NCH>{}, TrueT{},
-                          Y1, Y2, XNH * NT + 2 * g, epilogue);
+                          H1, H2, XNH * NT + 2 * g, epilogue);
             });
         }
 

@@ -164,7 +164,7 @@ def test_wave_tile_kernel_shape():
     it (112-128 of them are the activations it carries from layer to layer).  At the reference's width it must not spill for the
     small and medium observation spaces (halfcheetah, cart-pole, pendulum, ant; slim humanoid's 6 pair slots per lane are known to spill
     a few registers: profiles/r4_wave_tile.md), it must move its weights by LDS-DMA, and a step must hold the 960 MFMAs of 13 + 13 +
-    13 + 13 + 3 tiles (the layer loop is rolled: the code holds layer 0, ONE hidden layer and the head)."""
+    13 + 13 + 3 tiles."""
     seen = 0
     for img in _code_objects(LIB):
         for sym, ins in _kernels(img, "rollout_wt_kernel").items():
@@ -175,10 +175,10 @@ def test_wave_tile_kernel_shape():
             assert any(x.startswith("global_load_lds_dwordx4") for x in ins), "%s: no LDS-DMA weight requests" % sym
             n_mfma = sum(1 for x in ins if x.startswith("v_mfma_f32_16x16x32_f16"))
             if hid == 200 and env == 0:
-                # layer 0: 13 tiles x (1 or 2) chunks x 3; one hidden layer: 13 x 7 x 3 (+ its last tile once more: the block behind a layer's
-                # last one is the next layer's first or the head's first -- two copies with the next block's size a constant); head: 3 x 7 x 3
+                # layer 0: 13 tiles x (1 or 2) chunks x 3; three hidden layers (the layer loop is unrolled: the activation register
+                # sets swap roles): 13 x 7 x 3 each; head: 3 x 7 x 3 -- with two chunks in layer 0 the 960 MFMAs of a rollout step
                 nc0 = (18 + 6 + ctx + 31) // 32
-                assert n_mfma == 13 * nc0 * 3 + (13 + 1) * 7 * 3 + 3 * 7 * 3, "%s: %d MFMAs" % (sym, n_mfma)
+                assert n_mfma == 13 * nc0 * 3 + 3 * 13 * 7 * 3 + 3 * 7 * 3, "%s: %d MFMAs" % (sym, n_mfma)
             if hid <= 200 and env != 2:
                 scratch = [x for x in ins if x.startswith("scratch_")]
                 assert not scratch, "%s: %d scratch accesses (e.g. %s)" % (sym, len(scratch), scratch[0])
