@@ -40,7 +40,10 @@ struct WT {
     static constexpr int TABW = 28;
     // two register sets for the weight fragments (chunk c + 1 requested from LDS before chunk c's MFMAs) where the registers allow:
     // wide observation spaces keep more rollout state and head output per lane (slim humanoid: 6 pair slots)
-    static constexpr bool DBUF = !(NTO > 4 || (NTO > 3 && NCH > 7));
+#ifndef CADM_WT_NBUF
+#define CADM_WT_NBUF 2
+#endif
+    static constexpr int DBUF = (NTO > 4 || (NTO > 3 && NCH > 7)) ? 1 : CADM_WT_NBUF;      // register sets of weight fragments
     // LDS carve (bytes)
     static constexpr int SLOTS = 2;                                      // ring depth: the block requested at a boundary is the one right behind the block computed
     static constexpr int RING = 0;                                       // [SLOTS][BLK]
@@ -117,15 +120,15 @@ __device__ __forceinline__ const unsigned char* wt_block_boundary(WTRing& rg, un
 
 // accumulate GS tiles over NCHL chunks from the block at `slot`: hi += w1 x1, lo += w2 x1 + w1 x2 per chunk, in the cooperative
 // kernel's order per accumulator.  HEAD: the block stores its fragments tile-major (xdl_geo.h), else chunk-major.
-template <int GS, int NCHL, bool HEAD, bool DBUF, int NX>
+template <int GS, int NCHL, bool HEAD, int DBUF, int NX>
 __device__ __forceinline__ void wt_accumulate(const unsigned char* slot, int lane, const f16x8 (&X1)[NX], const f16x8 (&X2)[NX],
                                               floatx4 (&hi)[2], floatx4 (&lo)[2]) {
     // the fragments of chunk c + 1 are requested before chunk c's MFMAs (two register sets): a wave alone on its SIMD otherwise
     // waits out the LDS latency at every chunk
-    uintx4 w[2][GS][2];
+    uintx4 w[DBUF][GS][2];
 #ifdef CADM_WT_EXPERIMENT_NOFRAG
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < DBUF; ++q)
 #pragma unroll
         for (int k = 0; k < GS; ++k) { w[q][k][0] = uintx4{1u, 2u, 3u, 4u}; w[q][k][1] = uintx4{1u, 2u, 3u, 4u}; }
 #endif
@@ -137,29 +140,28 @@ __device__ __forceinline__ void wt_accumulate(const unsigned char* slot, int lan
             for (int part = 0; part < 2; ++part) {
                 const int fi = HEAD ? k * NCHL + c : c * GS + k;
 #ifndef CADM_WT_EXPERIMENT_NOFRAG
-                w[DBUF ? c & 1 : 0][k][part] = *reinterpret_cast<const uintx4*>(slot + (fi * 2 + part) * 1024 + lane * 16);
+                w[c % DBUF][k][part] = *reinterpret_cast<const uintx4*>(slot + (fi * 2 + part) * 1024 + lane * 16);
 #else
                 (void)fi;
 #endif
             }
     };
-    if constexpr (DBUF) wload(std::integral_constant<int, 0>{});
+    static_for(std::make_integer_sequence<int, (DBUF - 1 < NCHL ? DBUF - 1 : NCHL)>{}, [&](auto cc) { wload(cc); });
     static_for(std::make_integer_sequence<int, NCHL>{}, [&](auto cc) {
         constexpr int c = decltype(cc)::value;
-        if constexpr (!DBUF) wload(cc);
-        else if constexpr (c + 1 < NCHL) wload(std::integral_constant<int, c + 1>{});
+        if constexpr (c + DBUF - 1 < NCHL) wload(std::integral_constant<int, c + DBUF - 1>{});
 #ifdef CADM_WT_EXPERIMENT_NOMFMA
 #pragma unroll
-        for (int k = 0; k < GS; ++k) asm volatile("" : "+v"(hi[k]), "+v"(lo[k]) : "v"(w[DBUF ? c & 1 : 0][k][0]), "v"(w[DBUF ? c & 1 : 0][k][1]), "v"(X1[c]), "v"(X2[c]));
+        for (int k = 0; k < GS; ++k) asm volatile("" : "+v"(hi[k]), "+v"(lo[k]) : "v"(w[c % DBUF][k][0]), "v"(w[c % DBUF][k][1]), "v"(X1[c]), "v"(X2[c]));
 #else
 #pragma unroll
-        for (int k = 0; k < GS; ++k) hi[k] = xmfma(w[DBUF ? c & 1 : 0][k][0], X1[c], hi[k]);
+        for (int k = 0; k < GS; ++k) hi[k] = xmfma(w[c % DBUF][k][0], X1[c], hi[k]);
 #pragma unroll
-        for (int k = 0; k < GS; ++k) lo[k] = xmfma(w[DBUF ? c & 1 : 0][k][1], X1[c], lo[k]);
+        for (int k = 0; k < GS; ++k) lo[k] = xmfma(w[c % DBUF][k][1], X1[c], lo[k]);
 #pragma unroll
-        for (int k = 0; k < GS; ++k) lo[k] = xmfma(w[DBUF ? c & 1 : 0][k][0], X2[c], lo[k]);
+        for (int k = 0; k < GS; ++k) lo[k] = xmfma(w[c % DBUF][k][0], X2[c], lo[k]);
 #endif
-        if constexpr (DBUF) __builtin_amdgcn_sched_barrier(0);      // pin the pipeline: no load sinking / hoisting across chunks
+        if constexpr (DBUF > 1) __builtin_amdgcn_sched_barrier(0);      // pin the pipeline: no load sinking / hoisting across chunks
     });
 }
 
