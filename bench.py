@@ -504,8 +504,12 @@ def main():
     head, cfgname, m = make(args.config, args.cand_per_gpu)
     api_elapsed = head.run_api(args.steps, args.warmup)
     plain = head.run_device(args.steps, args.warmup, profile=False)      # device-resident wall time: no event bracketing
-    r = head.run_device(args.steps, args.warmup, profile=True)           # kernel / collective times from hipEvents
-    s = head.summary(r, args.steps)
+    # kernel / collective times from hipEvents: its own pass of at least 60 get_actions behind 20 bracketed warmup ones -- the brackets read
+    # 166-169 us per rollout over the first 100 launches of a bracketed pass and 160 over 500 (rocprofv3 of the same command: 155-157);
+    # `roofline.launches` says how many launches the average is over.  The K timed steps of the headline are the two passes above.
+    ksteps = max(args.steps, 60)
+    r = head.run_device(ksteps, max(args.warmup, 20), profile=True)
+    s = head.summary(r, ksteps)
     cfg = head.cfg
     api_ms = api_elapsed / args.steps * 1e3
     dev_ms = plain["elapsed"] / args.steps * 1e3

@@ -41,7 +41,7 @@ def test_bench_self_launches_its_ranks(n):
     assert out["config"]["rccl_nranks"] == n and out["config"]["global_candidates"] == 200 * n
     assert abs(out["per_gpu_value"] * n - out["value"]) < 1e-6 * out["value"]
     if n > 1:
-        assert out["config"]["allgathers_timed"] == 3 * 5 and out["config"]["allgather_us"] is not None
+        assert out["config"]["allgathers_timed"] == max(3, 60) * 5 and out["config"]["allgather_us"] is not None
         assert set(out["legs"]) == {"cfg5"} and out["legs"]["cfg5"]["rccl_nranks"] == n
         assert "cpu_baseline" not in out          # rank 0 at N = 1 only
 
