@@ -13,6 +13,7 @@ struct XdlPackArgs {
     int* overflow;                                // set to 1 if a weight does not fit the f16 range
     XdlGeo g;
     int E;
+    int swish_fold;                               // hidden nonlinearity is swish: log2(e) folded into the packed weights (xdl_geo.h)
 };
 
 __device__ __forceinline__ unsigned short f16_bits(_Float16 h) { return __builtin_bit_cast(unsigned short, h); }
@@ -74,6 +75,9 @@ __global__ void pack_xdl_kernel(const XdlPackArgs a) {
                 if (d < g.D) v = a.W[g.NH + (r >> 1)][((size_t)e * K + kin) * g.D + d];
             }
         }
+        // swish fold: layer 0 maps true inputs to scaled pre-activations (W * c), the hidden layers map scaled activations to scaled
+        // pre-activations (W unchanged), the head maps scaled activations to true outputs (W / c)
+        if (a.swish_fold) v *= layer == 0 ? CADM_XDL_LOG2E : layer == g.NH ? (1.0f / CADM_XDL_LOG2E) : 1.0f;
         if (!(fabsf(v) <= 65000.0f)) { *a.overflow = 1; v = 0.0f; }
         const _Float16 v1 = (_Float16)v;
         const _Float16 v2 = (_Float16)((v - (float)v1) * 2048.0f);
@@ -98,6 +102,7 @@ __global__ void pack_xdl_bias_kernel(const XdlPackArgs a) {
             tile %= g.NT;
             const int u = 16 * tile + 4 * grp + r;
             if (u < g.HIDR) v = a.b[layer][(size_t)e * g.HIDR + u];
+            if (a.swish_fold) v *= CADM_XDL_LOG2E;          // every hidden pre-activation is scaled
         } else {
             tile -= g.NH * g.NT;
             const int d = 8 * tile + 2 * grp + (r & 1);
@@ -117,6 +122,7 @@ int cadm_pack_xdl(cadm_ctx* ctx, hipStream_t s) {
     a.overflow = ctx->xflag;
     a.g = ctx->xg;
     a.E = ctx->E;
+    a.swish_fold = ctx->cfg.hidden_act == CADM_ACT_SWISH ? 1 : 0;
     CADM_CHECK_HIP(hipMemsetAsync(ctx->xflag, 0, sizeof(int), s));
     const size_t total = (size_t)ctx->xg.member_frags() * 1024 * ctx->E;
     hipLaunchKernelGGL(pack_xdl_kernel, dim3((unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192)), dim3(256), 0, s, a);

@@ -118,7 +118,7 @@ __device__ __forceinline__ const unsigned char* wt_block_boundary(WTRing& rg, un
     return cur;
 }
 
-// accumulate GS tiles over NCHL chunks from the block at `slot`: hi += w1 x1, lo += w2 x1 + w1 x2 per chunk, in the cooperative
+// accumulate GS tiles over NCHL chunks from the block at `slot`: hi += w1 x1 + w1 x2, lo += w2 x1 per chunk, in the cooperative
 // kernel's order per accumulator.  HEAD: the block stores its fragments tile-major (xdl_geo.h), else chunk-major.
 template <int GS, int NCHL, bool HEAD, int DBUF, int NX>
 __device__ __forceinline__ void wt_accumulate(const unsigned char* slot, int lane, const f16x8 (&X1)[NX], const f16x8 (&X2)[NX],
@@ -159,7 +159,7 @@ __device__ __forceinline__ void wt_accumulate(const unsigned char* slot, int lan
 #pragma unroll
         for (int k = 0; k < GS; ++k) lo[k] = xmfma(w[c % DBUF][k][1], X1[c], lo[k]);
 #pragma unroll
-        for (int k = 0; k < GS; ++k) lo[k] = xmfma(w[c % DBUF][k][0], X2[c], lo[k]);
+        for (int k = 0; k < GS; ++k) hi[k] = xmfma(w[c % DBUF][k][0], X2[c], hi[k]);
 #endif
         if constexpr (DBUF > 1) __builtin_amdgcn_sched_barrier(0);      // pin the pipeline: no load sinking / hoisting across chunks
     });
@@ -224,7 +224,6 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
     rg.bytes = a.xw1_member_b;
     rg.par = 0;
     rg.next = 0;
-    constexpr int NF_L0_FIRST = W::gs_hidden(0) * NC0;
     // the first SLOTS - 1 blocks of the step; every block boundary then requests the block SLOTS - 1 ahead
     static_for(std::make_integer_sequence<int, W::SLOTS - 1>{}, [&](auto bc) {
         constexpr int b = decltype(bc)::value;

@@ -68,7 +68,7 @@ struct XC {
     static constexpr int NTOW = (NTO + NW - 1) / NW;      // head tile slots per wave
     static_assert(NTOW == 1, "one head tile per wave at most (obs dim <= 64)");
     static constexpr int R = CADM_XDL_RING;               // ring depth (fragments)
-    // products per 16x16x32 block: hi += w1 x1, lo += w2 x1 + w1 x2 [, ll += w2 x2].  The dropped w2 x2 term is 2^-22 of a
+    // products per 16x16x32 block: hi += w1 x1 + w1 x2, lo += w2 x1 [+ w2 x2] (xdl_geo.h).  The dropped w2 x2 term is 2^-22 of a
     // product; wide layers (K > 256) accumulate enough of them to show at the 1e-5 parity bar, so they take the 4th product.
     static constexpr int NPROD = HID > 256 ? 4 : 3;
     static constexpr int NP = (D + 1) / 2, NPI = (NP + 15) / 16, NAI = (A + 15) / 16;
@@ -227,10 +227,12 @@ __device__ __forceinline__ void xdl_operand_nops(floatx4& a, floatx4& b, floatx4
     else asm volatile("s_nop 4" : "+v"(a), "+v"(b));
 }
 
-// split an fp32 value for the f16 pipe: hi = f16(v), lo = f16((v - hi) * 2^11)
+// split an ACTIVATION for the f16 pipe: hi = f16(v), lo = f16(v - hi), UNSCALED (xdl_geo.h: the products w1 * lo accumulate next to
+// w1 * hi; a low part below the f16 normal range is a subnormal with 2^-24 absolute spacing: an absolute error of 3e-8 on an
+// activation that small)
 __device__ __forceinline__ void xsplit(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
-    lo = (_Float16)fmaf((float)hi, -2048.0f, v * 2048.0f);
+    lo = (_Float16)(v - (float)hi);
 }
 
 // Epilogue of a hidden tile: swish, f16 split, store as (half of) a B fragment of the next layer (the bias tile is the
@@ -267,17 +269,18 @@ struct XHiddenEpi {
         }
 #endif
         if constexpr (S == 0) {            // pre-activation (hi + 2^-11 lo), f16-range clamp, exp2 argument
-            const floatx2 c11 = {4.8828125e-4f, 4.8828125e-4f}, c22 = {2.384185791015625e-7f, 2.384185791015625e-7f};
+            const floatx2 c11 = {4.8828125e-4f, 4.8828125e-4f};
             constexpr float KE = G::ACT == CADM_ACT_TANH ? -2.0f * 1.4426950408889634f : -1.4426950408889634f;
             const floatx2 ke = {KE, KE};
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 floatx2 pre = __builtin_elementwise_fma(q ? hi2(lo) : lo2(lo), c11, q ? hi2(hi) : lo2(hi));
-                if constexpr (G::NPROD == 4) pre = __builtin_elementwise_fma(q ? hi2(ll) : lo2(ll), c22, pre);
                 pre[0] = fminf(pre[0], 60000.0f);
                 pre[1] = fminf(pre[1], 60000.0f);
                 st.v[q] = pre;
-                st.s[q] = pre * ke;
+                // swish: the packed weights carry log2(e) (xdl_geo.h: CADM_XDL_SWISH_FOLD), pre IS the exp2 argument up to its sign
+                if constexpr (G::ACT == CADM_ACT_SWISH) st.s[q] = -pre;
+                else st.s[q] = pre * ke;
             }
         } else if constexpr (S == 1) {
             if constexpr (G::ACT != CADM_ACT_RELU && G::ACT != CADM_ACT_NONE) {
@@ -311,15 +314,14 @@ struct XHiddenEpi {
                 st.h1[2 * q] = (_Float16)st.v[q][0];
                 st.h1[2 * q + 1] = (_Float16)st.v[q][1];
             }
-        } else if constexpr (S == 4) {     // low part: (h - hi) * 2^11 = fma(hi, -2^11, h * 2^11), exact in fp32, rounded once to f16
-            const floatx2 k11 = {2048.0f, 2048.0f};
+        } else if constexpr (S == 4) {     // low part: h - hi = fma(hi, -1, h), exact in fp32, rounded once to f16 (unscaled: xsplit)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const floatx2 t = st.v[q] * k11;
+                const floatx2 t = st.v[q];
                 const f16x2 hp = {st.h1[2 * q], st.h1[2 * q + 1]};
                 f16x2 lp;
                 asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-                    : "=&v"(lp) : "v"(hp), "s"(-2048.0f), "v"(t[0]), "v"(t[1]));
+                    : "=&v"(lp) : "v"(hp), "s"(-1.0f), "v"(t[0]), "v"(t[1]));
                 st.h2[2 * q] = lp[0];
                 st.h2[2 * q + 1] = lp[1];
             }
@@ -351,7 +353,6 @@ struct XHeadEpi {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             v[r] = fmaf(lo[r], 4.8828125e-4f, hi[r]);
-            if constexpr (G::NPROD == 4) v[r] = fmaf(ll[r], 2.384185791015625e-7f, v[r]);
         }
         *reinterpret_cast<floatx4*>(xsmem + G::OFULL + hh * G::OFULL_T + (ht * 64 + lane) * 16) = v;
     }
@@ -422,7 +423,7 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
 #pragma unroll
         for (int k = 0; k < gs; ++k)
 #pragma unroll
-            for (int h = 0; h < MT; ++h) xdl_operand_nops<G::NPROD == 4>(hi[gp][k][h], lo[gp][k][h], ll[gp][k][h]);      // VALU-zeroed accumulators -> MFMA srcC
+            for (int h = 0; h < MT; ++h) xdl_operand_nops<false>(hi[gp][k][h], lo[gp][k][h], ll[gp][k][h]);      // VALU-zeroed accumulators -> MFMA srcC
         static_for(std::make_integer_sequence<int, NCHL>{}, [&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int j0 = GS * g * NCHL + c * gs;
@@ -431,7 +432,7 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
             static_for(std::make_integer_sequence<int, NPR * gs * MT>{}, [&](auto mc) {      // hi(k,h).. lo(k,h).. lo'(k,h).. [ll(k,h)..]
                 constexpr int h = decltype(mc)::value % MT, k = (decltype(mc)::value / MT) % gs, prod = decltype(mc)::value / (MT * gs);
                 constexpr int j = j0 + k;
-                floatx4& acc = prod == 0 ? hi[gp][k][h] : prod == 3 ? ll[gp][k][h] : lo[gp][k][h];
+                floatx4& acc = (prod == 0 || prod == 2) ? hi[gp][k][h] : lo[gp][k][h];      // w1 x1, w1 x2 | w2 x1 [, w2 x2] (x2 unscaled: xdl_geo.h)
                 const f16x8& x = prod >= 2 ? X2[c % XD][h] : X1[c % XD][h];
                 constexpr int part = (prod == 1 || prod == 3) ? 1 : 0;
                 if constexpr (j < NRES) xmfma_res(acc, res[j][part], x);
@@ -461,7 +462,7 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
 #pragma unroll
             for (int k = 0; k < gs; ++k)
 #pragma unroll
-                for (int h = 0; h < MT; ++h) xdl_result_nops<G::NPROD == 4>(hi[gp][k][h], lo[gp][k][h], ll[gp][k][h]);
+                for (int h = 0; h < MT; ++h) xdl_result_nops<false>(hi[gp][k][h], lo[gp][k][h], ll[gp][k][h]);
             static_for(std::make_integer_sequence<int, NST>{}, [&](auto sc) {
 #pragma unroll
                 for (int k = 0; k < gs; ++k)

@@ -3,10 +3,15 @@
 //
 //   * A dense layer is evaluated transposed (OUT^T = W^T * IN^T) with v_mfma_f32_16x16x32_f16: the weights are
 //     the A operand (16 output units x 32 input features), 16 data rows are the B / D columns.
-//   * fp32 accuracy on the f16 matrix pipe: every fp32 value v is split as  v = v1 + 2^-11 * v2,
-//     v1 = f16_rn(v), v2 = f16_rn((v - v1) * 2^11)  (the 2^11 keeps the low part a NORMAL f16 number), and a
-//     product  w * x  is evaluated as  w1*x1  (accumulator HI)  +  2^-11 * (w2*x1 + w1*x2)  (accumulator LO);
-//     the dropped term w2*x2 is <= 2^-22 |w x|.  3 MFMAs at 16x the fp32-MFMA rate instead of 8.
+//   * fp32 accuracy on the f16 matrix pipe: a WEIGHT is split as  w = w1 + 2^-11 * w2,  w1 = f16_rn(w), w2 = f16_rn((w - w1) * 2^11)
+//     (the 2^11 keeps the low part a NORMAL f16 number); an ACTIVATION as  x = x1 + x2,  x1 = f16_rn(x), x2 = f16_rn(x - x1), unscaled
+//     (round 4: the scaling cost the epilogue 2 of its 28 instructions per tile, and the kernels are bound by their VALU instructions as
+//     much as by their MFMAs; a low part below the f16 normal range is a subnormal: 3e-8 ABSOLUTE error on an activation below 0.25).
+//     A product  w * x  is evaluated as  w1*x1 + w1*x2  (accumulator HI)  +  2^-11 * w2*x1  (accumulator LO); the dropped term
+//     w2*x2 is <= 2^-22 |w x| (layers wider than 256 add it to LO).  3 MFMAs at 16x the fp32-MFMA rate instead of 8.
+//   * swish layers (the reference's default): log2(e) is folded into the packed weights -- layer 0's W and every hidden bias are
+//     multiplied by it, the head's W divided -- so a hidden pre-activation arrives as  p' = log2(e) * p,  sigmoid(p) = 1 / (1 + exp2(-p'))
+//     needs no multiply, and the activation handed on is  p' * sigmoid(p) = log2(e) * swish(p)  (2 more instructions per tile saved).
 //   * An output tile is 16 units; the K dimension of the layers that consume a hidden layer is cut in chunks of
 //     32 = one PAIR of producer tiles, so a lane's D fragments (units 4g..4g+3 of tiles 2c, 2c+1) ARE its B fragment
 //     for chunk c: activations cross layers through LDS without any cross-lane movement.
@@ -19,6 +24,7 @@
 #pragma once
 
 #define CADM_XDL_FRAG_BYTES 2048
+#define CADM_XDL_LOG2E 1.4426950408889634f
 // Tiles a wave accumulates at a time.  Waves 0-3 (the first wave of each SIMD) take their tiles two at a time and run
 // the epilogues at the end; waves 4-7 go tile by tile, each tile's epilogue right behind its MFMAs.  The two waves of a
 // SIMD are thereby out of phase: one wave's epilogue (VALU) meets the other's MFMAs instead of its epilogue

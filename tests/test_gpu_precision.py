@@ -75,7 +75,7 @@ def test_precision_beyond_hid200(gpu, cfgname, hidden, n):
 
 # ------------------------------------------------------------------------------------------------------------------
 # (iii) edges of the f16 range -- the kernel's DOCUMENTED behaviour (DESIGN.md numerics notes):
-#   * network inputs are clamped to +-65000 and hidden pre-activations to <= 60000 (the f16 operands of the matrix pipe
+#   * network inputs are clamped to +-65000 and hidden pre-activations to <= 60000 (swish: 60000 / log2 e = 41589; the f16 operands of the matrix pipe
 #     top out at 65504); inside those clamps results keep the 1e-5 bar.  Only diverged rows ever get there;
 #   * f16-subnormal-range operands (|x| < 6.1e-5) keep an ABSOLUTE accuracy of 2^-35 (3e-11) instead of a relative 2^-22;
 #   * a non-finite or > 65000 weight is refused at cadm_repack; a non-finite observation / action / context value makes
@@ -128,10 +128,11 @@ def test_activations_beyond_the_f16_range_are_clamped(gpu):
     prob, obs_rows, actions, eps = _problem(seed=32)
     prob["ff"]["hidden_0_weight"] = prob["ff"]["hidden_0_weight"] * 2.0e4        # layer-0 pre-activations of order 1e5
     eng = make_engine(prob, p=20, H=1)
-    act = lambda x: onets.swish(np.minimum(x, np.float32(60000.0)))
+    # (swish nets: the packed weights carry log2(e), so the clamp at 60000 acts on log2(e) * pre: 41589 in the model's own units)
+    act = lambda x: onets.swish(np.minimum(x, np.float32(60000.0 / 1.4426950408889634)))
     rows, traj, r_ref, t_ref = _one_step(prob, eng, obs_rows, actions, eps, 20, hidden_act=act)
     assert np.isfinite(traj).all()
-    assert_close(traj, t_ref, 2e-5, "next obs with pre-activations clamped at 60000 vs the fp32 oracle with the same clamp")
+    assert_close(traj, t_ref, 2e-5, "next obs with pre-activations clamped at 60000 / log2(e) vs the fp32 oracle with the same clamp")
     _, t_plain = oplanner.rollout_indexed(*_oracle_args(prob), actions.astype(np.float32), eps.astype(np.float32), 5, 20, False,
                                           obs_rows=obs_rows.astype(np.float32), return_traj=True)
     assert not np.allclose(t_plain, t_ref, rtol=1e-3)   # the clamp was really exercised
