@@ -98,7 +98,7 @@ __host__ __device__ constexpr int xdl_frag_index(int ntw, int nchl, int ti, int 
 //           2: wave-tile kernel, 4 tiles per workgroup           cap 4        CADM_COST_WT4   (one wave per SIMD: never wins, exists for the tests)
 //           3: wave-tile kernel, 8 tiles per workgroup           cap 8        CADM_COST_WT8   (per round)
 // 1 unit = one CU share of the member (n_cus / E tiles); costs in units of the one-tile launch, measured at the cfg2 / cfg3 geometry
-// (halfcheetah, 51 workgroups per member: 168 / 269 / 615 / 910 us, profiles/r4_s3_flavour_table.txt).  The cheapest cover is a small
+// (halfcheetah, 51 workgroups per member: 165 / 261 / 600 / 876 us, profiles/r4_s3_flavour_table.txt).  The cheapest cover is a small
 // dynamic programme, f(u) = min over flavours (cost + f(u - cap)); count[o] = launches (rounds) of flavour o.
 #ifndef CADM_COST_MT2
 #define CADM_COST_MT2 1.6f
@@ -107,7 +107,7 @@ __host__ __device__ constexpr int xdl_frag_index(int ntw, int nchl, int ti, int 
 #define CADM_COST_WT4 3.6f
 #endif
 #ifndef CADM_COST_WT8
-#define CADM_COST_WT8 5.4f
+#define CADM_COST_WT8 5.3f
 #endif
 inline void xdl_plan_units(int units, bool mt2_ok, bool wt_ok, int (&count)[4]) {
     const int capu[4] = {1, mt2_ok ? 2 : 0, wt_ok ? 4 : 0, wt_ok ? 8 : 0};

@@ -9,7 +9,7 @@ import pytest
 from cadm_amd import _lib
 
 CAP = (1, 2, 4, 8)
-COST = (1.0, 1.6, 3.6, 5.4)
+COST = (1.0, 1.6, 3.6, 5.3)
 
 
 def plan(units, two=True, wave=True):
