@@ -13,7 +13,7 @@
 //     1-4 KB LDS image to get from "dims per lane" to the B-operand layout);
 //   * every SIMD hosts the same work (two waves x 13 tiles), whatever the hidden width;
 //   * the weights are what the waves share: the member's fragment stream (ONE consumption order for all waves: layer by layer,
-//     tile pair by tile pair) goes L2 -> LDS once per workgroup and step by LDS-DMA (global_load_lds_dwordx4, no registers), in
+//     tile pair by tile pair) goes L2 -> LDS once per workgroup and step by LDS-DMA (buffer_load_dwordx4 .. lds, no registers), in
 //     BLOCKS of one tile pair (28 KB at HID = 200), double-buffered: at every block boundary one barrier says "block b has
 //     landed, block b-1 is no longer read", then the waves request block b+1 and compute block b from LDS.
 //     L2 -> CU traffic per row drops 5x against the one-tile cooperative kernel (640 KB per step for 128 rows instead of 404 KB for 16).
@@ -68,16 +68,18 @@ struct WT {
     }
 };
 
-__device__ __forceinline__ void wt_glds16(const unsigned char* gsrc, unsigned char* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
 // The ring's bookkeeping: two slots; `par` = slot of the block computed next, `next` = stream offset of the block REQUESTED next.
 struct WTRing {
-    const unsigned char* src;      // this member's stream
+    __amdgpu_buffer_rsrc_t rsrc;   // the whole stream buffer (all members)
+    unsigned mbase;                // this member's byte offset in it
     unsigned next, bytes;
     int par;
 };
+
+// one LDS-DMA piece: 64 lanes x 16 B from stream offset `off` of this member to lds_dst (wave-uniform) + lane * 16
+__device__ __forceinline__ void wt_glds16(const WTRing& rg, unsigned off, int lane, unsigned char* lds_dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg.rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, lane * 16, rg.mbase + off, 0, 0);
+}
 
 
 // this wave's share of a block of nf fragments (= 2 nf pieces of 1 KB, piece i to wave i mod 8) into slot `slot_idx`
@@ -91,8 +93,9 @@ __device__ __forceinline__ void wt_request(WTRing& rg, unsigned char* sm, int sl
     static_for(std::make_integer_sequence<int, (2 * NF + W::NW - 1) / W::NW>{}, [&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const int piece = wave + W::NW * i;
-        if constexpr (W::NW * i + W::NW - 1 < 2 * NF) wt_glds16(rg.src + rg.next + piece * 1024 + lane * 16, dst + piece * 1024);
-        else { if (piece < 2 * NF) wt_glds16(rg.src + rg.next + piece * 1024 + lane * 16, dst + piece * 1024); }
+        // buffer form of the LDS-DMA load: descriptor + scalar offset + the lane's 16 B -- no per-request 64-bit address arithmetic on the VALU
+        if constexpr (W::NW * i + W::NW - 1 < 2 * NF) wt_glds16(rg, rg.next + (unsigned)piece * 1024u, lane, dst + piece * 1024);
+        else { if (piece < 2 * NF) wt_glds16(rg, rg.next + (unsigned)piece * 1024u, lane, dst + piece * 1024); }
     });
 #endif
     rg.next += (unsigned)NF * CADM_XDL_FRAG_BYTES;
@@ -220,7 +223,8 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
 
     // ---- the weight ring: the member's stream, block by block, forever (a step ends where the next one starts) ----
     WTRing rg;
-    rg.src = reinterpret_cast<const unsigned char*>(a.xw1) + (size_t)e * a.xw1_member_b;
+    rg.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.xw1, 0, a.xw1_member_b * (unsigned)a.E, 0x00020000);
+    rg.mbase = (unsigned)e * a.xw1_member_b;
     rg.bytes = a.xw1_member_b;
     rg.par = 0;
     rg.next = 0;

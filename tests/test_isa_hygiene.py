@@ -172,7 +172,7 @@ def test_wave_tile_kernel_shape():
             assert m, sym
             env, ctx, hid = int(m.group(1)), int(m.group(2)), int(m.group(3))
             ins = [x.split("//")[0].strip() for x in ins if x.strip()]
-            assert any(x.startswith("global_load_lds_dwordx4") for x in ins), "%s: no LDS-DMA weight requests" % sym
+            assert any(x.startswith("buffer_load_dwordx4") and x.endswith(" lds") for x in ins), "%s: no LDS-DMA weight requests" % sym
             n_mfma = sum(1 for x in ins if x.startswith("v_mfma_f32_16x16x32_f16"))
             if hid == 200 and env == 0:
                 # layer 0: 13 tiles x (1 or 2) chunks x 3; three hidden layers (the layer loop is unrolled: the activation register
