@@ -102,7 +102,7 @@ __device__ __forceinline__ void wt_request(WTRing& rg, unsigned char* sm, int sl
     if (rg.next >= rg.bytes) rg.next = 0;
 }
 
-// Block boundary.  One barrier says: block b has landed (hipcc drains vmcnt in front of __syncthreads(), so every wave's share of the
+// Block boundary.  One barrier says: block b has landed (s_waitcnt vmcnt(0) in front of it: every wave's share of the
 // requests issued one block ago is in LDS) and nobody reads block b-1 any more; then block b+1 is requested into the slot b-1 left.
 // Measured alternatives (profiles/r4_wave_tile.md, same box): three slots with the next block's first fragments requested from LDS a
 // block ahead +-0; a raw s_barrier behind a counted s_waitcnt vmcnt(k) (requests in flight across the barrier) +4 %; the requests
@@ -112,6 +112,9 @@ template <class G, int NF_NEXT>
 __device__ __forceinline__ const unsigned char* wt_block_boundary(WTRing& rg, unsigned char* sm, int wave, int lane) {
     using W = WT<G>;
 #if !defined(CADM_WT_EXPERIMENT_NOBAR)
+    // every wave's share of the requests issued one block ago must be IN LDS before any wave reads the block: the wait is stated here and not
+    // left to hipcc (a workgroup-scope barrier does not have to drain vmcnt; tests/test_isa_hygiene.py checks the shipped code for it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #endif
     const int ahead = rg.par + W::SLOTS - 1;
@@ -233,6 +236,7 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
         constexpr int b = decltype(bc)::value;
         wt_request<G, W::block_frags(b)>(rg, sm, b, wave, lane);
     });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (as at every block boundary: this wave's pieces of the first block have landed)
     __syncthreads();
 
     const int r16 = r * 16;
@@ -438,8 +442,8 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
                     constexpr int g = decltype(gc)::value, GS = W::gs_hidden(g);
                     static_assert(W::SLOTS == 2, "a block boundary names the block right behind the current one");
                     auto epilogue = [&](floatx4 (&hi)[2], floatx4 (&lo)[2]) __attribute__((always_inline)) {
-                        const XHiddenEpi<G> epi{nullptr, nullptr, 0, 0, 0, 0, 0};
-                        typename XHiddenEpi<G>::State st[2];
+                        const XHiddenEpi<G, CADM_EPI_PACKED_WT> epi{nullptr, nullptr, 0, 0, 0, 0, 0};
+                        typename XHiddenEpi<G, CADM_EPI_PACKED_WT>::State st[2];
                         const floatx4 zero = floatx4{0.f, 0.f, 0.f, 0.f};
                         static_for(std::make_integer_sequence<int, 5>{}, [&](auto sc) {
 #pragma unroll

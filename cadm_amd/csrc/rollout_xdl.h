@@ -239,10 +239,26 @@ __device__ __forceinline__ void xsplit(float v, _Float16& hi, _Float16& lo) {
 // accumulator's initial value).  Cut in STAGES of mutually independent instructions (stage s of every value before
 // stage s+1 of any): a wave issues in order, so a VALU op waiting for its predecessor's result (v_exp -> v_add -> v_rcp ..)
 // would hold up the MFMAs queued behind it.
-template <class G>
+// PACKED: the arithmetic on pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: 24 VALU instructions per tile) or on scalars (30).  Packed fp32 does
+// NOT co-execute with the matrix pipe on gfx950 -- one v_pk_* behind a v_mfma_f32_16x16x32_f16 costs the wave +19 cycles, a wave of packed work
+// runs at the SUM of its own time and its SIMD partner's MFMA time -- plain v_fma_f32 / v_exp_f32 / v_cvt overlap 0.6-0.9 with the partner's
+// MFMAs and two of them hide behind each of the wave's own (tools/micro/gen_coissue_bench.py, profiles/r5_coissue_microbench.md; rounds 3-4
+// concluded "VALU and MFMA do not overlap" from micro-benchmarks hipcc had SLP-packed).  Which form is faster is a property of the kernel:
+// the wave-tile kernel's waves drift apart inside a block, an epilogue meets the partner's MFMAs: scalar, cfg3 -1.8 %; the cooperative
+// kernel's waves run the same phase between the same barriers, the shorter epilogue wins: packed, cfg2 -0.5..1.5 % (same-box A/B,
+// profiles/r5_wave_tile_experiments.md).  The rollout translation units are compiled with -fno-slp-vectorize so hipcc does not re-pack scalars.
+#ifndef CADM_EPI_PACKED_COOP
+#define CADM_EPI_PACKED_COOP 1
+#endif
+#ifndef CADM_EPI_PACKED_WT
+#define CADM_EPI_PACKED_WT 0
+#endif
+template <class G, bool PACKED = CADM_EPI_PACKED_COOP>
 struct XHiddenEpi {
     static constexpr int NSTAGE = 6;
-    struct State { floatx2 v[2], s[2]; f16x4 h1, h2; };
+    struct StateP { floatx2 v[2], s[2]; f16x4 h1, h2; };
+    struct StateS { float v[4], s[4]; f16x4 h1, h2; };      // (scalars: a pair type invites the instruction selector to re-pack)
+    using State = std::conditional_t<PACKED, StateP, StateS>;
     unsigned char* xsmem;
     const float* xb;
     int bias_off;
@@ -254,10 +270,6 @@ struct XHiddenEpi {
         if constexpr (G::BIAS_LDS) return *reinterpret_cast<const floatx4*>(xsmem + bias_off + tile * G::BIAS_TILE_B + (lane >> 4) * 16);
         else return *reinterpret_cast<const floatx4*>(xb + bt * 4);
     }
-    // The arithmetic is written on PAIRS (floatx2) so that it compiles to packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 /
-    // v_pk_add_f32: two values per 4-cycle issue); the low f16 part comes from v_fma_mixlo/hi_f16 (f16 source, f32 addend, f16
-    // result: one instruction instead of convert, fma, convert).  VALU instructions of the two waves of a SIMD do not overlap
-    // with its MFMAs on gfx950 (tools/micro/coexec_bench.hip), so every instruction saved here is time saved per layer.
     static __device__ __forceinline__ floatx2 lo2(const floatx4& x) { return __builtin_shufflevector(x, x, 0, 1); }
     static __device__ __forceinline__ floatx2 hi2(const floatx4& x) { return __builtin_shufflevector(x, x, 2, 3); }
     template <int S>
@@ -268,9 +280,11 @@ struct XHiddenEpi {
             return;
         }
 #endif
+        constexpr float KE = G::ACT == CADM_ACT_TANH ? -2.0f * 1.4426950408889634f : -1.4426950408889634f;
+        constexpr bool SIG = G::ACT != CADM_ACT_RELU && G::ACT != CADM_ACT_NONE;       // nonlinearities built on sigmoid
+        if constexpr (PACKED) {
         if constexpr (S == 0) {            // pre-activation (hi + 2^-11 lo), f16-range clamp, exp2 argument
             const floatx2 c11 = {4.8828125e-4f, 4.8828125e-4f};
-            constexpr float KE = G::ACT == CADM_ACT_TANH ? -2.0f * 1.4426950408889634f : -1.4426950408889634f;
             const floatx2 ke = {KE, KE};
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -283,12 +297,12 @@ struct XHiddenEpi {
                 else st.s[q] = pre * ke;
             }
         } else if constexpr (S == 1) {
-            if constexpr (G::ACT != CADM_ACT_RELU && G::ACT != CADM_ACT_NONE) {
+            if constexpr (SIG) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) { st.s[q][0] = __builtin_amdgcn_exp2f(st.s[q][0]); st.s[q][1] = __builtin_amdgcn_exp2f(st.s[q][1]); }
             }
         } else if constexpr (S == 2) {
-            if constexpr (G::ACT != CADM_ACT_RELU && G::ACT != CADM_ACT_NONE) {
+            if constexpr (SIG) {
                 const floatx2 one = {1.0f, 1.0f};
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -325,7 +339,51 @@ struct XHiddenEpi {
                 st.h2[2 * q] = lp[0];
                 st.h2[2 * q + 1] = lp[1];
             }
+        }
         } else {
+        if constexpr (S == 0) {            // pre-activation (hi + 2^-11 lo), f16-range clamp; the exp2 argument of tanh / sigmoid
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st.v[r] = fminf(fmaf(lo[r], 4.8828125e-4f, hi[r]), 60000.0f);
+                if constexpr (SIG && G::ACT != CADM_ACT_SWISH) st.s[r] = st.v[r] * KE;
+            }
+        } else if constexpr (S == 1) {
+            // swish: the packed weights carry log2(e) (xdl_geo.h), the pre-activation IS the exp2 argument up to its sign (a source modifier)
+            if constexpr (SIG) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st.s[r] = __builtin_amdgcn_exp2f(G::ACT == CADM_ACT_SWISH ? -st.v[r] : st.s[r]);
+            }
+        } else if constexpr (S == 2) {
+            if constexpr (SIG) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st.s[r] = __builtin_amdgcn_rcpf(st.s[r] + 1.0f);
+            }
+        } else if constexpr (S == 3) {     // the nonlinearity (dynamics.py:17-24) and the high f16 part
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (G::ACT == CADM_ACT_SWISH) st.v[r] = st.v[r] * st.s[r];                 // x * sigmoid(x), :23
+                else if constexpr (G::ACT == CADM_ACT_SIGMOID) st.v[r] = st.s[r];                    // 1 / (1 + e^-x)
+                else if constexpr (G::ACT == CADM_ACT_TANH) {      // 2 sigmoid(2x) - 1 (s was built from 2x); odd series near 0, where that cancels
+                    const float x = st.v[r], x2 = x * x;
+                    const float ser = x * fmaf(x2, fmaf(x2, fmaf(x2, -0.05396825396825397f, 0.13333333333333333f), -0.3333333333333333f), 1.0f);
+                    st.v[r] = fabsf(x) < 0.1f ? ser : fmaf(2.0f, st.s[r], -1.0f);
+                } else if constexpr (G::ACT == CADM_ACT_RELU) st.v[r] = fmaxf(st.v[r], 0.0f);
+                else if constexpr (G::ACT == CADM_ACT_NONE) st.v[r] = fmaxf(st.v[r], -60000.0f);     // f16 range, both sides
+                st.h1[r] = (_Float16)st.v[r];
+            }
+        } else if constexpr (S == 4) {     // low part: h - hi = fma(hi, -1, h), exact in fp32, rounded once to f16 (unscaled: xsplit)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f16x2 hp = {st.h1[2 * q], st.h1[2 * q + 1]};
+                f16x2 lp;
+                asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                    : "=&v"(lp) : "v"(hp), "s"(-1.0f), "v"(st.v[2 * q]), "v"(st.v[2 * q + 1]));
+                st.h2[2 * q] = lp[0];
+                st.h2[2 * q + 1] = lp[1];
+            }
+        }
+        }
+        if constexpr (S == 5) {
             const int Tg = tstart + ti;
             unsigned char* dst = xsmem + out + hh * G::ACT_T + ((Tg >> 1) * 64 + lane) * 16 + (Tg & 1) * 8;
             *reinterpret_cast<f16x4*>(dst) = st.h1;

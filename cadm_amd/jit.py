@@ -105,7 +105,7 @@ def build(env_kind, C_, hid, nh, act, noise, verbose=False):
         if os.path.exists(path):                     # another process built it while this one waited
             return path
         tmp = path + ".tmp%d" % os.getpid()
-        cmd = [cc, "--offload-arch=" + ARCH, "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
+        cmd = [cc, "--offload-arch=" + ARCH, "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
                "-Wno-unused-function", "-DCADM_JIT_MODULE", "-DCADM_JIT_ENV=%d" % env_kind, "-DCADM_JIT_C=%d" % C_, "-DCADM_JIT_HID=%d" % hid,
                "-DCADM_JIT_NH=%d" % nh, "-DCADM_JIT_ACT=%d" % act, "-DCADM_JIT_NOISE=%d" % noise,
                os.path.join(_lib.CSRC, "rollout_jit.hip"), "-o", tmp]

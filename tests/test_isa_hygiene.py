@@ -182,5 +182,69 @@ def test_wave_tile_kernel_shape():
             if hid <= 200 and env != 2:
                 scratch = [x for x in ins if x.startswith("scratch_")]
                 assert not scratch, "%s: %d scratch accesses (e.g. %s)" % (sym, len(scratch), scratch[0])
+            # the weight ring is only correct if every wave's LDS-DMA pieces (tracked by vmcnt) have landed BEFORE the block
+            # barrier -- walking back from every s_barrier, a `s_waitcnt vmcnt(0)` must come before any LDS-DMA request
+            for i, x in enumerate(ins):
+                if not x.startswith("s_barrier"):
+                    continue
+                j = i - 1
+                while j >= 0 and not (ins[j].startswith("s_waitcnt") and re.search(r"vmcnt\(0\)", ins[j])):
+                    assert not (ins[j].startswith("buffer_load_dwordx4") and ins[j].endswith(" lds")), \
+                        "%s: an LDS-DMA request at instruction %d reaches the barrier at %d without a vmcnt(0) wait" % (sym, j, i)
+                    assert not ins[j].startswith(("s_barrier", "s_endpgm")), "%s: barrier at %d is not preceded by s_waitcnt vmcnt(0)" % (sym, i)
+                    j -= 1
+                assert j >= 0, "%s: barrier at %d is not preceded by s_waitcnt vmcnt(0)" % (sym, i)
             seen += 1
     assert seen >= 5 * 2 * 3
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump not available")
+def test_coissue_bench_streams_are_what_they_claim(tmp_path):
+    """VERDICT r4 #1a: the MFMA / VALU co-issue micro-benchmark of rounds 3-4 was SLP-packed (542 v_pk_*_f32) and clustered by hipcc, so it
+    measured packed fp32 next to MFMAs -- which does not co-execute -- and the conclusion drawn from it ("VALU and MFMA do not overlap on
+    gfx950") was wrong for plain VALU.  tools/micro/gen_coissue_bench.py writes every stream as ONE asm block; this test compiles a sample of
+    its variants and checks the disassembly: exactly F fillers behind every MFMA, evenly spaced, no packed fp32 in the scalar variants and
+    nothing but packed fp32 in the packed ones."""
+    import importlib.util
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    spec = importlib.util.spec_from_file_location("gen_coissue_bench", os.path.join(ROOT, "tools", "micro", "gen_coissue_bench.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    sample = [v for v in gen.variants() if v[0] in ("solo_m16_n4_fma3", "both_m16_n8_fma2", "solo_m32_n2_fma5", "solo_m16_n4_pkfma2", "both_m16_n4_epi3",
+                                                     "both_m16_n4_epipk3", "pair_m16_n4_fma")]
+    assert len(sample) == 7
+    src = ["#include <hip/hip_runtime.h>", "typedef float floatx2 __attribute__((ext_vector_type(2)));", "typedef float floatx4 __attribute__((ext_vector_type(4)));",
+           "typedef float floatx16 __attribute__((ext_vector_type(16)));", "typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));"]
+    src += [gen.variant(*v) for v in sample]
+    hip = tmp_path / "coissue_sample.hip"
+    hip.write_text("\n".join(src))
+    obj = tmp_path / "coissue_sample.o"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-c", str(hip), "-o", str(obj)], check=True, capture_output=True)
+    kernels = {}
+    for img in _code_objects(str(obj)):
+        for sym, ins in _kernels(img, "k_").items():
+            kernels[sym] = [x.split("//")[0].strip() for x in ins if x.strip()]
+    for (vname, mf, nm, kind, F, threads, pair) in sample:
+        ins = next(v for k, v in kernels.items() if ("k_" + vname) in k)
+        mf_at = [i for i, x in enumerate(ins) if x.startswith(gen.MFMA[mf][0])]
+        assert len(mf_at) == nm, "%s: %d MFMAs in the loop body, expected %d" % (vname, len(mf_at), nm)
+        packed = [x for x in ins[mf_at[0]:mf_at[-1] + F + 1] if x.startswith("v_pk_")]
+        if pair:      # the MFMA stream is bare; the filler stream is a second loop
+            assert all(b - a == 1 for a, b in zip(mf_at, mf_at[1:])), vname
+            continue
+        # evenly spaced: exactly F fillers between consecutive MFMAs, and behind the last one
+        assert all(b - a == F + 1 for a, b in zip(mf_at, mf_at[1:])), "%s: fillers are not evenly spaced" % vname
+        body = ins[mf_at[0]:mf_at[-1] + F + 1]
+        fillers = [x for i, x in enumerate(body) if (i % (F + 1)) != 0]
+        assert len(fillers) == nm * F
+        if kind in ("fma", "epi"):
+            assert not packed, "%s: packed fp32 in a scalar stream: %s" % (vname, packed[:2])
+            if kind == "fma":
+                assert all(x.startswith("v_fma_f32") for x in fillers), vname
+        if kind == "pkfma":
+            assert all(x.startswith("v_pk_fma_f32") for x in fillers), vname
+        if kind == "epipk":
+            assert packed, vname
