@@ -5,34 +5,7 @@
 // ---------------------------------------------------------------------------------------------
 // action sampling
 // ---------------------------------------------------------------------------------------------
-// one candidate action element L = ((mi * n + c) * H + t) * A + a from the CEM distribution (mu, var) of its (t, a)
-__device__ __forceinline__ float sample_action(float mu, float var, const float* __restrict__ z, size_t L, uint32_t seed, uint32_t call,
-                                               int it, float lb, float ub) {
-    const float lbd = mu - lb, ubd = ub - mu;                                  // :425
-    const float a1 = lbd / 2.0f, a2 = ubd / 2.0f;
-    const float cv = fminf(fminf(a1 * a1, a2 * a2), var);                      // :426
-    float zz;
-    if (z) {
-        zz = z[L];
-    } else {
-        // TF TruncatedNormalDistribution: reject |x| >= 2 (kTruncateValue)
-        zz = 0.0f;
-        for (uint32_t attempt = 0; attempt < 64; ++attempt) {
-            uint32_t r[4];
-            philox4x32_10((uint32_t)(L & 0xFFFFFFFFull), attempt, (uint32_t)(L >> 32),
-                          CADM_STREAM_ACT | ((uint32_t)it << 8), seed, call, r);
-            float c0, c1, c2, c3;
-            box_muller(u01(r[0]), u01(r[1]), c0, c1);
-            box_muller(u01(r[2]), u01(r[3]), c2, c3);
-            if (fabsf(c0) < 2.0f) { zz = c0; break; }
-            if (fabsf(c1) < 2.0f) { zz = c1; break; }
-            if (fabsf(c2) < 2.0f) { zz = c2; break; }
-            if (fabsf(c3) < 2.0f) { zz = c3; break; }
-        }
-    }
-    return mu + sqrtf(cv) * zz;                                                // :429
-}
-
+// (sample_action: common.h -- also used by the fused head of the staged planner call, context.hip)
 __global__ void sample_actions_kernel(const float* __restrict__ mean, const float* __restrict__ var,
                                       const float* __restrict__ z, uint32_t seed, uint32_t call, int it,
                                       int m, int n, int H, int A, float lb, float ub,
@@ -82,12 +55,7 @@ __global__ void particle_mean_kernel(const float* __restrict__ rows, int total, 
 // ---------------------------------------------------------------------------------------------
 // elite refit: bitonic sort of (return desc, index asc) keys in LDS, then statistics
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t make_key(float v, uint32_t idx) {
-    uint32_t u = __float_as_uint(v);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-orderable
-    return ((uint64_t)(~u) << 32) | idx;               // ascending key == descending value, ties -> lower idx
-}
-
+// (make_key: common.h)
 __device__ __forceinline__ float cand_at(const float* cand, int G, int n_local, int m, int mi, int ni) {
     return cand[((size_t)(ni / n_local) * m + mi) * n_local + (ni % n_local)];
 }
@@ -299,7 +267,9 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
 // `actions`: the elites' values of these elements were read before).  Arithmetic = cem_refit_kernel + sample_actions_kernel
 // (same summation order, same Philox counters): the fused planner equals the stepwise composition bit for bit.
 // ---------------------------------------------------------------------------------------------
-#define CADM_FUSED_EPW 8
+#ifndef CADM_FUSED_EPW
+#define CADM_FUSED_EPW 4      // elements per workgroup: n x EPW <= 1024 samples = one round of the workgroup's threads at n <= 256
+#endif
 __global__ __launch_bounds__(1024) void cem_refit_sample_kernel(const float* __restrict__ cand, const float* __restrict__ rows, int p, int G,
                                                                int n_local, float* __restrict__ actions, int m, int H, int A, int K, float alpha,
                                                                const float* mean_in, const float* var_in, float* mean_out, float* var_out, float lb,
@@ -314,6 +284,9 @@ __global__ __launch_bounds__(1024) void cem_refit_sample_kernel(const float* __r
     const int NS = (HA + CADM_FUSED_EPW - 1) / CADM_FUSED_EPW;
     const int mi = blockIdx.x / NS, ta0 = (blockIdx.x % NS) * CADM_FUSED_EPW;
     const int ne = HA - ta0 < CADM_FUSED_EPW ? HA - ta0 : CADM_FUSED_EPW;
+    // (requested now, consumed behind the statistics: their round trip used to sit at the end of the kernel's dependent chain)
+    float mean_pre = 0.0f, var_pre = 0.0f;
+    if (tid < ne) { mean_pre = mean_in[(size_t)mi * HA + ta0 + tid]; var_pre = var_in[(size_t)mi * HA + ta0 + tid]; }
     // ---- elites: rank by counting (keys are unique: candidate index in the low word), as cem_refit_kernel's small-n path;
     //      the n x n comparisons are cut in 4 column quarters (1024 threads), partial ranks meet in integer LDS atomics
     if (tid < 256) rank_s[tid] = 0;
@@ -376,8 +349,8 @@ __global__ __launch_bounds__(1024) void cem_refit_sample_kernel(const float* __r
             for (int g = 0; g < KG; ++g) nv += part[g * CADM_FUSED_EPW + tid];
             nv = nv / (float)K;                                                    // :483
             const size_t o = (size_t)mi * HA + ta0 + tid;
-            const float mo = mean_in[o] * alpha + (1.0f - alpha) * nmean[tid];     // :485
-            const float vo = var_in[o] * alpha + (1.0f - alpha) * nv;              // :486
+            const float mo = mean_pre * alpha + (1.0f - alpha) * nmean[tid];       // :485
+            const float vo = var_pre * alpha + (1.0f - alpha) * nv;                // :486
             mean_out[o] = mo; var_out[o] = vo;
             nd[tid] = mo; nd[CADM_FUSED_EPW + tid] = vo;
         }
@@ -390,8 +363,8 @@ __global__ __launch_bounds__(1024) void cem_refit_sample_kernel(const float* __r
             for (int k = 0; k < K; ++k) { const float d = vals[k * CADM_FUSED_EPW + tid] - nm; v += d * d; }
             const float nv = v / (float)K;
             const size_t o = (size_t)mi * HA + ta0 + tid;
-            const float mo = mean_in[o] * alpha + (1.0f - alpha) * nm;
-            const float vo = var_in[o] * alpha + (1.0f - alpha) * nv;
+            const float mo = mean_pre * alpha + (1.0f - alpha) * nm;
+            const float vo = var_pre * alpha + (1.0f - alpha) * nv;
             mean_out[o] = mo; var_out[o] = vo;
             nd[tid] = mo; nd[CADM_FUSED_EPW + tid] = vo;
         }

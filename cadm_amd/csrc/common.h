@@ -177,6 +177,14 @@ int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, 
                         float* returns_rows, float* traj_out, hipStream_t s, int dry_run = 0, int force_deterministic = -1);
 int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs,
                         float* out, hipStream_t s);
+// Per-call inputs of a small planner call travel as KERNEL ARGUMENTS (cadm_cem_plan_staged, capi.hip): up to CADM_INGEST_MAX floats.
+#define CADM_INGEST_MAX 896
+struct IngestBlock { float v[CADM_INGEST_MAX]; };
+// The head of a staged planner call as ONE launch (context.hip: plan_head_kernel): unpack the ingest block into the device block, the
+// context encoder on the block's history (C > 0), and the candidates of CEM iteration 0.  off[5] = float offsets of obs, cp_obs,
+// cp_act, init_mean, init_var inside the block (-1: absent).
+int cadm_launch_plan_head(cadm_ctx* ctx, const float* host_block, int nfloats, const int32_t off[5], float* dev_block, int m, int n,
+                          uint32_t seed, uint32_t call, float* ctx_out, float* actions_out, hipStream_t s);
 void cadm_train_free(cadm_ctx* ctx);
 // (developer library: dev/dev_api.hip) Adam moment buffers of one trained tensor; layer as in cadm_set_weights, is_bias 0 / 1;
 // layer == -1 / -2: max_logvar / min_logvar of the forward net.  Returns null pointers before cadm_train_configure.
@@ -211,6 +219,43 @@ __device__ __forceinline__ void box_muller(float u1, float u2, float& z0, float&
     z0 = r * __builtin_amdgcn_cosf(u2);
     z1 = r * __builtin_amdgcn_sinf(u2);
 }
+
+// one candidate action element L = ((mi * n + c) * H + t) * A + a from the CEM distribution (mu, var) of its (t, a)
+__device__ __forceinline__ float sample_action(float mu, float var, const float* __restrict__ z, size_t L, uint32_t seed, uint32_t call,
+                                               int it, float lb, float ub) {
+    const float lbd = mu - lb, ubd = ub - mu;                                  // :425
+    const float a1 = lbd / 2.0f, a2 = ubd / 2.0f;
+    const float cv = fminf(fminf(a1 * a1, a2 * a2), var);                      // :426
+    float zz;
+    if (z) {
+        zz = z[L];
+    } else {
+        // TF TruncatedNormalDistribution: reject |x| >= 2 (kTruncateValue)
+        zz = 0.0f;
+        for (uint32_t attempt = 0; attempt < 64; ++attempt) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)(L & 0xFFFFFFFFull), attempt, (uint32_t)(L >> 32),
+                          CADM_STREAM_ACT | ((uint32_t)it << 8), seed, call, r);
+            float c0, c1, c2, c3;
+            box_muller(u01(r[0]), u01(r[1]), c0, c1);
+            if (fabsf(c0) < 2.0f) { zz = c0; break; }
+            if (fabsf(c1) < 2.0f) { zz = c1; break; }
+            box_muller(u01(r[2]), u01(r[3]), c2, c3);      // (the call's second pair: needed by 0.2 % of the draws)
+            if (fabsf(c2) < 2.0f) { zz = c2; break; }
+            if (fabsf(c3) < 2.0f) { zz = c3; break; }
+        }
+    }
+    return mu + sqrtf(cv) * zz;                                                // :429
+}
+
+
+// (return desc, index asc) as one ascending 64-bit key: reproduces tf.nn.top_k's order, ties -> lower index (core/utils.py:475)
+__device__ __forceinline__ uint64_t make_key(float v, uint32_t idx) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-orderable
+    return ((uint64_t)(~u) << 32) | idx;               // ascending key == descending value, ties -> lower idx
+}
+
 
 // tf.nn.softplus (TF 1.15 Eigen functor): threshold = log(eps) + 2
 __device__ __forceinline__ float tf_softplus(float x) {

@@ -3,6 +3,8 @@
 // Two kernels: `context_kernel` for the planner's call (once per get_action on E*m rows, 5 at m = 1, ~1 MFLOP: a latency
 // kernel, one workgroup per (member, row), K split across its waves and reduced through LDS) and `context_batched_kernel` for
 // many histories per call (get_context_pred from the PPO consumer, SURVEY 8f-3: a GEMM chain on the fp32 matrix pipe).
+#include <string.h>
+
 #include "common.h"
 
 #define CP_MAX_WIDTH 1024
@@ -24,17 +26,17 @@ struct CpArgs {
 // so the K dimension is cut 16 ways -- every wave has all of its (at most 15) rows in flight at once.
 #define CP_THREADS 1024
 #define CP_KQ (CP_THREADS / 64)
-__global__ __launch_bounds__(CP_THREADS) void context_kernel(const CpArgs a) {
+// the encoder on ONE (member, history) row: `in_obs(i)` / `in_act(i)` read element i of the row's raw history
+template <class InObs, class InAct>
+__device__ __forceinline__ void context_row(const CpArgs& a, int e, int mi, InObs&& in_obs, InAct&& in_act) {
     __shared__ float xa[CP_MAX_WIDTH];
     __shared__ float xb[CP_MAX_WIDTH];
     __shared__ float red[CP_KQ][256];
-    const int e = blockIdx.x / a.m, mi = blockIdx.x % a.m;
     const int tid = threadIdx.x;
-    const size_t in_row = a.bs ? ((size_t)e * a.m + mi) : (size_t)mi;   // tile(.., [E,1,1]) unless already [E,m,.]
     for (int i = tid; i < a.n_obs; i += CP_THREADS)
-        xa[i] = (a.cp_obs[in_row * a.n_obs + i] - a.obs_mean[i]) / (a.obs_std[i] + 1e-10f);          // :403
+        xa[i] = (in_obs(i) - a.obs_mean[i]) / (a.obs_std[i] + 1e-10f);          // :403
     for (int i = tid; i < a.n_act; i += CP_THREADS)
-        xa[a.n_obs + i] = (a.cp_act[in_row * a.n_act + i] - a.act_mean[i]) / (a.act_std[i] + 1e-10f);  // :404
+        xa[a.n_obs + i] = (in_act(i) - a.act_mean[i]) / (a.act_std[i] + 1e-10f);  // :404
     __syncthreads();
     float* xin = xa;
     float* xout = xb;
@@ -98,6 +100,42 @@ __global__ __launch_bounds__(CP_THREADS) void context_kernel(const CpArgs a) {
     }
     const int C = a.dims[a.nlayers];
     for (int i = tid; i < C; i += CP_THREADS) a.out[((size_t)e * a.m + mi) * C + i] = xin[i];
+}
+
+__global__ __launch_bounds__(CP_THREADS) void context_kernel(const CpArgs a) {
+    const int e = blockIdx.x / a.m, mi = blockIdx.x % a.m;
+    const size_t in_row = a.bs ? ((size_t)e * a.m + mi) : (size_t)mi;   // tile(.., [E,1,1]) unless already [E,m,.]
+    context_row(a, e, mi, [&](int i) { return a.cp_obs[in_row * a.n_obs + i]; }, [&](int i) { return a.cp_act[in_row * a.n_act + i]; });
+}
+
+// Head of a staged planner call (cadm_cem_plan_staged), one launch instead of three (ingest, context encoder, candidates of CEM
+// iteration 0: 4.8 us of sampling and two dependent-launch boundaries of a 0.85 ms get_action): the call's inputs arrive as kernel
+// arguments; workgroups [0, E m) run the encoder on the histories IN the argument block, workgroup E m unpacks the block into the
+// device block (what the later launches of the call read), the rest draw the candidates of iteration 0 from the block's mean / var.
+struct PlanHeadArgs {
+    int off_cp_obs, off_cp_act, off_mean, off_var, nfloats;
+    float* dev_block;
+    int ctx_blocks;                    // E * m (0: no context model)
+    int n, H, A; float lb, ub; uint32_t seed, call;
+    float* actions;
+};
+__global__ __launch_bounds__(CP_THREADS) void plan_head_kernel(const IngestBlock blk, const CpArgs a, const PlanHeadArgs x) {
+    const int b = blockIdx.x;
+    if (b < x.ctx_blocks) {
+        const int e = b / a.m, mi = b % a.m;
+        context_row(a, e, mi, [&](int i) { return blk.v[x.off_cp_obs + mi * a.n_obs + i]; }, [&](int i) { return blk.v[x.off_cp_act + mi * a.n_act + i]; });
+    } else if (b == x.ctx_blocks) {
+        for (int i = threadIdx.x; i < x.nfloats; i += CP_THREADS) x.dev_block[i] = blk.v[i];
+    } else {
+        const int HA = x.H * x.A;
+        const size_t total = (size_t)a.m * x.n * HA;
+        const size_t stride = (size_t)(gridDim.x - x.ctx_blocks - 1) * CP_THREADS;
+        for (size_t L = (size_t)(b - x.ctx_blocks - 1) * CP_THREADS + threadIdx.x; L < total; L += stride) {
+            const int ta = (int)(L % HA);
+            const int mi = (int)(L / ((size_t)x.n * HA));
+            x.actions[L] = sample_action(blk.v[x.off_mean + mi * HA + ta], blk.v[x.off_var + mi * HA + ta], nullptr, L, x.seed, x.call, 0, x.lb, x.ub);
+        }
+    }
 }
 
 
@@ -333,9 +371,7 @@ static int launch_context_batched(cadm_ctx* ctx, const CpArgs& a, int m, hipStre
     return CADM_OK;      // layers too wide for an LDS-resident tile: the per-row kernel takes the call
 }
 
-int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs, float* out,
-                        hipStream_t s) {
-    CpArgs a{};
+static int context_args(cadm_ctx* ctx, CpArgs& a) {
     const int nl = ctx->cfg.n_cp_hidden + 1;
     a.nlayers = nl;
     a.dims[0] = (ctx->D + ctx->A) * ctx->cfg.history_length;
@@ -352,12 +388,51 @@ int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act,
             return CADM_EINVAL;
         }
     }
-    a.cp_obs = cp_obs; a.cp_act = cp_act;
     a.obs_mean = ctx->st.cp_obs_mean; a.obs_std = ctx->st.cp_obs_std;
     a.act_mean = ctx->st.cp_act_mean; a.act_std = ctx->st.cp_act_std;
     a.n_obs = ctx->D * ctx->cfg.history_length;
     a.n_act = ctx->A * ctx->cfg.history_length;
-    a.m = m; a.bs = bs; a.E = ctx->E; a.out = out;
+    a.E = ctx->E;
+    return CADM_OK;
+}
+
+int cadm_launch_plan_head(cadm_ctx* ctx, const float* host_block, int nfloats, const int32_t off[5], float* dev_block, int m, int n,
+                          uint32_t seed, uint32_t call, float* ctx_out, float* actions_out, hipStream_t s) {
+    CADM_REQUIRE(nfloats > 0 && nfloats <= CADM_INGEST_MAX && off[3] >= 0 && off[4] >= 0, "plan head: bad ingest block");
+    static_assert(sizeof(IngestBlock) + sizeof(CpArgs) + sizeof(PlanHeadArgs) <= 4096, "kernel argument block");
+    CpArgs a{};
+    PlanHeadArgs x{};
+    if (ctx->C > 0) {
+        CADM_REQUIRE(off[1] >= 0 && off[2] >= 0, "plan head: cp_obs / cp_act required for a context model");
+        const int rc = context_args(ctx, a);
+        if (rc) return rc;
+        a.out = ctx_out;
+        x.ctx_blocks = ctx->E * m;
+    }
+    a.m = m; a.bs = 0;
+    x.off_cp_obs = off[1]; x.off_cp_act = off[2]; x.off_mean = off[3]; x.off_var = off[4]; x.nfloats = nfloats;
+    x.dev_block = dev_block;
+    x.n = n; x.H = ctx->H; x.A = ctx->A; x.lb = ctx->cfg.lower_bound; x.ub = ctx->cfg.upper_bound; x.seed = seed; x.call = call;
+    x.actions = actions_out;
+    const size_t total = (size_t)m * n * ctx->H * ctx->A;
+    size_t sb = (total + CP_THREADS - 1) / CP_THREADS;
+    if (sb > 2048) sb = 2048;
+    IngestBlock blk;
+    memcpy(blk.v, host_block, (size_t)nfloats * sizeof(float));
+    hipLaunchKernelGGL(plan_head_kernel, dim3(x.ctx_blocks + 1 + (unsigned)sb), dim3(CP_THREADS), 0, s, blk, a, x);
+    CADM_CHECK_HIP(hipGetLastError());
+    return CADM_OK;
+}
+
+int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs, float* out,
+                        hipStream_t s) {
+    CpArgs a{};
+    {
+        const int rc = context_args(ctx, a);
+        if (rc) return rc;
+    }
+    a.cp_obs = cp_obs; a.cp_act = cp_act;
+    a.m = m; a.bs = bs; a.out = out;
     if (m >= CADM_CONTEXT_BATCHED_MIN_ROWS) {       // many histories per member: the GEMM-shaped path (weights reused across rows)
         bool launched = false;
         const int rc = launch_context_batched(ctx, a, m, s, &launched);

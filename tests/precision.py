@@ -45,10 +45,12 @@ def oracle_rollout(prob, dt, actions, eps, p, det, obs_rows=None, it=0, **kw):
                                     prob["E"], p, det, obs_rows=None if obs_rows is None else obs_rows.astype(dt), return_traj=True, **kw)
 
 
-def measure(engines, cfgname="cfg2", seed=77, H=30, n_traj=24, hidden=200, n=None):
+def measure(engines, cfgname="cfg2", seed=77, H=30, n_traj=24, hidden=200, n=None, mutate=None, obs_scale=None):
     """engines: dict name -> HipEngine factory(prob, p, H, det).  Returns {kernel name: {...}, "fp32_oracle": {...}}:
       one_step_*   every row of the FULL configuration advanced one teacher-forced step from its own random state
-      traj_*       `n_traj` candidates x all particles over the whole horizon (next observation after every step)"""
+      traj_*       `n_traj` candidates x all particles over the whole horizon (next observation after every step)
+    mutate(prob): applied to both synthetic problems (statistics / weights of the widened-envelope cases); obs_scale [D]: the
+    observations (one-step rows and the trajectory's start) are multiplied by it (raw, un-normalised magnitudes)."""
     cfg = synth.CONFIGS[cfgname]
     E, p, n, det = cfg["E"], cfg["p"], n or cfg["n"], cfg["deterministic"]
     hs = (hidden,) * 4
@@ -56,12 +58,20 @@ def measure(engines, cfgname="cfg2", seed=77, H=30, n_traj=24, hidden=200, n=Non
     out = {}
     # ---- one step, full size
     prob1 = synth.make_problem(env=cfg["env"], context=cfg["context"], E=E, m=1, H=1, trained_like=True, seed=seed, hidden_sizes=hs)
+    if mutate is not None:
+        mutate(prob1)
     D, A = prob1["D"], prob1["A"]
     obs_rows = rng.standard_normal((1, n, p, D))
+    if obs_scale is not None:
+        obs_rows = obs_rows * np.asarray(obs_scale)
+        prob1["obs"] = prob1["obs"] * np.asarray(obs_scale)
     act1 = rng.uniform(-1, 1, (1, n, 1, A))
     eps1 = None if det else rng.standard_normal((1, 1, n, p, D))
     r64, t64 = oracle_rollout(prob1, np.float64, act1, eps1, p, det, obs_rows=obs_rows)
     r32, t32 = oracle_rollout(prob1, np.float32, act1, eps1, p, det, obs_rows=obs_rows)
+    # (the step itself: next obs - obs is what the network computed; with raw-scale observations the sum is dominated by the exact addend)
+    additive = cfg["env"] in ("slim_humanoid", "cartpole", "pendulum") and t64.size == obs_rows.size      # obs_postproc = obs + delta on every dim
+    d64 = t64 - obs_rows.reshape(t64.shape) if additive else None
     out["fp32_oracle"] = {"one_step_obs": err_stats(t32, t64), "one_step_reward": err_stats(r32, r64)}
     got1 = {}
     for name, make in engines.items():
@@ -71,9 +81,15 @@ def measure(engines, cfgname="cfg2", seed=77, H=30, n_traj=24, hidden=200, n=Non
         got1[name] = (rows.cpu().numpy(), traj.cpu().numpy())
         out[name] = {"one_step_obs": err_stats(got1[name][1], t64), "one_step_reward": err_stats(got1[name][0], r64),
                      "one_step_obs_vs_fp32_oracle": err_stats(got1[name][1], t32)}
+        if additive:      # envs whose postproc is obs + delta on every dim compare the increment too
+            out[name]["one_step_delta"] = err_stats(got1[name][1].astype(np.float64) - obs_rows.reshape(t64.shape), d64)
         eng.close()
     # ---- whole horizon, a slice of candidates
     probH = synth.make_problem(env=cfg["env"], context=cfg["context"], E=E, m=1, H=H, trained_like=True, seed=seed + 1, hidden_sizes=hs)
+    if mutate is not None:
+        mutate(probH)
+    if obs_scale is not None:
+        probH["obs"] = probH["obs"] * np.asarray(obs_scale)
     actH = rng.uniform(-1, 1, (1, n_traj, H, A))
     epsH = None if det else rng.standard_normal((H, 1, n_traj, p, D))
     R64, T64 = oracle_rollout(probH, np.float64, actH, epsH, p, det)
@@ -115,8 +131,8 @@ def markdown(res):
              "|d|/|ref| over elements with |ref| >= 0.25 rms (no floor).", "",
              "| quantity | metric | xdl | f32mfma | fp32 oracle |", "|---|---|---|---|---|"]
     names = [k for k in ("xdl", "f32mfma") if k in res]
-    for q, label in (("one_step_obs", "one-step next obs"), ("one_step_reward", "one-step reward"), ("traj_obs", "30-step trajectory"),
-                     ("traj_last_obs", "obs after step 30"), ("returns", "30-step returns")):
+    for q, label in (("one_step_obs", "one-step next obs"), ("one_step_reward", "one-step reward"), ("traj_obs", "%d-step trajectory" % m["H"]),
+                     ("traj_last_obs", "obs after step %d" % m["H"]), ("returns", "%d-step returns" % m["H"])):
         for met, ml in (("max_rel", "max/max"), ("pure_rel_big", "pure rel")):
             cells = ["%.2e" % res[k][q][met] if k in res else "-" for k in ("xdl", "f32mfma", "fp32_oracle")]
             lines.append("| %s | %s | %s |" % (label, ml, " | ".join(cells)))
