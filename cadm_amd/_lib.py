@@ -68,6 +68,7 @@ SIGNATURES = {
     "cadm_set_norm_stats": (_i, [_P, C.POINTER(_P), _P]),
     "cadm_context_forward": (_i, [_P, _P, _P, _i, _i, _P, _P]),
     "cadm_sample_actions": (_i, [_P, _P, _P, _P, _u32, _u32, _i, _i, _i, _P, _P]),
+    "cadm_sample_actions_shard": (_i, [_P, _P, _P, _P, _u32, _u32, _i, _i, _i, _i, _i, _P, _P]),
     "cadm_sample_uniform": (_i, [_P, _u32, _u32, _i, _i, _P, _P, _P]),
     "cadm_rollout_returns": (_i, [_P, _P, _P, _P, _P, _P, _i, _u32, _u32, _i, _i, _i, _i, _i, _P, _P, _P]),
     "cadm_rollout_builtin": (_i, [_P]),
@@ -75,6 +76,7 @@ SIGNATURES = {
     "cadm_rollout_check": (_i, [_P, _i, _i, _i]),
     "cadm_particle_mean": (_i, [_P, _P, _i, _i, _P, _P]),
     "cadm_cem_refit": (_i, [_P, _P, _i, _i, _P, _i, _P, _P, _P, _P]),
+    "cadm_cem_refit_regen": (_i, [_P, _P, _i, _i, _i, _P, _P, _u32, _u32, _i, _P, _P]),
     "cadm_rs_select": (_i, [_P, _P, _i, _i, _P, _i, _P, _P, _P]),
     "cadm_plan_workspace_bytes": (C.c_size_t, [_P, _i, _i]),
     "cadm_cem_plan": (_i, [_P, _P, _P, _P, _P, _P, _i, _i, _u32, _u32, _P, _P, _P]),
@@ -103,6 +105,8 @@ DEV_SIGNATURES = {
     "cadm_dev_set_timing_buffer": (_i, [_P, _P]),
     "cadm_dev_read_adam_moment": (_i, [_P, _i, _i, _i, _i, _P, C.c_long, _P]),
     "cadm_dev_rollout_plan": (_i, [_i, _i, _i, C.POINTER(_i)]),
+    "cadm_dev_refit_sharded": (_i, [_P, _P, _i, _i, _i, _i, _P, _P, _u32, _u32, _i, _P, _P]),
+    "cadm_dev_input_checksum": (_i, [_P, _P, _P, _P, _P, _P, _i, _P, _P]),
 }
 DEV_ROLLOUT_XDL, DEV_ROLLOUT_F32 = 0, 1
 

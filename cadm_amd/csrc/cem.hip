@@ -6,15 +6,19 @@
 // action sampling
 // ---------------------------------------------------------------------------------------------
 // (sample_action: common.h -- also used by the fused head of the staged planner call, context.hip)
+// candidates [c0, c0 + nc) of every env, at their GLOBAL positions in out [m, n, H, A] (a rank of a sharded planner draws only its own
+// shard: the draws are keyed by the global element index, so what it writes is what every other rank would have written there)
 __global__ void sample_actions_kernel(const float* __restrict__ mean, const float* __restrict__ var,
                                       const float* __restrict__ z, uint32_t seed, uint32_t call, int it,
                                       int m, int n, int H, int A, float lb, float ub,
-                                      float* __restrict__ out) {
-    const size_t total = (size_t)m * n * H * A;
+                                      float* __restrict__ out, int c0, int nc) {
     const int HA = H * A;
-    for (size_t L = blockIdx.x * (size_t)blockDim.x + threadIdx.x; L < total; L += (size_t)gridDim.x * blockDim.x) {
-        const int ta = (int)(L % HA);
-        const int mi = (int)(L / ((size_t)n * HA));
+    const size_t per = (size_t)nc * HA, total = (size_t)m * per;
+    for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < total; q += (size_t)gridDim.x * blockDim.x) {
+        const int mi = (int)(q / per);
+        const size_t r = q - (size_t)mi * per;
+        const size_t L = ((size_t)mi * n + c0) * HA + r;
+        const int ta = (int)(r % HA);
         out[L] = sample_action(mean[(size_t)mi * HA + ta], var[(size_t)mi * HA + ta], z, L, seed, call, it, lb, ub);
     }
 }
@@ -44,8 +48,10 @@ __global__ void sample_uniform_kernel(uint32_t seed, uint32_t call, int m, int n
 // ---------------------------------------------------------------------------------------------
 // particle mean (:474)
 // ---------------------------------------------------------------------------------------------
-__global__ void particle_mean_kernel(const float* __restrict__ rows, int total, int p, float* __restrict__ out) {
+// tail: (sharded planner) one more word behind the means -- the checksum of this rank's inputs, which travels in the all-gather payload
+__global__ void particle_mean_kernel(const float* __restrict__ rows, int total, int p, float* __restrict__ out, const unsigned* tail) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tail && i == 0) out[total] = __uint_as_float(*tail);
     if (i >= total) return;
     float s = 0.0f;
     for (int j = 0; j < p; ++j) s += rows[(size_t)i * p + j];
@@ -56,14 +62,16 @@ __global__ void particle_mean_kernel(const float* __restrict__ rows, int total, 
 // elite refit: bitonic sort of (return desc, index asc) keys in LDS, then statistics
 // ---------------------------------------------------------------------------------------------
 // (make_key: common.h)
-__device__ __forceinline__ float cand_at(const float* cand, int G, int n_local, int m, int mi, int ni) {
-    return cand[((size_t)(ni / n_local) * m + mi) * n_local + (ni % n_local)];
+// gathered candidate returns: rank g's [m, n_local] block at g * gstride (gstride = m * n_local, + 1 with the trailing input checksum)
+__device__ __forceinline__ float cand_at(const float* cand, int G, int n_local, int m, int mi, int ni, int gstride = 0) {
+    const size_t gs = gstride > 0 ? (size_t)gstride : (size_t)m * n_local;
+    return cand[(size_t)(ni / n_local) * gs + (size_t)mi * n_local + (ni % n_local)];
 }
 
 // candidate return: from the gathered per-candidate means, or (single-rank fused path) the particle mean
 // (core/utils.py:474) taken on the fly from the row returns [m, n, p]
-__device__ __forceinline__ float cand_value(const float* cand, const float* rows, int p, int G, int n_local, int m, int mi, int ni) {
-    if (!rows) return cand_at(cand, G, n_local, m, mi, ni);
+__device__ __forceinline__ float cand_value(const float* cand, const float* rows, int p, int G, int n_local, int m, int mi, int ni, int gstride = 0) {
+    if (!rows) return cand_at(cand, G, n_local, m, mi, ni, gstride);
     const float* r = rows + ((size_t)mi * n_local + ni) * p;
     float s = 0.0f;
     for (int j = 0; j < p; ++j) s += r[j];
@@ -91,18 +99,30 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
                                  int m, int H, int A, int K, float alpha, int npow2, const float* mean_in,
                                  const float* var_in, float* mean_out, float* var_out, int32_t* __restrict__ elites_out,
                                  float* __restrict__ plan_out, float lo, float hi, int do_clip, int part_off,
-                                 unsigned* done_flag, unsigned done_val) {
+                                 unsigned* done_flag, unsigned done_val, RefitRegen rg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);
     const int mi = blockIdx.x;
     const int n = G * n_local;
+    // sharded planner: every rank's payload ends with the checksum of the inputs it was fed (RefitRegen); one that differs from this
+    // rank's poisons the plan with NaN on EVERY rank (each sees all checksums) -- the host raises on it (HipEngine.cem_plan_host)
+    __shared__ int poison_s;
+    if (threadIdx.x == 0) {
+        int bad = 0;
+        if (rg.gstride > 0 && rg.my_rank >= 0) {
+            const unsigned mine = __float_as_uint(cand[(size_t)rg.my_rank * rg.gstride + (size_t)m * n_local]);
+            for (int g = 0; g < G; ++g) bad |= __float_as_uint(cand[(size_t)g * rg.gstride + (size_t)m * n_local]) != mine;
+        }
+        poison_s = bad;
+    }
+    if (rg.gstride <= 0) rg.gstride = m * n_local;
     constexpr int SMALL_N = 256, LISTMAX = 1024;
     bool done = false;
     if (n <= SMALL_N) {
         // small n: every candidate's rank by counting (keys are unique: index in the low word); the K best
         // land sorted in keys[0..K) with one barrier instead of the O(log^2 n) barriers of a sort
         uint64_t* raw = keys + npow2;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) raw[i] = make_key(cand_value(cand, rows, p, G, n_local, m, mi, i), (uint32_t)i);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) raw[i] = make_key(cand_value(cand, rows, p, G, n_local, m, mi, i, rg.gstride), (uint32_t)i);
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const uint64_t ki = raw[i];
@@ -121,7 +141,7 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
         uint64_t* raw = keys + 2 * LISTMAX;                    // [n]
         unsigned* hist = reinterpret_cast<unsigned*>(raw + n); // [256] + {prefix, krem, count}
         unsigned* ctl = hist + 256;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) raw[i] = make_key(cand_value(cand, rows, p, G, n_local, m, mi, i), (uint32_t)i);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) raw[i] = make_key(cand_value(cand, rows, p, G, n_local, m, mi, i, rg.gstride), (uint32_t)i);
         if (threadIdx.x == 0) { ctl[0] = 0u; ctl[1] = (unsigned)K; ctl[2] = 0u; }
         for (int pass = 3; pass >= 0; --pass) {
             for (int b = threadIdx.x; b < 256; b += blockDim.x) hist[b] = 0u;
@@ -181,7 +201,7 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
     }
     if (!done) {
         for (int i = threadIdx.x; i < npow2; i += blockDim.x)
-            keys[i] = i < n ? make_key(cand_value(cand, rows, p, G, n_local, m, mi, i), (uint32_t)i) : ~0ull;
+            keys[i] = i < n ? make_key(cand_value(cand, rows, p, G, n_local, m, mi, i, rg.gstride), (uint32_t)i) : ~0ull;
         __syncthreads();
         bitonic_sort_lds(keys, npow2);                                             // tf.nn.top_k, :475
     }
@@ -191,6 +211,14 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
     // (fixed order -> deterministic); the elites' actions stay in registers between the mean and the variance pass
     const int HA = H * A;
     const float* act_m = actions + (size_t)mi * n * HA;
+    // an elite's action element: read from the candidates' buffer, or (sharded planner: this rank drew only its own shard) drawn again
+    // from the counter-based RNG by its global element index -- the same number, without any exchange of action sequences
+    auto elite_at = [&](uint64_t key, int ta) -> float {
+        const size_t c = (size_t)(key & 0xFFFFFFFFu);
+        if (!rg.on) return act_m[c * HA + ta];
+        const size_t L = ((size_t)mi * n + c) * HA + ta;
+        return sample_action(mean_in[(size_t)mi * HA + ta], var_in[(size_t)mi * HA + ta], nullptr, L, rg.seed, rg.call, rg.it, rg.lb, rg.ub);
+    };
     float* part = reinterpret_cast<float*>(smem_raw + part_off);                  // [KG][HA]
     constexpr int MAXE = 16;                                                       // elites per thread (K <= KG * MAXE)
     const int KG = min((int)blockDim.x / HA, K) > 0 ? min((int)blockDim.x / HA, K) : 1;
@@ -204,7 +232,7 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
 #pragma unroll
         for (int i = 0; i < MAXE; ++i) {
             const int k = kg + i * KG;
-            v[i] = (on && k < K) ? act_m[(size_t)(keys[k < K ? k : 0] & 0xFFFFFFFFu) * HA + ta] : 0.0f;
+            v[i] = (on && k < K) ? elite_at(keys[k < K ? k : 0], ta) : 0.0f;
         }
 #pragma unroll
         for (int i = 0; i < MAXE; ++i) s += v[i];
@@ -227,27 +255,29 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
             for (int g = 0; g < KG; ++g) nv += part[g * HA + ta];
             nv = nv / (float)K;                                                    // :483
             const size_t o = (size_t)mi * HA + ta;
-            const float mo = mean_in[o] * alpha + (1.0f - alpha) * nm;             // :485
+            float mo = mean_in[o] * alpha + (1.0f - alpha) * nm;                   // :485
+            if (poison_s) mo = __uint_as_float(0x7fc00000u);                       // (ranks fed different inputs: NaN everywhere)
             mean_out[o] = mo;
             var_out[o] = var_in[o] * alpha + (1.0f - alpha) * nv;                  // :486
-            if (plan_out) plan_out[o] = do_clip ? fminf(fmaxf(mo, lo), hi) : mo;   // dynamics.py:365-366 (last iteration)
+            if (plan_out) plan_out[o] = (do_clip && !poison_s) ? fminf(fmaxf(mo, lo), hi) : mo;   // dynamics.py:365-366 (last iteration)
         }
     } else {
         for (int ta = threadIdx.x; ta < HA; ta += blockDim.x) {
             float s = 0.0f;
-            for (int k = 0; k < K; ++k) s += act_m[(size_t)(keys[k] & 0xFFFFFFFFu) * HA + ta];
+            for (int k = 0; k < K; ++k) s += elite_at(keys[k], ta);
             const float nm = s / (float)K;
             float v = 0.0f;
             for (int k = 0; k < K; ++k) {
-                const float d = act_m[(size_t)(keys[k] & 0xFFFFFFFFu) * HA + ta] - nm;
+                const float d = elite_at(keys[k], ta) - nm;
                 v += d * d;
             }
             const float nv = v / (float)K;
             const size_t o = (size_t)mi * HA + ta;
-            const float mo = mean_in[o] * alpha + (1.0f - alpha) * nm;
+            float mo = mean_in[o] * alpha + (1.0f - alpha) * nm;
+            if (poison_s) mo = __uint_as_float(0x7fc00000u);
             mean_out[o] = mo;
             var_out[o] = var_in[o] * alpha + (1.0f - alpha) * nv;
-            if (plan_out) plan_out[o] = do_clip ? fminf(fmaxf(mo, lo), hi) : mo;
+            if (plan_out) plan_out[o] = (do_clip && !poison_s) ? fminf(fmaxf(mo, lo), hi) : mo;
         }
     }
     // completion flag of the staged planner call (cadm_cem_plan_staged): the host polls it in pinned memory instead of
@@ -440,16 +470,22 @@ static int grid_for(size_t total) {
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
+extern "C" int cadm_sample_actions_shard(cadm_ctx* ctx, const float* mean, const float* var, const float* z,
+                                         uint32_t seed, uint32_t call, int it, int m, int n_global, int cand_offset, int n_local,
+                                         float* actions_out, void* stream) {
+    CADM_REQUIRE(ctx && mean && var && actions_out && m > 0 && n_global > 0 && cand_offset >= 0 && n_local > 0 &&
+                 cand_offset + n_local <= n_global, "cadm_sample_actions: bad arguments");
+    CADM_ON_DEVICE(ctx);
+    const size_t total = (size_t)m * n_local * ctx->H * ctx->A;
+    hipLaunchKernelGGL(sample_actions_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, mean, var, z,
+                       seed, call, it, m, n_global, ctx->H, ctx->A, ctx->cfg.lower_bound, ctx->cfg.upper_bound, actions_out, cand_offset, n_local);
+    CADM_CHECK_HIP(hipGetLastError());
+    return CADM_OK;
+}
 extern "C" int cadm_sample_actions(cadm_ctx* ctx, const float* mean, const float* var, const float* z,
                                    uint32_t seed, uint32_t call, int it, int m, int n_global,
                                    float* actions_out, void* stream) {
-    CADM_REQUIRE(ctx && mean && var && actions_out && m > 0 && n_global > 0, "cadm_sample_actions: bad arguments");
-    CADM_ON_DEVICE(ctx);
-    const size_t total = (size_t)m * n_global * ctx->H * ctx->A;
-    hipLaunchKernelGGL(sample_actions_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, mean, var, z,
-                       seed, call, it, m, n_global, ctx->H, ctx->A, ctx->cfg.lower_bound, ctx->cfg.upper_bound, actions_out);
-    CADM_CHECK_HIP(hipGetLastError());
-    return CADM_OK;
+    return cadm_sample_actions_shard(ctx, mean, var, z, seed, call, it, m, n_global, 0, n_global, actions_out, stream);
 }
 
 extern "C" int cadm_sample_uniform(cadm_ctx* ctx, uint32_t seed, uint32_t call, int m, int n_global,
@@ -463,20 +499,57 @@ extern "C" int cadm_sample_uniform(cadm_ctx* ctx, uint32_t seed, uint32_t call, 
     return CADM_OK;
 }
 
+// Checksum of the replicated per-call inputs of a sharded planner call: position-weighted sum of the raw 32-bit patterns, modulo 2^32
+// (exact, order-independent accumulation; NaN-safe; a permutation or a single changed bit changes it).  One workgroup.
+__global__ void input_checksum_kernel(const float* a0, int n0, const float* a1, int n1, const float* a2, int n2, const float* a3, int n3,
+                                      const float* a4, int n4, unsigned* out) {
+    __shared__ unsigned red[256];
+    const float* ptr[5] = {a0, a1, a2, a3, a4};
+    const int cnt[5] = {n0, n1, n2, n3, n4};
+    unsigned h = 0u, base = 1u;
+    for (int q = 0; q < 5; ++q) {
+        if (ptr[q])
+            for (int i = threadIdx.x; i < cnt[q]; i += blockDim.x) h += __float_as_uint(ptr[q][i]) * (2u * (base + (unsigned)i) + 1u);
+        base += (unsigned)cnt[q] + 7u;
+    }
+    red[threadIdx.x] = h;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) *out = red[0] | 1u;      // (never the bit pattern of 0.0f)
+}
+int cadm_launch_input_checksum(cadm_ctx* ctx, const float* obs, const float* cp_obs, const float* cp_act, const float* mean, const float* var,
+                               int m, unsigned* out, hipStream_t s) {
+    const int HA = ctx->H * ctx->A, Hh = ctx->cfg.history_length;
+    hipLaunchKernelGGL(input_checksum_kernel, dim3(1), dim3(256), 0, s, obs, m * ctx->D, cp_obs, cp_obs ? m * ctx->D * Hh : 0, cp_act,
+                       cp_act ? m * ctx->A * Hh : 0, mean, m * HA, var, m * HA, out);
+    CADM_CHECK_HIP(hipGetLastError());
+    return CADM_OK;
+}
+
 extern "C" int cadm_particle_mean(cadm_ctx* ctx, const float* returns_rows, int m, int n_local,
                                   float* cand_returns, void* stream) {
     CADM_REQUIRE(ctx && returns_rows && cand_returns && m > 0 && n_local > 0, "cadm_particle_mean: bad arguments");
     CADM_ON_DEVICE(ctx);
     const int total = m * n_local;
     hipLaunchKernelGGL(particle_mean_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, returns_rows,
-                       total, ctx->p, cand_returns);
+                       total, ctx->p, cand_returns, (const unsigned*)nullptr);
+    CADM_CHECK_HIP(hipGetLastError());
+    return CADM_OK;
+}
+int cadm_launch_particle_mean_tail(cadm_ctx* ctx, const float* returns_rows, int m, int n_local, float* cand_returns, const unsigned* tail,
+                                   hipStream_t stream) {
+    const int total = m * n_local;
+    hipLaunchKernelGGL(particle_mean_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, returns_rows, total, ctx->p, cand_returns, tail);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
 }
 
 int cadm_launch_refit(cadm_ctx* ctx, const float* cand_returns, const float* rows, int G, int n_local, const float* actions,
                       int m, const float* mean_in, const float* var_in, float* mean_out, float* var_out, int32_t* elites_out,
-                      float* plan_out, hipStream_t stream) {
+                      float* plan_out, hipStream_t stream, const RefitRegen* regen) {
+    RefitRegen rg{};
+    if (regen) rg = *regen;
+    rg.lb = ctx->cfg.lower_bound; rg.ub = ctx->cfg.upper_bound;
     const int n = G * n_local;
     CADM_REQUIRE(n >= ctx->cfg.num_elites, "cadm_cem_refit: n_candidates %d < num_elites %d (tf.nn.top_k would fail)",
                  n, ctx->cfg.num_elites);
@@ -502,7 +575,7 @@ int cadm_launch_refit(cadm_ctx* ctx, const float* cand_returns, const float* row
     hipLaunchKernelGGL(cem_refit_kernel, dim3(m), dim3(1024), lds, stream, cand_returns, rows, ctx->p, G, n_local, actions,
                        m, ctx->H, ctx->A, ctx->cfg.num_elites, ctx->cfg.alpha, npow2, mean_in, var_in, mean_out, var_out,
                        elites_out, plan_out, ctx->cfg.lower_bound, ctx->cfg.upper_bound, ctx->cfg.discrete ? 0 : 1, (int)lds_keys,
-                       plan_out ? ctx->plan_done : nullptr, ctx->plan_done_val);
+                       plan_out ? ctx->plan_done : nullptr, ctx->plan_done_val, rg);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
 }
@@ -513,7 +586,17 @@ extern "C" int cadm_cem_refit(cadm_ctx* ctx, const float* cand_returns, int G, i
                  "cadm_cem_refit: bad arguments");
     CADM_ON_DEVICE(ctx);
     return cadm_launch_refit(ctx, cand_returns, nullptr, G, n_local, actions, m, mean_io, var_io, mean_io, var_io, elites_out,
-                             nullptr, (hipStream_t)stream);
+                             nullptr, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int cadm_cem_refit_regen(cadm_ctx* ctx, const float* cand_returns, int G, int n_local, int m, float* mean_io, float* var_io,
+                                    uint32_t seed, uint32_t call, int it, int32_t* elites_out, void* stream) {
+    CADM_REQUIRE(ctx && cand_returns && mean_io && var_io && G > 0 && n_local > 0 && m > 0, "cadm_cem_refit_regen: bad arguments");
+    CADM_ON_DEVICE(ctx);
+    RefitRegen rg{};
+    rg.on = 1; rg.seed = seed; rg.call = call; rg.it = it; rg.my_rank = -1;
+    return cadm_launch_refit(ctx, cand_returns, nullptr, G, n_local, nullptr, m, mean_io, var_io, mean_io, var_io, elites_out,
+                             nullptr, (hipStream_t)stream, &rg);
 }
 
 extern "C" int cadm_rs_select(cadm_ctx* ctx, const float* cand_returns, int G, int n_local, const float* actions,

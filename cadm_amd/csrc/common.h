@@ -175,6 +175,18 @@ int cadm_launch_rollout(cadm_ctx* ctx, const float* obs, const float* obs_rows, 
                         const float* actions, const float* eps, int norm_actions, uint32_t seed,
                         uint32_t call, int it, int cand_offset, int n_global, int m, int n_local,
                         float* returns_rows, float* traj_out, hipStream_t s, int dry_run = 0, int force_deterministic = -1);
+// Sharded planner (capi.hip: cem_plan_impl): what the refit needs to REGENERATE the elites' action sequences by global
+// candidate id instead of reading them (a rank draws only its own shard), and to check the input checksums at the end of every rank's
+// all-gather payload.
+struct RefitRegen {
+    int on;                    // 1: elite actions are drawn again from (seed, call, it); the actions pointer may be null
+    uint32_t seed, call; int it;
+    float lb, ub;
+    int gstride;               // floats per rank in the gathered buffer (0: m * n_local); m * n_local + 1 with the trailing checksum
+    int my_rank;               // >= 0: compare every rank's checksum with this rank's; mismatch -> NaN plan
+};
+int cadm_launch_input_checksum(cadm_ctx* ctx, const float* obs, const float* cp_obs, const float* cp_act, const float* mean, const float* var,
+                               int m, unsigned* out, hipStream_t s);
 int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs,
                         float* out, hipStream_t s);
 // Per-call inputs of a small planner call travel as KERNEL ARGUMENTS (cadm_cem_plan_staged, capi.hip): up to CADM_INGEST_MAX floats.

@@ -21,6 +21,15 @@ int cadm_dev_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf);
 /* The launcher's plan for a member of `units` CU shares of row tiles (csrc/xdl_geo.h: xdl_plan_units): count_out[4] = launches
  * (rounds) of {cooperative one tile, cooperative two tiles, wave-tile 4, wave-tile 8}.  Host logic only: no ctx, no device. */
 int cadm_dev_rollout_plan(int units, int two_tile_ok, int wave_tile_ok, int* count_out);
+/* The sharded planner's refit on a FABRICATED all-gather result (one GPU plays every rank): payload [G][m * n_local + 1] floats -- every
+ * rank's candidate means followed by the checksum word of the inputs it was fed (cadm_dev_input_checksum) --, this rank = my_rank; the
+ * elites are regenerated from (seed, call, it) as in a sharded cadm_cem_plan; plan_out [m,H,A] optional.  A checksum that differs from
+ * my_rank's makes mean / var / plan NaN. */
+int cadm_dev_refit_sharded(cadm_ctx* ctx, const float* payload, int G, int n_local, int m, int my_rank, float* mean_io, float* var_io,
+                           uint32_t seed, uint32_t call, int it, float* plan_out, void* stream);
+/* the checksum word (as stored in a payload) of a call's replicated inputs; cp_obs / cp_act may be NULL */
+int cadm_dev_input_checksum(cadm_ctx* ctx, const float* obs, const float* cp_obs, const float* cp_act, const float* mean, const float* var,
+                            int m, float* word_out, void* stream);
 int cadm_dev_read_adam_moment(cadm_ctx* ctx, int net, int layer, int is_bias, int second, float* dst, long n_floats, void* stream);
 #ifdef __cplusplus
 }

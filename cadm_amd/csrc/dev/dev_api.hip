@@ -87,3 +87,23 @@ extern "C" int cadm_dev_read_adam_moment(cadm_ctx* ctx, int net, int layer, int 
     CADM_CHECK_HIP(hipMemcpyAsync(dst, second ? v : m, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return CADM_OK;
 }
+
+int cadm_launch_refit(cadm_ctx* ctx, const float* cand_returns, const float* rows, int G, int n_local, const float* actions,
+                      int m, const float* mean_in, const float* var_in, float* mean_out, float* var_out, int32_t* elites_out,
+                      float* plan_out, hipStream_t stream, const RefitRegen* regen);
+
+extern "C" int cadm_dev_refit_sharded(cadm_ctx* ctx, const float* payload, int G, int n_local, int m, int my_rank, float* mean_io, float* var_io,
+                                      uint32_t seed, uint32_t call, int it, float* plan_out, void* stream) {
+    CADM_REQUIRE(ctx && payload && mean_io && var_io && G > 0 && n_local > 0 && m > 0 && my_rank >= 0 && my_rank < G, "cadm_dev_refit_sharded: bad arguments");
+    CADM_ON_DEVICE(ctx);
+    RefitRegen rg{};
+    rg.on = 1; rg.seed = seed; rg.call = call; rg.it = it; rg.gstride = m * n_local + 1; rg.my_rank = my_rank;
+    return cadm_launch_refit(ctx, payload, nullptr, G, n_local, nullptr, m, mean_io, var_io, mean_io, var_io, nullptr, plan_out, (hipStream_t)stream, &rg);
+}
+
+extern "C" int cadm_dev_input_checksum(cadm_ctx* ctx, const float* obs, const float* cp_obs, const float* cp_act, const float* mean,
+                                       const float* var, int m, float* word_out, void* stream) {
+    CADM_REQUIRE(ctx && obs && mean && var && word_out && m > 0, "cadm_dev_input_checksum: bad arguments");
+    CADM_ON_DEVICE(ctx);
+    return cadm_launch_input_checksum(ctx, obs, cp_obs, cp_act, mean, var, m, reinterpret_cast<unsigned*>(word_out), (hipStream_t)stream);
+}

@@ -108,6 +108,7 @@ __global__ void pack_xdl_bias_kernel(const XdlPackArgs a) {
             const int d = 8 * tile + 2 * grp + (r & 1);
             if (d < g.D) v = a.b[g.NH + (r >> 1)][(size_t)e * g.D + d];
         }
+        if (!(fabsf(v) <= 3.0e38f)) { *a.overflow = 1; v = 0.0f; }      // biases are fp32 accumulator inits: any FINITE value is representable
         a.bias[idx] = v;
     }
 }
@@ -141,7 +142,8 @@ int cadm_pack_xdl(cadm_ctx* ctx, hipStream_t s) {
     CADM_CHECK_HIP(hipMemcpyAsync(&flag, ctx->xflag, sizeof(int), hipMemcpyDeviceToHost, s));
     CADM_CHECK_HIP(hipStreamSynchronize(s));
     if (flag) {
-        cadm_set_error("cadm_repack: a dynamics weight is non-finite or exceeds the split-f16 range (|w| > 65000)");
+        cadm_set_error("cadm_repack: a dynamics weight is non-finite or exceeds the split-f16 range (|w| > 65000 as packed: swish nets carry log2(e) "
+                       "in layer 0, i.e. |w| > 45052 there), or a bias is non-finite");
         return CADM_EINVAL;
     }
     return CADM_OK;

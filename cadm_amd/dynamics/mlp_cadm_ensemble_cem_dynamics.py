@@ -297,8 +297,11 @@ class MLPEnsembleCEMDynamicsModel(object):
                    cem_init_var.shape)
             if sig == self._checked_sig:
                 shard, fused = self._sharding()
-                counted = shard.world > 1
-                if fused and not (counted and self._replication_check_due()):
+                due = False
+                if shard.world > 1:      # the call is counted HERE, whatever path it then takes (the torch.distributed
+                    due = self._replication_check_due()      # fallback used to re-ask with peek=True without ever having counted)
+                    counted = True
+                if fused and not due:
                     self._call += 1
                     return self.engine.cem_plan_host((obs, cp_obs, cp_act, cem_init_mean, cem_init_var), self.n_candidates, seed=self.seed,
                                                      call=self._call & 0xFFFFFFFF, shapes=sig)
@@ -334,6 +337,9 @@ class MLPEnsembleCEMDynamicsModel(object):
                 eng.cem_plan(obs, cp_obs, cp_act, cem_init_mean, cem_init_var, self.n_candidates, seed=self.seed, call=call, out=host)
                 torch.cuda.current_stream(eng.device).synchronize()
                 action = host.numpy().copy()
+                if shard.world > 1 and np.isnan(action).any():      # (the in-library refit checks every rank's input checksum on every call)
+                    raise RuntimeError("candidate-sharded planning: the plan is NaN -- the ranks of the group were fed different obs / "
+                                       "history / warm start on this call (or an input is non-finite)")
                 return action if self.discrete else np.minimum(np.maximum(action, -1.0), 1.0)
             else:
                 action = _planner.cem_plan(self.engine, obs, cp_obs, cp_act, cem_init_mean, cem_init_var,

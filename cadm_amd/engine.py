@@ -314,13 +314,16 @@ class HipEngine:
               "cadm_context_forward")
         return out
 
-    def sample_actions(self, mean, var, n_global, z=None, seed=0, call=0, it=0):
+    def sample_actions(self, mean, var, n_global, z=None, seed=0, call=0, it=0, cand_offset=0, n_local=None):
+        """Candidates [cand_offset, cand_offset + n_local) of the [m, n_global, H, A] buffer (default: all of them).  A rank of a sharded
+        planner draws only its own shard -- the draws are keyed by the global element index -- and leaves the rest of the buffer alone."""
         mean, var = self._t(mean), self._t(var)
         m = mean.shape[0]
         z = None if z is None else self._t(z)
+        n_local = n_global - cand_offset if n_local is None else n_local
         out = torch.empty((m, n_global, self.H, self.A), dtype=torch.float32, device=self.device)
-        self._check(self.lib.cadm_sample_actions(self._ctx, ptr(mean), ptr(var), ptr(z), seed, call, it, m, n_global,
-                                           ptr(out), self.stream), "cadm_sample_actions")
+        self._check(self.lib.cadm_sample_actions_shard(self._ctx, ptr(mean), ptr(var), ptr(z), seed, call, it, m, n_global, cand_offset,
+                                                       n_local, ptr(out), self.stream), "cadm_sample_actions")
         return out
 
     def sample_uniform(self, m, n_global, seed=0, call=0):
@@ -353,11 +356,18 @@ class HipEngine:
         self._check(self.lib.cadm_particle_mean(self._ctx, ptr(rows), m, n_local, ptr(out), self.stream), "cadm_particle_mean")
         return out
 
-    def cem_refit(self, cand, actions, mean, var, G=1, want_elites=False):
-        """cand [G,m,n_local] (or [m,n] when G == 1); mean/var updated IN PLACE."""
+    def cem_refit(self, cand, actions, mean, var, G=1, want_elites=False, regen=None):
+        """cand [G,m,n_local] (or [m,n] when G == 1); mean/var updated IN PLACE.  regen = (seed, call, it): the elites' action
+        sequences are drawn again from the device RNG by global candidate id instead of being read from `actions` (a rank of a
+        sharded planner holds only its own shard's draws); bit-identical to the gathered form."""
         m = actions.shape[0]
         n_local = actions.shape[1] // G
         el = torch.empty((m, self.num_elites), dtype=torch.int32, device=self.device) if want_elites else None
+        if regen is not None:
+            seed, call, it = regen
+            self._check(self.lib.cadm_cem_refit_regen(self._ctx, ptr(cand), G, n_local, m, ptr(mean), ptr(var), seed, call, it, ptr(el),
+                                                      self.stream), "cadm_cem_refit_regen")
+            return el
         self._check(self.lib.cadm_cem_refit(self._ctx, ptr(cand), G, n_local, ptr(actions), m, ptr(mean), ptr(var), ptr(el),
                                       self.stream), "cadm_cem_refit")
         return el
@@ -434,7 +444,12 @@ class HipEngine:
                                            st["ws"], st["op"], 1, self.stream)
         if rc:
             self._check(rc, "cadm_cem_plan_staged")
-        return st["out_np"].copy()
+        out = st["out_np"].copy()
+        if self.dist_world > 1 and np.isnan(out).any():
+            # the sharded refit compares the checksums every rank's all-gather payload carries (csrc/cem.hip: RefitRegen)
+            raise RuntimeError("candidate-sharded planning: the plan is NaN -- the ranks of the group were fed different obs / history / warm "
+                               "start on this call (or an input is non-finite); every rank of the group raises on the same call")
+        return out
 
     def rs_plan(self, obs, cp_obs, cp_act, n, seed=0, call=0):
         obs = self._t(obs)

@@ -6,9 +6,10 @@ This module is the per-iteration form used
     torch.distributed group (backend "nccl" == RCCL over xGMI; "gloo" in CPU tests), each rank
     rolls out its own shard and ONE all-gather of the per-candidate returns per CEM iteration
     ([m, n/G] floats per rank) gives every rank the full [m, n] vector; every rank then runs the
-    identical top-k + refit.  Action sequences are never communicated: every rank samples all n
-    candidates from the counter-based RNG (keyed by global candidate id), so elites can be
-    gathered locally;
+    identical top-k + refit.  Action sequences are never communicated and never sampled twice:
+    a rank draws only ITS candidates from the counter-based RNG (keyed by global candidate id) and
+    the refit draws the <= num_elites elite sequences again by id -- the work beside
+    the rollout does not grow with the number of ranks;
   * for parity tests with injected ``z`` / ``eps`` (the reference's TF RNG streams are unseeded,
     SURVEY.md section 0).
 Reference: /root/reference/cadm/dynamics/core/utils.py:398-488 (CEM), :490-561 (RS).
@@ -83,12 +84,17 @@ def cem_plan(engine, obs, cp_obs, cp_act, init_mean, init_var, n, seed=0, call=0
     var = engine._t(init_var).clone()
     ctx_vec = engine.context_forward(cp_obs, cp_act) if engine.C > 0 else None
     info = []
+    local = shard.world > 1 and z is None and not return_info       # (injected draws / diagnostics: the fully sampled form)
     for it in range(engine.num_cem_iters):
-        actions = engine.sample_actions(mean, var, n, z=None if z is None else z[it], seed=seed, call=call, it=it)
+        if local:
+            actions = engine.sample_actions(mean, var, n, seed=seed, call=call, it=it, cand_offset=shard.offset, n_local=shard.n_local)
+        else:
+            actions = engine.sample_actions(mean, var, n, z=None if z is None else z[it], seed=seed, call=call, it=it)
         rows = engine.rollout_returns(obs, ctx_vec, actions, eps=None if eps is None else eps[it], seed=seed,
                                       call=call, it=it, cand_offset=shard.offset, n_local=shard.n_local)
         cand = gather_cand_returns(engine.particle_mean(rows), shard)
-        elites = engine.cem_refit(cand, actions, mean, var, G=shard.world, want_elites=return_info)
+        elites = engine.cem_refit(cand, actions, mean, var, G=shard.world, want_elites=return_info,
+                                  regen=(seed, call, it) if local else None)
         if return_info:
             info.append(dict(actions=actions, rows=rows, cand=cand, elites=elites, mean=mean.clone(), var=var.clone()))
     plan = mean if engine.discrete else mean.clamp(-1.0, 1.0)   # dynamics.py:365-366

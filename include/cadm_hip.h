@@ -109,7 +109,11 @@ int cadm_set_weights(cadm_ctx* ctx, int net, int layer, float* W, float* b);
 int cadm_set_logvar_bounds(cadm_ctx* ctx, int net, float* max_logvar, float* min_logvar);
 /* The caller has written master weights in place (load(), a manual assign; ANY net): re-pack the planner's weight streams
  * now and mark the training chains' packed operand copies stale (rebuilt at the next cadm_train_step / cadm_predict;
- * training steps themselves keep them current).  Writing registered weights without this call leaves both on old values. */
+ * training steps themselves keep them current).  Writing registered weights without this call leaves both on old values.
+ * Fails with CADM_EINVAL if a dynamics weight cannot be split for the f16 matrix pipe: non-finite, or |w| > 65000 AS PACKED -- swish
+ * nets carry log2(e) in layer 0 (limit 45052 in the model's units) and 1 / log2(e) in the heads (93780); biases: any finite value.
+ * The planner's other range limits (inputs clamped at +-65000, hidden pre-activations at 60000 = 41589 for swish nets in the model's
+ * units) are listed in INTEGRATION.md, "Numeric envelope of the planner". */
 int cadm_repack(cadm_ctx* ctx, void* stream);
 
 /* The 12 normalisation vectors fed per call in the reference (dynamics.py:344-347,604-645), order:
@@ -131,6 +135,12 @@ int cadm_context_forward(cadm_ctx* ctx, const float* cp_obs, const float* cp_act
 int cadm_sample_actions(cadm_ctx* ctx, const float* mean, const float* var, const float* z,
                         uint32_t seed, uint32_t call, int it, int m, int n_global,
                         float* actions_out, void* stream);
+/* The same for candidates [cand_offset, cand_offset + n_local) only, written at their GLOBAL positions of actions_out
+ * [m,n_global,H,A]: the draws are keyed by the global element index, so a rank of a candidate-sharded planner that draws only its own
+ * shard writes exactly what any other rank would have written there (the other positions are left untouched). */
+int cadm_sample_actions_shard(cadm_ctx* ctx, const float* mean, const float* var, const float* z,
+                              uint32_t seed, uint32_t call, int it, int m, int n_global, int cand_offset, int n_local,
+                              float* actions_out, void* stream);
 /* Random-shooting draws (core/utils.py:498-503): U[-1,1) actions (continuous) or one-hot rows of
  * uniform integer actions (discrete; raw ints also written to raw_out [m,n,H] if non-NULL). */
 int cadm_sample_uniform(cadm_ctx* ctx, uint32_t seed, uint32_t call, int m, int n_global,
@@ -181,6 +191,13 @@ int cadm_particle_mean(cadm_ctx* ctx, const float* returns_rows, int m, int n_lo
  *   elites_out    [m,num_elites] optional int32 out (global candidate ids), else NULL */
 int cadm_cem_refit(cadm_ctx* ctx, const float* cand_returns, int G, int n_local, const float* actions,
                    int m, float* mean_io, float* var_io, int32_t* elites_out, void* stream);
+
+/* cadm_cem_refit without the candidates' action sequences: the <= num_elites elites' sequences are DRAWN AGAIN from the device RNG by
+ * global candidate id -- (seed, call, it) and mean_io / var_io (before the update) are the distribution iteration `it` was sampled
+ * from -- so a rank that sampled only its own shard (cadm_sample_actions_shard) refits over the global set without any exchange of
+ * actions.  Bit-identical to cadm_cem_refit on the fully sampled buffer. */
+int cadm_cem_refit_regen(cadm_ctx* ctx, const float* cand_returns, int G, int n_local, int m, float* mean_io, float* var_io,
+                         uint32_t seed, uint32_t call, int it, int32_t* elites_out, void* stream);
 
 /* Random-shooting selection (core/utils.py:554-561): argmax over candidates (first maximum),
  * out[m,A] = actions[mi, best, 0, :].  best_out [m] optional. */

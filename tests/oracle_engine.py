@@ -28,10 +28,16 @@ class OracleEngine:
     def context_forward(self, cp_obs, cp_act):
         return self._t(onets.context_forward(self.o["cp"], self._n(cp_obs), self._n(cp_act), self.o["st"]))
 
-    def sample_actions(self, mean, var, n_global, z=None, seed=0, call=0, it=0):
+    def sample_actions(self, mean, var, n_global, z=None, seed=0, call=0, it=0, cand_offset=0, n_local=None):
         m = mean.shape[0]
         zz = self._n(z) if z is not None else ophilox.truncated_normals(seed, call, it, m, n_global, self.H, self.A)
-        return self._t(oplanner.sample_actions(self._n(mean), self._n(var), zz))
+        a = oplanner.sample_actions(self._n(mean), self._n(var), zz)
+        if n_local is not None and (cand_offset, n_local) != (0, n_global):
+            # a rank of a sharded planner draws only its own shard: everything else in the buffer is poison (nothing may read it)
+            keep = a[:, cand_offset:cand_offset + n_local].copy()
+            a = np.full_like(a, np.nan)
+            a[:, cand_offset:cand_offset + n_local] = keep
+        return self._t(a)
 
     def sample_uniform(self, m, n_global, seed=0, call=0):
         return self._t(ophilox.rs_uniforms(seed, call, m, n_global, self.H, self.A)), None
@@ -58,7 +64,12 @@ class OracleEngine:
         c = self._n(cand)                       # [G, m, n_local] -> [m, G * n_local]
         return np.concatenate([c[g] for g in range(G)], axis=1)
 
-    def cem_refit(self, cand, actions, mean, var, G=1, want_elites=False):
+    def cem_refit(self, cand, actions, mean, var, G=1, want_elites=False, regen=None):
+        if regen is not None:      # the elites' sequences drawn again by global candidate id from the distribution this iteration was sampled from
+            seed, call, it = regen
+            m, n_global = actions.shape[:2]
+            zz = ophilox.truncated_normals(seed, call, it, m, n_global, self.H, self.A)
+            actions = self._t(oplanner.sample_actions(self._n(mean), self._n(var), zz))
         nm, nv, idx = oplanner.elite_refit(self._n(mean), self._n(var), self._n(actions), self._ungather(cand, G), self.num_elites)
         mean.copy_(self._t(nm))
         var.copy_(self._t(nv))

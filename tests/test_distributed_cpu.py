@@ -131,3 +131,29 @@ def test_replication_check_schedule():
     assert due == [True, True, False, False, True, False, False, False, False, True, False, False]
     off = types.SimpleNamespace(_check_replicated_left=0, _check_replicated_every=0, _sharded_calls=0)
     assert not any(M._replication_check_due(off) for _ in range(600))
+
+
+def test_replication_guard_fires_on_the_unfused_sharded_path(monkeypatch):
+    """with the torch.distributed fallback (no in-library communicator: `fused` False) the fast-signature branch of
+    get_action used to mark the call as counted without counting it, so `_sharded_calls` stayed at 1 and the periodic check never
+    fired -- in exactly the degraded mode where ranks are most likely to drift apart.  get_action on a stand-in object (the class
+    itself needs a GPU): the check must run on calls 1, 2 (check_replicated_calls) and then on every 4th."""
+    import types
+    import torch
+    from cadm_amd.dynamics import mlp_cadm_ensemble_cem_dynamics as mod
+    M = mod.MLPEnsembleCEMDynamicsModel
+    checked, planned = [], []
+    monkeypatch.setattr(mod._planner, "check_replicated", lambda tensors, shard: checked.append(len(planned) + 1))
+    monkeypatch.setattr(mod._planner, "cem_plan", lambda eng, *a, **k: (planned.append(1), torch.zeros(1, 3, 2))[1])
+    eng = types.SimpleNamespace(stage=lambda xs: tuple(None if x is None else torch.as_tensor(x) for x in xs), _t=lambda x: x)
+    me = types.SimpleNamespace(_stats_dirty=False, _checked_sig=None, _call=0, _check_replicated_left=2, _check_replicated_every=4,
+                               _sharded_calls=0, engine=eng, n_candidates=8, seed=0, discrete=False, n_forwards=3, action_space_dims=2,
+                               _sharding=lambda: (types.SimpleNamespace(world=2), False))
+    me._next_call = lambda: M._next_call(me)
+    me._replication_check_due = lambda peek=False: M._replication_check_due(me, peek=peek)
+    me._check_planner_inputs = lambda *a: None
+    obs, mean, var = np.zeros((1, 4), np.float32), np.zeros((1, 3, 2), np.float32), np.ones((1, 3, 2), np.float32)
+    for _ in range(12):
+        M.get_action(me, obs, None, None, mean, var)
+    assert len(planned) == 12 and me._sharded_calls == 12
+    assert checked == [1, 2, 4, 8, 12], checked

@@ -47,6 +47,24 @@ def test_batched_context_matches_oracle_and_the_per_row_kernel(gpu, m):
     eng.close()
 
 
+def test_context_across_the_kernel_dispatch_threshold(gpu):
+    """cadm_context_forward switches kernels at 48 histories per member (per-row fmaf chain below, fp32-MFMA GEMM chain from
+    there on; csrc/context.hip: CADM_CONTEXT_BATCHED_MIN_ROWS).  The two sum in different orders, so the context vector of the SAME
+    history is not bitwise the same in a 47-row and a 48-row call -- documented (numeric envelope) and pinned here: the
+    first 47 rows of both calls agree to 2e-6 of the tensor's scale, each call is bitwise reproducible, and within one kernel a row's
+    result does not depend on how many other rows the call carries (40 vs 47 rows: bit-equal)."""
+    prob = synth.make_problem(env="halfcheetah", trained_like=True, seed=11)
+    eng = make_engine(prob, p=5)
+    cp_obs, cp_act = _histories(prob, 48, 4711)
+    a47 = eng.context_forward(cp_obs[:47], cp_act[:47]).cpu().numpy()
+    a48 = eng.context_forward(cp_obs, cp_act).cpu().numpy()
+    assert_close(a48[:, :47], a47, 2e-6, "context of the same 47 histories: batched (m = 48) vs per-row (m = 47) kernel")
+    np.testing.assert_array_equal(eng.context_forward(cp_obs[:47], cp_act[:47]).cpu().numpy(), a47)
+    np.testing.assert_array_equal(eng.context_forward(cp_obs, cp_act).cpu().numpy(), a48)
+    np.testing.assert_array_equal(eng.context_forward(cp_obs[:40], cp_act[:40]).cpu().numpy(), a47[:, :40])
+    eng.close()
+
+
 @pytest.mark.parametrize("env,E,Hh,cp_sizes,C,m", [
     ("pendulum", 5, 1, (8, 6), 3, 100),                # input width 4, layers narrower than one 64-unit group, odd widths
     ("halfcheetah", 3, 3, (320, 100, 30), 10, 77),     # a layer wider than 256; widths not multiples of 4 / 64 (scalar weight loads)

@@ -129,6 +129,74 @@ def test_cfg5_eight_candidate_shards_on_one_gpu(gpu):
     np.testing.assert_array_equal(_np(v1), _np(v2))
     nm, nv, idx = oplanner.elite_refit(_np(mean), _np(var), _np(actions), _np(cand_full))
     np.testing.assert_array_equal(_np(el1), idx)
+    # SURVEY 8e / VERDICT r4 #7: a rank samples ONLY its own shard (the draws are keyed by the global element index: what rank r writes
+    # at its positions is what the full sampler writes there) and the refit draws the elites' sequences again by global candidate id
+    # instead of reading them -- bit-identical statistics without any rank ever holding another rank's candidates
+    for r in (0, 3, 7):
+        shard = eng.sample_actions(mean, var, n, seed=5, call=2, it=0, cand_offset=r * nl, n_local=nl)
+        np.testing.assert_array_equal(_np(shard)[:, r * nl:(r + 1) * nl], _np(actions)[:, r * nl:(r + 1) * nl])
+    m3, v3 = mean.clone(), var.clone()
+    hollow = torch.full_like(actions, float("nan"))                                       # (the refit must not read it)
+    el3 = eng.cem_refit(gathered, hollow, m3, v3, G=G, want_elites=True, regen=(5, 2, 0))
+    np.testing.assert_array_equal(_np(el3), _np(el1))
+    np.testing.assert_array_equal(_np(m3), _np(m1))
+    np.testing.assert_array_equal(_np(v3), _np(v1))
+    # a later iteration (another stream id, a non-trivial distribution): still bit-identical
+    act1 = eng.sample_actions(m1, v1, n, seed=5, call=2, it=1)
+    cand1 = torch.randn((1, n), device=eng.device)
+    m4, v4, m5, v5 = m1.clone(), v1.clone(), m1.clone(), v1.clone()
+    eng.cem_refit(cand1, act1, m4, v4, G=1)
+    eng.cem_refit(cand1.view(G, 1, nl).contiguous(), hollow, m5, v5, G=G, regen=(5, 2, 1))
+    np.testing.assert_array_equal(_np(m5), _np(m4))
+    np.testing.assert_array_equal(_np(v5), _np(v4))
+
+
+def test_sharded_refit_checks_every_ranks_input_checksum(gpu):
+    """a sharded cadm_cem_plan carries the checksum of the inputs each rank was fed as one extra word of its
+    all-gather payload, and the refit of EVERY iteration compares all of them: ranks that drifted apart get a NaN plan on the very
+    call (the host raises on it), not up to 255 calls later.  One GPU plays the ranks: the developer library's hooks run the sharded
+    refit on a fabricated all-gather result (csrc/dev/dev_api.h)."""
+    from cadm_amd import _lib
+    from cadm_amd._lib import ptr
+    prob = synth.make_problem(env="halfcheetah", context=True, E=5, m=2, H=6, trained_like=True, seed=91)
+    eng = make_engine(prob, p=10, H=6, lib=_lib.load_dev())
+    G, nl, m = 4, 16, 2
+    n = G * nl
+    mean, var = eng._t(prob["init_mean"]), eng._t(prob["init_var"])
+    obs, cpo, cpa = eng._t(prob["obs"]), eng._t(prob["cp_obs"]), eng._t(prob["cp_act"])
+    word = torch.zeros(1, device=eng.device)
+    chk = lambda o: (eng._check(eng.lib.cadm_dev_input_checksum(eng._ctx, ptr(o), ptr(cpo), ptr(cpa), ptr(mean), ptr(var), m, ptr(word), eng.stream)),
+                     word.clone())[1]
+    w_same = chk(obs)
+    assert torch.equal(chk(obs.clone()), w_same)                                      # a function of the values only
+    o2 = obs.clone(); o2[1, 3] = torch.nextafter(o2[1, 3], o2[1, 3] + 1)               # one bit of one observation
+    w_bit = chk(o2)
+    o3 = obs.clone(); o3[0, 2], o3[0, 5] = obs[0, 5], obs[0, 2]                       # a permutation (a plain sum would not see it)
+    w_perm = chk(o3)
+    assert w_bit.view(torch.int32).item() != w_same.view(torch.int32).item() and w_perm.view(torch.int32).item() != w_same.view(torch.int32).item()
+    cand = torch.randn((G, m * nl), device=eng.device)
+
+    def refit(words, rank):
+        payload = torch.cat([cand, torch.stack(words).view(G, 1)], dim=1).contiguous()     # [G, m * nl + 1]
+        mm, vv = mean.clone(), var.clone()
+        plan = torch.zeros_like(mean)
+        eng._check(eng.lib.cadm_dev_refit_sharded(eng._ctx, ptr(payload), G, nl, m, rank, ptr(mm), ptr(vv), 7, 3, 0, ptr(plan), eng.stream))
+        return _np(mm), _np(vv), _np(plan)
+
+    good = refit([w_same] * G, 0)
+    assert all(np.isfinite(x).all() for x in good)
+    # the same refit through the product API on the contiguous [G, m, nl] layout (no checksum word): bit-identical
+    m0, v0 = mean.clone(), var.clone()
+    eng.cem_refit(cand.view(G, m, nl).contiguous(), torch.empty((m, n, 6, 6), device=eng.device), m0, v0, G=G, regen=(7, 3, 0))
+    np.testing.assert_array_equal(good[0], _np(m0))
+    np.testing.assert_array_equal(good[1], _np(v0))
+    for rank in range(G):                     # every rank sees the same verdict, whichever rank was fed something else
+        for bad_word in (w_bit, w_perm):
+            words = [w_same] * G
+            words[2] = bad_word
+            mm, vv, plan = refit(words, rank)
+            assert np.isnan(mm).all() and np.isnan(plan).all(), "rank %d did not notice rank 2's different inputs" % rank
+    eng.close()
 
 
 def test_production_shape_m10(gpu):

@@ -23,4 +23,15 @@ for n in (200, 400, 800, 1600, 2000, 4000, 8000):
     for _ in range(200):
         eng.sample_actions(mean, var, n, seed=1, call=1, it=0)
     torch.cuda.synchronize(); ts = (time.perf_counter() - t0) / 200
-    print("n=%5d  refit %.1f us   sample %.1f us" % (n, tr * 1e6, ts * 1e6))
+    G = 8
+    cg = cand.view(G, 1, n // G).contiguous()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        eng.cem_refit(cg, acts, mean, var, G=G, regen=(1, 1, 0))
+    torch.cuda.synchronize(); trg = (time.perf_counter() - t0) / 200
+    t0 = time.perf_counter()
+    for _ in range(200):
+        eng.sample_actions(mean, var, n, seed=1, call=1, it=0, cand_offset=n // G, n_local=n // G)
+    torch.cuda.synchronize(); tsl = (time.perf_counter() - t0) / 200
+    print("n=%5d  refit %.1f us   sample all %.1f us  |  8-way shard: refit with regenerated elites %.1f us   sample own shard %.1f us"
+          % (n, tr * 1e6, ts * 1e6, trg * 1e6, tsl * 1e6))

@@ -11,9 +11,11 @@ import torch
 from cadm_amd import _lib, synth
 
 cfg = dict(synth.CONFIGS["cfg2"])
-prob = synth.make_problem(env=cfg["env"], context=cfg["context"], E=cfg["E"], m=1, H=cfg["H"], seed=0)
 maxu = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-libp = os.path.join(ROOT, "cadm_amd", sys.argv[2]) if len(sys.argv) > 2 else None      # (a variant build, tools/build_variant.sh)
+libp = os.path.join(ROOT, "cadm_amd", sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "-" else None      # (a variant build, tools/build_variant.sh)
+ENV = sys.argv[3] if len(sys.argv) > 3 else cfg["env"]      # python tools/flavour_table.py 6 - slim_humanoid
+HID = int(sys.argv[4]) if len(sys.argv) > 4 else 200
+prob = synth.make_problem(env=ENV, context=cfg["context"], E=cfg["E"], m=1, H=cfg["H"], seed=0, hidden_sizes=(HID,) * 4)
 print("units  tiles/member   plan     coop-1   coop-2   wave-8   wave-4   (us per rollout)")
 for u in range(1, maxu + 1):
     n = 204 * u                      # n / 4 tiles per member
