@@ -56,7 +56,7 @@ typedef float floatx2 __attribute__((ext_vector_type(2)));
 template <int ENV_, int C_, int HID_, int MT_, int NH_, int ACT_>
 struct XC {
     static constexpr int ENV = ENV_, C = C_, HID = HID_, MT = MT_, NHC = NH_, ACT = ACT_;
-    static_assert(NH_ >= 2 && NH_ <= CADM_MAX_HIDDEN_LAYERS, "number of hidden layers");
+    static_assert(NH_ >= 1 && NH_ <= CADM_MAX_HIDDEN_LAYERS, "number of hidden layers");
     static constexpr int D = env_D(ENV), A = env_A(ENV), P = env_P(ENV);
     static constexpr int K0 = P + A + C;
     static constexpr int NC0 = (K0 + 31) / 32;            // chunks of layer 0
@@ -970,6 +970,9 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                 TS(2)
                 XDL_LAYER_SYNC();
                 TS(3)
+                if constexpr (ONED && XNH == 1) {      // one hidden layer: no hidden-layer-1 sweep to carry the next step's action features (see actt)
+                    if (actt && t + 1 < H) act_put(t + 1);
+                }
                 // hidden layers 1 .. NH-1: the first three are unrolled (distinct resident registers), the rest loop
                 auto hidden = [&](int l, auto res_c, auto base_c, auto lq_c) {
                     constexpr int NRES = decltype(res_c)::value, RBASE = decltype(base_c)::value;

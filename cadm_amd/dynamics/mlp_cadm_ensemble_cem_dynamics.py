@@ -111,8 +111,8 @@ class MLPEnsembleCEMDynamicsModel(object):
                  name,
                  env,
                  hidden_sizes=(200, 200, 200, 200),
-                 hidden_nonlinearity="swish",
-                 output_nonlinearity=None,
+                 hidden_nonlinearity="swish",       # (the reference's default, tf.nn.relu, is not a key of its own `_activations` table:
+                 output_nonlinearity=None,          #  dynamics.py:30 vs :104 raises KeyError on a defaulted call; every script passes 'swish')
                  batch_size=128,
                  learning_rate=0.001,
                  normalize_input=True,
@@ -151,10 +151,13 @@ class MLPEnsembleCEMDynamicsModel(object):
         if hidden_nonlinearity not in _ACTIVATIONS or output_nonlinearity not in _ACTIVATIONS:
             raise KeyError("unknown nonlinearity %r / %r" % (hidden_nonlinearity, output_nonlinearity))
         if hidden_nonlinearity == "softmax" or output_nonlinearity is not None:
+            # reference: `_activations` (dynamics.py:17-24) offers both; `output_nonlinearity` would be applied to BOTH heads and to the
+            # context encoder's output (core/utils.py:327,333,609), 'softmax' row-wise over a hidden layer's units.  No script of the
+            # reference passes either (run_cadm_pets.py:221, run_pets.py: 'swish' / None).
             raise NotImplementedError(
-                "the HIP kernels implement hidden_nonlinearity in (swish, relu, tanh, sigmoid, None) and "
-                "output_nonlinearity=None (run_cadm_pets.py / run_pets.py pass swish / None); got %r / %r"
-                % (hidden_nonlinearity, output_nonlinearity))
+                "the HIP kernels implement hidden_nonlinearity in (swish, relu, tanh, sigmoid, None) and output_nonlinearity=None "
+                "(reference: _activations, cadm/dynamics/mlp_cadm_ensemble_cem_dynamics.py:17-24; its scripts pass 'swish' / None: "
+                "run_cadm_pets.py:221); got hidden_nonlinearity=%r, output_nonlinearity=%r" % (hidden_nonlinearity, output_nonlinearity))
         # context_hidden_nonlinearity is accepted and ignored exactly like the reference
         # (always ReLU: dynamics.py:49 vs :141-156, layers.py:34).
         if optimizer is not None and getattr(optimizer, "__name__", "") not in ("AdamOptimizer",):

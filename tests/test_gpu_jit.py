@@ -26,6 +26,8 @@ GEOS = [  # hidden_sizes, context_out_dim, hidden_nonlinearity
     ((200,) * 3, 10, "swish"),       # depth other than 4
     ((144,) * 2, 7, "relu"),         # 9 tiles, odd context width, two layers
     ((320,) * 5, 10, "swish"),       # wider than 256 (4 split products, bias tiles from global memory), five layers
+    ((200,), 10, "swish"),           # ONE hidden layer (the reference accepts any hidden_sizes tuple, dynamics.py:28): layer 0 feeds the heads
+    ((144,), 7, "relu"),             # ... 9 tiles, odd context width
 ]
 
 
@@ -169,7 +171,7 @@ def test_unequal_hidden_widths_run_zero_padded(gpu, hidden, act, tmp_path):
         make_engine(prob, p=p, H=3, hidden_nonlinearity="sigmoid")
 
 
-@pytest.mark.parametrize("hidden,C,act", GEOS[:5])
+@pytest.mark.parametrize("hidden,C,act", GEOS[:5] + GEOS[7:8])
 def test_training_step_with_other_nonlinearities(gpu, hidden, C, act):
     E, B = 3, 48
     prob = synth.make_problem(env="halfcheetah", context=True, E=E, hidden_sizes=hidden, C=C, trained_like=True, with_back=True, seed=61)

@@ -80,3 +80,35 @@ def test_deterministic_model_both_flavours(gpu):
         np.testing.assert_array_equal(r2, r1, err_msg="flavour " + flavour)
         np.testing.assert_array_equal(t2, t1, err_msg="flavour " + flavour)
     eng.close()
+
+
+def test_one_hidden_layer_all_flavours_agree(gpu):
+    """One hidden layer (round 5: the reference accepts any hidden_sizes tuple, dynamics.py:28): layer 0 feeds the heads directly -- no
+    hidden-to-hidden sweep, no resident hidden fragments, and the side jobs that ride in the hidden-layer-1 sweep (the next step's action
+    features) need another home.  A JIT-built geometry over SEVERAL steps: all four flavours bit-identical, and the trajectory within the
+    multi-step band of the fp32 oracle."""
+    from helpers import assert_close, oracle_problem
+    from oracle import nets as onets
+    from oracle import planner as oplanner
+    H, m, n, p = 5, 1, 37, 20
+    prob = synth.make_problem(env="halfcheetah", context=True, E=5, m=m, H=H, hidden_sizes=(200,), trained_like=True, seed=23)
+    eng = make_engine(prob, p=p, lib=_lib.load_dev())
+    rng = np.random.default_rng(8)
+    acts_np = rng.uniform(-1, 1, (m, n, H, prob["A"])).astype(np.float32)
+    acts = eng._t(acts_np)
+    ctx = eng.context_forward(prob["cp_obs"], prob["cp_act"])
+    eps = torch.randn((H, m, n, p, prob["D"]), device=eng.device)
+    for kw, e in (({}, eps), ({"seed": 5, "call": 3, "it": 1}, None)):
+        r1, t1 = _run(eng, prob, ctx, acts, e, "1", **kw)
+        assert np.isfinite(r1).all()
+        for flavour in ("2", "3", "4"):
+            r2, t2 = _run(eng, prob, ctx, acts, e, flavour, **kw)
+            np.testing.assert_array_equal(r2, r1, err_msg="flavour " + flavour)
+            np.testing.assert_array_equal(t2, t1, err_msg="flavour " + flavour)
+        if e is not None:
+            o = oracle_problem(prob, np.float32)
+            T = oplanner.context_table_indexed(onets.context_forward(o["cp"], o["cp_obs"], o["cp_act"], o["st"]), 0)
+            r_ref, t_ref = oplanner.rollout_indexed(o["env"], o["ff"], o["st"], o["obs"], T, acts_np, e.cpu().numpy(), 5, p, False, return_traj=True)
+            assert_close(t1, t_ref, 5e-5, "5-step trajectory of a one-hidden-layer net vs the fp32 oracle")
+            assert_close(r1, r_ref, 5e-5, "returns")
+    eng.close()
