@@ -131,6 +131,8 @@ struct cadm_ctx {
     int n_cus = 256;
     std::unordered_set<const void*> attr_done;   // kernels whose dynamic-LDS attribute is set on THIS ctx's device
     size_t chain_attr_lds = 0;      // training chain kernel: the dynamic-LDS size its attribute was last raised to on this ctx's device
+    size_t chain_attr_lds4 = 0;     // (its 4-wave throughput flavour)
+    int train_force_nw = 0;         // developer library only: 4 / 8 = force that flavour of the chain kernel (0: by work items)
     NormStats st;
     TrainState* train = nullptr;
     // scratch for the context encoder

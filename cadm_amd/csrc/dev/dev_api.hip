@@ -107,3 +107,9 @@ extern "C" int cadm_dev_input_checksum(cadm_ctx* ctx, const float* obs, const fl
     CADM_ON_DEVICE(ctx);
     return cadm_launch_input_checksum(ctx, obs, cp_obs, cp_act, mean, var, m, reinterpret_cast<unsigned*>(word_out), (hipStream_t)stream);
 }
+
+extern "C" int cadm_dev_set_train_flavour(cadm_ctx* ctx, int waves) {
+    CADM_REQUIRE(ctx && (waves == 0 || waves == 4 || waves == 8), "cadm_dev_set_train_flavour: waves must be 0, 4 or 8");
+    ctx->train_force_nw = waves;
+    return CADM_OK;
+}

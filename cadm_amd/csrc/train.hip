@@ -179,8 +179,15 @@ typedef __attribute__((address_space(1))) float* gptr;
 __device__ __forceinline__ gcptr as_global(const float* p) { return (gcptr)p; }
 __device__ __forceinline__ gptr as_global(float* p) { return (gptr)p; }
 #define CH_ROWS 16
-#define CH_THREADS 512        // 8 waves: two per SIMD, so one wave's LDS / load / scalar work overlaps the other's MFMAs
-#define CH_WAVES 8
+// Two flavours of the chain kernel (template parameter NW = waves per workgroup), chosen per launch by the number of work items:
+//   NW = 8  ONE workgroup per CU, two waves per SIMD: one wave's LDS / load / scalar work overlaps the other's MFMAs.  The latency
+//           flavour: a step at the reference's batch size (256 rows x 5 members x 2 nets = 160 work items) is one partial round of the chip.
+//   NW = 4  THREE workgroups per CU (168 registers per wave, 53.6 KB of LDS each): three independent 16-row chains per CU, so one
+//           chain's epilogue / barrier / stage start (36 % of a stage, chain_timing) runs beside the others' MFMAs.  The throughput
+//           flavour, for launches of more work items than CUs: B = 4096 1.633 -> 1.200 ms per step (0.177 -> 0.241 of the fp32
+//           matrix peak), B = 1024 0.410 -> 0.340; at B = 256 it would be 0.144 instead of 0.120 ms (profiles/r5_train_scaling.md).
+#define CH_WAVES_MAX 8
+#define CH_THREADS_MAX (64 * CH_WAVES_MAX)
 #define CH_RING 8             // operand blocks (16 k x 2 tiles) of a wave's ring; CH_RING - 1 are in flight
 #define CH_MAXSTAGE 20
 #define CH_BLK_FLOATS 256     // one operand block of one tile: 64 lanes x float4
@@ -361,8 +368,9 @@ __device__ __forceinline__ ChainGroup group_of(const ChainStage* stg, int si, in
     return g;
 }
 // the wave's next tile pair behind (si, tp): the next pass of the same stage, else its pair in the next GEMM stage
+template <int NW>
 __device__ __forceinline__ ChainGroup next_group(const ChainStage* stg, int nst, int si, int tp, int wave, int e) {
-    if (si >= 0 && tp + CH_WAVES < uni(stg[si].ntp)) return group_of(stg, si, tp + CH_WAVES, e);
+    if (si >= 0 && tp + NW < uni(stg[si].ntp)) return group_of(stg, si, tp + NW, e);
     for (int sj = si + 1; sj < nst; ++sj)
         if (wave < uni(stg[sj].ntp)) return group_of(stg, sj, wave, e);
     ChainGroup g;
@@ -413,6 +421,7 @@ __device__ __forceinline__ void load_ops(const ChainStage* stg, const ChainGroup
 // One tile pair of a GEMM stage: k loop over the ring, epilogue.  At the end of the epilogue -- behind this group's
 // stores -- the NEXT group's operands and first ring blocks are requested: by the time the stage-end barrier has been
 // passed they have landed, so a stage starts with MFMAs instead of an L2 round trip.
+template <int NW>
 __device__ __forceinline__ void chain_group(const ChainStage* stg, int nst, int wave, const ChainGroup& g, ChainGroup& nxt, ChainOps& ops,
                                             float* bufs, int bufsz, int e, int B, int row0, int lane, unsigned long long* dbg) {
     if (dbg) dbg[0] = __builtin_readcyclecounter();
@@ -551,7 +560,7 @@ __device__ __forceinline__ void chain_group(const ChainStage* stg, int nst, int 
                 }
         }
     }
-    nxt = next_group(stg, nst, g.si, g.tp, wave, e);       // (looked up here, not in front of the k loop: its LDS reads are round trips)
+    nxt = next_group<NW>(stg, nst, g.si, g.tp, wave, e);       // (looked up here, not in front of the k loop: its LDS reads are round trips)
     load_ops(stg, nxt, e, B, row0, lane, ops);
     ring_prologue(nxt, loff);
     if (dbg) dbg[2] = __builtin_readcyclecounter();
@@ -576,7 +585,7 @@ struct ChainInSrc {
 };
 __device__ __forceinline__ ChainInSrc chain_input_src(const ChainLoad& d, const ChainAsm& ap, int e, int B, int row0, int tid) {
     ChainInSrc r;
-    const int row = row0 + ((tid >> 4) & 15);                 // (512 threads = 2 x 256 elements: a thread keeps its row)
+    const int row = row0 + ((tid >> 4) & 15);                 // (a thread's elements are 256 apart: it keeps its row)
     r.rok = row < B;
     r.grow = (long)e * B + (r.rok ? row : 0);
     long srow = r.grow, swin = r.grow;
@@ -600,11 +609,11 @@ __device__ __forceinline__ ChainInSrc chain_input_src(const ChainLoad& d, const 
     }
     return r;
 }
-template <int NU>
+template <int NT, int NU>
 __device__ __forceinline__ void chain_input_fetch(const ChainLoad& d, const ChainInSrc& r, int base, int tid, ChainIn<NU>& q) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const int idx = base + u * CH_THREADS + tid;
+        const int idx = base + u * NT + tid;
         const int k = (idx >> 8) * 16 + (idx & 15);
         const int j = k < d.K ? k : 0;
         const int jx = r.hc ? (j == 0 ? 1 : j <= 2 ? 2 : j) : j + r.shift;     // preproc_at's source column
@@ -613,14 +622,14 @@ __device__ __forceinline__ void chain_input_fetch(const ChainLoad& d, const Chai
         q.b[u] = r.b0[j];
     }
 }
-template <int NU>
+template <int NT, int NU>
 __device__ __forceinline__ void chain_input_commit(const ChainLoad& d, const ChainInSrc& r, int base, int tid, const ChainIn<NU>& q,
                                                    float* bufs, int bufsz) {
     float* dst = bufs + d.dst * bufsz;
     const int m = (tid >> 4) & 15;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        const int idx = base + u * CH_THREADS + tid;
+        const int idx = base + u * NT + tid;
         const int k = (idx >> 8) * 16 + (idx & 15);
         const bool ok = k < d.K && r.rok;
         float x;
@@ -722,7 +731,9 @@ __device__ __forceinline__ float chain_loss_target(const LossP& p, int e, int y,
     return y == 0 ? (p.delta[si] - p.dmean[d]) / (p.dstd[d] + 1e-10f) : (p.back_delta[si] - p.bdmean[d]) / (p.bdstd[d] + 1e-10f);
 }
 
+template <int NW>
 __device__ __forceinline__ void chain_loss_phase(const ChainArgs& a, float* bufs, float* scr, int e, int y, int row0, int tid, float tgt0) {
+    constexpr int CH_THREADS = 64 * NW;
     const LossP& p = a.lossp;
     const ReduceP& r = a.lossr;
     const int D = p.D, B = p.B, nel = CH_ROWS * D, lane = tid & 63, wave = tid >> 6;
@@ -780,8 +791,9 @@ __device__ __forceinline__ void chain_loss_phase(const ChainArgs& a, float* bufs
             if (a.loss_final) __hip_atomic_store(part + wave, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else part[wave] = v;
         }
-    } else {                                                       // per-dim terms: one thread per (bound, dim), rows ascending
-        for (int o = tid - 256; o < 2 * D; o += 256) {
+    }
+    {                                                              // per-dim terms: one thread per (bound, dim), rows ascending
+        for (int o = (NW > 4 ? tid - 256 : tid); o >= 0 && o < 2 * D; o += 256) {
             const int which = o / D, d = o - which * D;
             float v = 0.0f;
             for (int m = 0; m < CH_ROWS; ++m) v += scr[(4 + which) * nel + m * D + d];
@@ -808,10 +820,12 @@ __device__ __forceinline__ void chain_loss_phase(const ChainArgs& a, float* bufs
     if (tid == 0) *flag = atomicInc(r.counter, a.loss_slots - 1) == (unsigned)(a.loss_slots - 1);     // wraps back to 0 for the next step
     __syncthreads();
     if (!*flag) return;
-    loss_finalize<CH_THREADS, true>(r, a.loss_slots, scr, tid);
+    loss_finalize<256, true>(r, a.loss_slots, scr, tid);      // (256 threads' chunking in BOTH flavours -- and in dw_adam_kernel's copy: the same sums, bit for bit)
 }
 
-__global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void chain_kernel(const ChainArgs a) {
+    constexpr int CH_THREADS = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float chain_smem[];
     ChainStage* const stg = reinterpret_cast<ChainStage*>(chain_smem);
     float* const bufs = chain_smem + (CH_MAXSTAGE * sizeof(ChainStage)) / sizeof(float);
@@ -855,27 +869,28 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
                         d3 = y ? a.pre[1][3] : a.pre[0][3];
         // elements per thread requested in one go: 6 / 4 / 2 / 2 (96 / 64 / 32 / 32 columns; wider tiles loop).  Deeper would
         // push the prologue past 128 VGPRs: hipcc then parks values in AGPRs -- the ring's (tests/test_isa_hygiene.py).
-        ChainIn<6> q0;
-        ChainIn<4> q1;
-        ChainIn<2> q2, q3;
+        constexpr int Q0 = NW == 8 ? 6 : 2, Q1 = NW == 8 ? 4 : 2, Q2 = NW == 8 ? 2 : 1;      // (4-wave flavour: 84 VGPRs -- fewer in flight)
+        ChainIn<Q0> q0;
+        ChainIn<Q1> q1;
+        ChainIn<Q2> q2, q3;
         const ChainInSrc r0 = chain_input_src(d0, a.asmp, e, B, row0, tid), r1 = chain_input_src(np > 1 ? d1 : d0, a.asmp, e, B, row0, tid),
                          r2 = chain_input_src(np > 2 ? d2 : d0, a.asmp, e, B, row0, tid), r3 = chain_input_src(np > 3 ? d3 : d0, a.asmp, e, B, row0, tid);
-        chain_input_fetch(d0, r0, 0, tid, q0);
-        if (np > 1) chain_input_fetch(d1, r1, 0, tid, q1);
-        if (np > 2) chain_input_fetch(d2, r2, 0, tid, q2);
-        if (np > 3) chain_input_fetch(d3, r3, 0, tid, q3);
+        chain_input_fetch<CH_THREADS>(d0, r0, 0, tid, q0);
+        if (np > 1) chain_input_fetch<CH_THREADS>(d1, r1, 0, tid, q1);
+        if (np > 2) chain_input_fetch<CH_THREADS>(d2, r2, 0, tid, q2);
+        if (np > 3) chain_input_fetch<CH_THREADS>(d3, r3, 0, tid, q3);
         if (timed0) a.tbuf[201] = __builtin_readcyclecounter();
-        chain_input_commit(d0, r0, 0, tid, q0, bufs, a.bufsz);
-        if (np > 1) chain_input_commit(d1, r1, 0, tid, q1, bufs, a.bufsz);
-        if (np > 2) chain_input_commit(d2, r2, 0, tid, q2, bufs, a.bufsz);
-        if (np > 3) chain_input_commit(d3, r3, 0, tid, q3, bufs, a.bufsz);
+        chain_input_commit<CH_THREADS>(d0, r0, 0, tid, q0, bufs, a.bufsz);
+        if (np > 1) chain_input_commit<CH_THREADS>(d1, r1, 0, tid, q1, bufs, a.bufsz);
+        if (np > 2) chain_input_commit<CH_THREADS>(d2, r2, 0, tid, q2, bufs, a.bufsz);
+        if (np > 3) chain_input_commit<CH_THREADS>(d3, r3, 0, tid, q3, bufs, a.bufsz);
         for (int i = 0; i < np; ++i) {                        // the rest of wide tiles, one round trip per 32 columns
             const ChainLoad& d = i == 0 ? d0 : i == 1 ? d1 : i == 2 ? d2 : d3;
             const ChainInSrc& r = i == 0 ? r0 : i == 1 ? r1 : i == 2 ? r2 : r3;
-            const int done = (i == 0 ? 6 : i == 1 ? 4 : 2) * CH_THREADS;
-            for (int base = done; base < ((d.zero_to - d.dk0 + 15) & ~15) * CH_ROWS; base += 2 * CH_THREADS) {
-                chain_input_fetch(d, r, base, tid, q3);
-                chain_input_commit(d, r, base, tid, q3, bufs, a.bufsz);
+            const int done = (i == 0 ? Q0 : i == 1 ? Q1 : Q2) * CH_THREADS;
+            for (int base = done; base < ((d.zero_to - d.dk0 + 15) & ~15) * CH_ROWS; base += Q2 * CH_THREADS) {
+                chain_input_fetch<CH_THREADS>(d, r, base, tid, q3);
+                chain_input_commit<CH_THREADS>(d, r, base, tid, q3, bufs, a.bufsz);
             }
         }
     }
@@ -888,21 +903,23 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(const ChainArgs a) {
     if (timed) a.tbuf[0] = __builtin_readcyclecounter();
     const float tgt0 = a.loss_on ? chain_loss_target(a.lossp, e, y, row0, tid) : 0.0f;
     ChainOps ops;
-    ChainGroup cur = next_group(stg, nst, -1, 0, wave, e);
+    ChainGroup cur = next_group<NW>(stg, nst, -1, 0, wave, e);
     load_ops(stg, cur, e, B, row0, lane, ops);
     ring_prologue(cur, 16u * (unsigned)lane);
     for (int si = 0; si < nst; ++si) {
         while (cur.si == si) {
             ChainGroup nxt;
             unsigned long long* dbg = timed ? a.tbuf + 64 + si * 4 : nullptr;
-            chain_group(stg, nst, wave, cur, nxt, ops, bufs, a.bufsz, e, B, row0, lane, dbg);
+            chain_group<NW>(stg, nst, wave, cur, nxt, ops, bufs, a.bufsz, e, B, row0, lane, dbg);
             cur = nxt;
         }
         if (timed) a.tbuf[64 + si * 4 + 3] = __builtin_readcyclecounter();
         __syncthreads();
         if (timed) a.tbuf[si + 1] = __builtin_readcyclecounter();
     }
-    if (a.loss_on) chain_loss_phase(a, bufs, bufs + 3 * a.bufsz, e, y, row0, tid, tgt0);
+    // (the loss terms' scratch: an activation buffer the chain is done with -- the head outputs sit in loss_buf, the other two are dead;
+    //  a region of its own behind the buffers cost the third workgroup per CU its LDS)
+    if (a.loss_on) chain_loss_phase<NW>(a, bufs, bufs + ((a.loss_buf + 1) % 3) * a.bufsz, e, y, row0, tid, tgt0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1663,6 +1680,10 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
     }
     for (int i = 0; i < 5; ++i) { t->prog_first[i] = first[i]; t->prog_count[i] = count[i]; }
     t->chain_bufsz = CH_ROWS * ((maxk + 15) & ~15);
+    {   // (an activation buffer doubles as the loss phase's scratch: 6 term arrays of 16 x D elements, or 512 chunk sums, + a flag)
+        const int terms = 6 * CH_ROWS * ctx->D, need = ((terms > CH_THREADS_MAX ? terms : CH_THREADS_MAX) + 4 + 63) & ~63;
+        if (t->chain_bufsz < need) t->chain_bufsz = need;
+    }
     return CADM_OK;
 }
 
@@ -1686,21 +1707,28 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s, const Chai
     const int per = a.ntiles * a.ny;
     a.ips = (per + a.G - 1) / a.G;
     const int rounds = (ctx->E + 7) / 8;
-    size_t lds = CH_MAXSTAGE * sizeof(ChainStage) + 3 * (size_t)t->chain_bufsz * sizeof(float);
-    if (loss) {     // closing loss phase: 6 term arrays of the workgroup's 16 x D elements + a flag behind the activation buffers
+    const size_t lds = CH_MAXSTAGE * sizeof(ChainStage) + 3 * (size_t)t->chain_bufsz * sizeof(float);
+    if (loss) {     // closing loss phase: 6 term arrays of the workgroup's 16 x D elements + a flag, in an activation buffer the chain is done with
         a.loss_on = 1; a.loss_final = loss->final; a.loss_buf = t->loss_buf; a.loss_lv0 = t->loss_lv0; a.loss_slots = ctx->E * a.ny * a.ntiles;
         a.lossp = loss->lp; a.lossr = loss->rp;
-        const size_t terms = 6 * (size_t)CH_ROWS * ctx->D;          // (the final reduction reuses it for up to CH_THREADS chunk sums)
-        lds += ((terms > CH_THREADS ? terms : CH_THREADS) + 4) * sizeof(float);
+        const size_t terms = 6 * (size_t)CH_ROWS * ctx->D;          // (the final reduction reuses it for up to 512 chunk sums)
+        CADM_REQUIRE(((terms > CH_THREADS_MAX ? terms : CH_THREADS_MAX) + 4) * sizeof(float) <= (size_t)t->chain_bufsz * sizeof(float),
+                     "training chain: loss scratch does not fit an activation buffer");
     }
     CADM_REQUIRE(lds <= 160 * 1024, "training chain: layer too wide for the LDS-resident activation tile");
     CADM_REQUIRE((long long)B * (t->chain_bufsz / CH_ROWS) * 4 < (1LL << 32),
                  "training chain: batch of %d rows too large for 32-bit per-member offsets", B);
-    if (lds > ctx->chain_attr_lds) {      // per ctx = per device (a process-wide flag would leave a second GPU's attribute unset)
-        CADM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ctx->chain_attr_lds = lds;
+    // more work items than CUs: the throughput flavour (three 4-wave workgroups per CU), if three of them fit the LDS
+    const long items = (long)ctx->E * per;
+    const bool wide = ctx->train_force_nw ? ctx->train_force_nw == 4 : (items > ctx->n_cus && 3 * lds <= 160 * 1024);
+    const void* fn = wide ? reinterpret_cast<const void*>(&chain_kernel<4>) : reinterpret_cast<const void*>(&chain_kernel<8>);
+    size_t& attr = wide ? ctx->chain_attr_lds4 : ctx->chain_attr_lds;
+    if (lds > attr) {      // per ctx = per device (a process-wide flag would leave a second GPU's attribute unset)
+        CADM_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
     }
-    hipLaunchKernelGGL(chain_kernel, dim3(8 * a.ips * rounds), dim3(CH_THREADS), lds, s, a);
+    if (wide) hipLaunchKernelGGL(chain_kernel<4>, dim3(8 * a.ips * rounds), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(chain_kernel<8>, dim3(8 * a.ips * rounds), dim3(512), lds, s, a);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
 }

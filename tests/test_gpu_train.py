@@ -95,10 +95,12 @@ def _check_gradients(eng, grads, what):
     return checked
 
 
+@pytest.mark.parametrize("flavour", [8, 4])       # chain kernel: 8 waves x 1 workgroup per CU (latency) / 4 waves x 3 per CU (throughput)
 @pytest.mark.parametrize("env,context,with_back,det,E,B", CASES)
-def test_gradients_elementwise_vs_fp64_autograd(gpu, env, context, with_back, det, E, B):
+def test_gradients_elementwise_vs_fp64_autograd(gpu, env, context, with_back, det, E, B, flavour):
     prob = synth.make_problem(env=env, context=context, E=E, trained_like=True, with_back=with_back, seed=22)
     eng = _dev_engine(prob, E, deterministic=det)
+    eng._check(eng.lib.cadm_dev_set_train_flavour(eng._ctx, flavour), "cadm_dev_set_train_flavour")
     bc = 0.5 if with_back else 0.0
     eng.train_configure(1e-3, WD, CWD, 1.0, bc, max_batch=B, beta1=0.0)
     batch = synth.make_train_batch(prob, B=B, seed=3)
@@ -113,6 +115,33 @@ def test_gradients_elementwise_vs_fp64_autograd(gpu, env, context, with_back, de
         for name, w0 in before[net].items():
             if grads[net][name] is None:
                 assert torch.equal(w0, eng.nets[net][name]), "%s/%s moved although it has no gradient" % (net, name)
+
+
+def test_chain_kernel_flavours_agree_bitwise(gpu):
+    """Round 5: the chain kernel exists with 8 waves per workgroup (one workgroup per CU: the reference's batch of 256) and with 4 (three
+    workgroups per CU: large batches; the launcher picks by the number of work items).  A row's arithmetic -- operand order of every
+    MFMA chain, epilogues, the loss phase's reductions -- is the same in both: six training steps from the same state end in bit-identical
+    weights, moments and losses, at a batch size on either side of the switch."""
+    for B in (64, 600):
+        prob = synth.make_problem(env="halfcheetah", context=True, E=5, trained_like=True, with_back=True, seed=29)
+        batch = synth.make_train_batch(prob, B=B, seed=5)
+        end = {}
+        for fl in (8, 4, 0):
+            eng = _dev_engine(prob, 5)
+            eng._check(eng.lib.cadm_dev_set_train_flavour(eng._ctx, fl), "cadm_dev_set_train_flavour")
+            eng.train_configure(1e-3, WD, CWD, 1.0, 0.5, max_batch=B)
+            dev = _dev_batch(eng, batch, True, True)
+            losses = [eng.train_step(dev, train=True).cpu().numpy() for _ in range(6)]
+            ev = eng.train_step(dev, train=False).cpu().numpy()
+            end[fl] = (losses, ev, {n: {k: v.cpu().numpy() for k, v in eng.nets[n].items()} for n in eng.net_names()})
+            eng.close()
+        for fl in (4, 0):
+            for a, b in zip(end[8][0], end[fl][0]):
+                np.testing.assert_array_equal(a, b)
+            np.testing.assert_array_equal(end[8][1], end[fl][1])
+            for n in end[8][2]:
+                for k in end[8][2][n]:
+                    np.testing.assert_array_equal(end[8][2][n][k], end[fl][2][n][k], err_msg="B=%d flavour %d %s/%s" % (B, fl, n, k))
 
 
 def test_adam_steps_match_tf1_semantics_elementwise(gpu):
