@@ -70,7 +70,7 @@ typedef struct cadm_config {
     int32_t act_dim;           /* A */
     int32_t proc_obs_dim;      /* P */
     int32_t context_dim;       /* C = context_out_dim, 0 for the vanilla PE-TS model */
-    int32_t n_hidden;          /* number of hidden layers (4) */
+    int32_t n_hidden;          /* number of hidden layers (4; 1 .. CADM_MAX_HIDDEN_LAYERS) */
     int32_t hidden;            /* hidden width, all layers equal (200) */
     int32_t horizon;           /* n_forwards H */
     int32_t deterministic;     /* dynamics.py:43 */
