@@ -133,6 +133,7 @@ struct cadm_ctx {
     size_t chain_attr_lds = 0;      // training chain kernel: the dynamic-LDS size its attribute was last raised to on this ctx's device
     size_t chain_attr_lds4 = 0;     // (its 4-wave throughput flavour)
     int train_force_nw = 0;         // developer library only: 4 / 8 = force that flavour of the chain kernel (0: by work items)
+    int train_force_spread = 0;     // developer library only: 1 / 2 = force the chain kernel's work items spread over all XCDs / member-affine
     NormStats st;
     TrainState* train = nullptr;
     // scratch for the context encoder

@@ -108,8 +108,11 @@ extern "C" int cadm_dev_input_checksum(cadm_ctx* ctx, const float* obs, const fl
     return cadm_launch_input_checksum(ctx, obs, cp_obs, cp_act, mean, var, m, reinterpret_cast<unsigned*>(word_out), (hipStream_t)stream);
 }
 
-extern "C" int cadm_dev_set_train_flavour(cadm_ctx* ctx, int waves) {
-    CADM_REQUIRE(ctx && (waves == 0 || waves == 4 || waves == 8), "cadm_dev_set_train_flavour: waves must be 0, 4 or 8");
+extern "C" int cadm_dev_set_train_flavour(cadm_ctx* ctx, int flavour) {
+    const int waves = flavour & 15, map = flavour >> 4;          // + 16: work items spread over all XCDs, + 32: member-affine (0: the launcher's rule)
+    CADM_REQUIRE(ctx && (waves == 0 || waves == 4 || waves == 8) && map >= 0 && map <= 2,
+                 "cadm_dev_set_train_flavour: 0, 4 or 8 waves (+ 16 / + 32 to force the XCD mapping)");
     ctx->train_force_nw = waves;
+    ctx->train_force_spread = map;
     return CADM_OK;
 }

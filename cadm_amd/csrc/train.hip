@@ -186,6 +186,7 @@ __device__ __forceinline__ gptr as_global(float* p) { return (gptr)p; }
 //           chain's epilogue / barrier / stage start (36 % of a stage, chain_timing) runs beside the others' MFMAs.  The throughput
 //           flavour, for launches of more work items than CUs: B = 4096 1.633 -> 1.200 ms per step (0.177 -> 0.241 of the fp32
 //           matrix peak), B = 1024 0.410 -> 0.340; at B = 256 it would be 0.144 instead of 0.120 ms (profiles/r5_train_scaling.md).
+//           With the work items spread over all eight XCDs (xcd_spread_item) B = 4096 0.88 ms (0.328).
 #define CH_WAVES_MAX 8
 #define CH_THREADS_MAX (64 * CH_WAVES_MAX)
 #define CH_RING 8             // operand blocks (16 k x 2 tiles) of a wave's ring; CH_RING - 1 are in flight
@@ -207,11 +208,17 @@ struct ChainSeg {
     const float *bias, *zprev;                           // bias [E][N]; zprev [E][B][ldz]: pre-activation whose act' scales the result
     float *out0, *out1;                                  // [E][B][ldo]: value before act_o / after
     int N, ldo, ldz, vec;                                // vec: N, ldo, ldz, dk0 all multiples of 4 -> 16-byte accesses
-    int nt, pad[3];                                      // tiles of the stream
+    int nt;                                              // tiles of the stream
+    int pkB, pkC, pad;                                   // (host, finish of sync_programs) vec | nt << 8;  N | ldz << 16: the lookup of a wave's next
+                                                         //  group reads these instead of the four fields (registers: see chain_group)
 };
 struct ChainStage {
     int KB, src, dst, dk0, act_d, act_o, ntp, tp1;       // KB: k-blocks; ntp: tile pairs (all segments); tp1: first pair of segment 1
-    int zfill, pad[7];                                   // zfill: columns N .. of the last tile are written as zeros
+    int zfill;                                           // zfill: columns N .. of the last tile are written as zeros
+    unsigned char nxt[8];                                // wave slot w's next stage behind this one (index inside the chain; 31: none) | 0x80 if its
+                                                         //  pair there (tile pair w) belongs to segment 1 -- filled by finish_chain_table (host)
+    int pkA;                                             // (host) KB | src << 8 | tp1 << 16 | ntp << 24
+    int pad[4];
     ChainSeg seg[2];
 };
 struct ChainLoad {        // input tile -> LDS: K columns of g0 (+ g1) [E][B][ld_in] become rows dk0 .. dk0 + K - 1 of buffer dst,
@@ -231,6 +238,9 @@ struct ChainArgs {
     LossP lossp; ReduceP lossr;                          //  (head outputs in LDS buffer loss_buf: mu at rows 0.., logvar at rows loss_lv0..)
     int B, bufsz;                                        // rows per member, floats per LDS activation buffer
     int E, ny, ntiles, G, ips;                           // work decomposition, see chain_kernel
+    int spread, per_xcd;                                 // spread: XCD x takes the x-th contiguous eighth of the (member-major) work items
+    unsigned long long* tfine;                           // (same item) wave 0's epilogue, per GEMM stage: [6 si ..] activation math done, LDS tile
+                                                         // stored, global stores issued, next group looked up, its operands requested
     unsigned long long* tbuf;                            // cadm_dev_set_timing_buffer: clocks of member 0's first work item:
                                                          // [0..63] stage boundaries, [64 + 4 si ..] wave 0: group start, k loop end,
                                                          // epilogue end, barrier reached
@@ -284,6 +294,7 @@ struct ChainGroup {       // one wave's work in one stage: a tile pair
     int bstep;            // bytes from one k-block to the next
     int sg, nb, src;      // its segment, first column inside the segment, LDS buffer of the stage's input: looked up with the
                           // group (one stage ahead), so that nothing the k loop needs is read out of the table at stage start
+    int ntp; unsigned nx; // the stage's tile pairs; ChainStage::nxt of this wave slot: what the NEXT lookup starts from (scalars, no LDS read)
 };
 
 // block i of the group -> ring slot S (both tiles); (uniform 64-bit base in SGPRs) + (32-bit per-lane byte offset)
@@ -355,7 +366,7 @@ __device__ __forceinline__ void ring_done(floatx4 (&acc)[2]) {   // last MFMA ->
     asm volatile("s_nop 11" : "+v"(acc[0]), "+v"(acc[1]));
 }
 
-__device__ __forceinline__ ChainGroup group_of(const ChainStage* stg, int si, int tp, int e) {
+__device__ __forceinline__ ChainGroup group_of(const ChainStage* stg, int si, int tp, int e, int wave) {
     const ChainStage& st = stg[si];
     const int tp1 = uni(st.tp1);
     const int sg = tp >= tp1 ? 1 : 0;
@@ -365,16 +376,17 @@ __device__ __forceinline__ ChainGroup group_of(const ChainStage* stg, int si, in
     g.sg = sg; g.nb = 32 * (tp - (sg ? tp1 : 0)); g.src = uni(st.src);
     g.w0 = uni((gcbytes)(as_global(seg.P) + (long)e * seg.sP + (long)(2 * (tp - (sg ? tp1 : 0))) * CH_BLK_FLOATS));
     g.bstep = uni(seg.nt) * (CH_BLK_FLOATS * 4);
+    g.ntp = uni(st.ntp); g.nx = (unsigned)uni((int)st.nxt[wave]);
     return g;
 }
 // the wave's next tile pair behind (si, tp): the next pass of the same stage, else its pair in the next GEMM stage
 template <int NW>
 __device__ __forceinline__ ChainGroup next_group(const ChainStage* stg, int nst, int si, int tp, int wave, int e) {
-    if (si >= 0 && tp + NW < uni(stg[si].ntp)) return group_of(stg, si, tp + NW, e);
+    if (si >= 0 && tp + NW < uni(stg[si].ntp)) return group_of(stg, si, tp + NW, e, wave);
     for (int sj = si + 1; sj < nst; ++sj)
-        if (wave < uni(stg[sj].ntp)) return group_of(stg, sj, wave, e);
+        if (wave < uni(stg[sj].ntp)) return group_of(stg, sj, wave, e, wave);
     ChainGroup g;
-    g.si = -1; g.tp = 0; g.KB = 0; g.w0 = nullptr; g.bstep = 0; g.sg = 0; g.nb = 0; g.src = 0;
+    g.si = -1; g.tp = 0; g.KB = 0; g.w0 = nullptr; g.bstep = 0; g.sg = 0; g.nb = 0; g.src = 0; g.ntp = 0; g.nx = 31;
     return g;
 }
 
@@ -423,7 +435,8 @@ __device__ __forceinline__ void load_ops(const ChainStage* stg, const ChainGroup
 // passed they have landed, so a stage starts with MFMAs instead of an L2 round trip.
 template <int NW>
 __device__ __forceinline__ void chain_group(const ChainStage* stg, int nst, int wave, const ChainGroup& g, ChainGroup& nxt, ChainOps& ops,
-                                            float* bufs, int bufsz, int e, int B, int row0, int lane, unsigned long long* dbg) {
+                                            float* bufs, int bufsz, int e, int B, int row0, int lane, unsigned long long* dbg,
+                                            unsigned long long* fine) {
     if (dbg) dbg[0] = __builtin_readcyclecounter();
     const ChainStage& st = stg[g.si];
     const int m = lane & 15, q = lane >> 4;
@@ -458,7 +471,7 @@ __device__ __forceinline__ void chain_group(const ChainStage* stg, int nst, int 
     const bool VEC = uni(rvec) != 0;
     gcbytes p_o0 = uni_ptr(ro0), p_o1 = uni_ptr(ro1);
     const bool has_z = uni_ptr(rz) != nullptr, has_b = uni_ptr(rbias) != nullptr, s0 = p_o0 != nullptr, s1 = p_o1 != nullptr;
-    floatx4 v0[2], v1[2];                         // [tile][r]: before / after the output activation
+    floatx4 v0[2];                                // [tile][r]: before the output activation
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -489,6 +502,31 @@ __device__ __forceinline__ void chain_group(const ChainStage* stg, int nst, int 
                 for (int r = 0; r < 4; ++r) { const float sg_ = sigmoid_fast(zp[j][r]); v0[j][r] *= sg_ * (1.0f - sg_); }
         }
     }
+    // global stores: (uniform base of this member) + 32-bit byte offset (host checks B * ldo * 4 < 2^32).  The value before the output
+    // activation is stored as soon as it exists -- not next to the activated one: eight registers fewer are live through the activation math.
+    typedef __attribute__((address_space(1))) float* gfp;
+    typedef __attribute__((address_space(1))) floatx4* gf4p;
+    auto store_rows = [&](gcbytes base, const floatx4 (&v)[2]) {
+        if (row >= B) return;
+        if (VEC) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (n0[j] >= N) continue;
+                *(gf4p)(base + 4u * (unsigned)(row * ldo + n0[j])) = v[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0[j] + r;
+                    if (n >= N) continue;
+                    *(gfp)(base + 4u * (unsigned)(row * ldo + n)) = v[j][r];
+                }
+        }
+    };
+    if (s0) store_rows(p_o0 + mrow * ldo * 4, v0);
+    floatx4 v1[2];                                // ... and after
     if (act_o == ACT_SWISH) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -517,6 +555,26 @@ __device__ __forceinline__ void chain_group(const ChainStage* stg, int nst, int 
 #pragma unroll
         for (int j = 0; j < 2; ++j) v1[j] = v0[j];
     }
+    // The wave's next group -- the next pass of this stage (tile pair tp + NW), else its pair in the stage the table names (ChainStage::nxt,
+    // precomputed on the host) -- is known from scalars that came with THIS group's descriptor, so its whole descriptor is ONE batch of LDS reads,
+    // requested here -- behind the activation math, whose registers it would compete for: hipcc parks values in the ring's AGPRs otherwise -- and
+    // consumed behind this group's stores, which run under its latency.  (Until round 5 the
+    // lookup walked the table behind the stores -- stage's pair count, next stage's, the group's fields, the operands' fields: three to four
+    // dependent LDS round trips, 2-3 k of an epilogue's 5-6 k cycles under load, tools/chain_timing.py.)
+    const unsigned nx = g.nx;
+    const bool same_stage = g.tp + NW < g.ntp;
+    const int nsi = same_stage ? g.si : ((nx & 31u) == 31u ? -1 : (int)(nx & 31u));
+    const int ntpp = same_stage ? g.tp + NW : wave;
+    const int nsg = same_stage ? (ntpp >= tp1 ? 1 : 0) : (int)(nx >> 7);
+    struct { int A, B, C, nx; const float *P, *bias, *z; long sP; } rq;
+    auto request_next = [&]() {
+        const ChainStage& ns = stg[nsi < 0 ? 0 : nsi];
+        const ChainSeg& nseg = ns.seg[nsg];
+        rq.A = ns.pkA; rq.B = nseg.pkB; rq.C = nseg.pkC; rq.nx = ns.nxt[wave];
+        rq.P = nseg.P; rq.bias = nseg.bias; rq.z = nseg.zprev; rq.sP = nseg.sP;
+    };
+    if constexpr (NW == 8) request_next();
+    if (fine) fine[0] = __builtin_readcyclecounter();
     if (dsti >= 0) {
         float* dst = bufs + dsti * bufsz;
         const int sg0 = sg ? 32 * tp1 : 0;                // a second segment's columns follow the first's tile pairs
@@ -534,34 +592,48 @@ __device__ __forceinline__ void chain_group(const ChainStage* stg, int nst, int 
                 }
         }
     }
-    // global stores: (uniform base of this member) + 32-bit byte offset (host checks B * ldo * 4 < 2^32)
-    gcbytes b0 = p_o0 + mrow * ldo * 4, b1 = p_o1 + mrow * ldo * 4;
-    typedef __attribute__((address_space(1))) float* gfp;
-    typedef __attribute__((address_space(1))) floatx4* gf4p;
-    if (row < B) {
-        if (VEC) {
+    if constexpr (NW != 8) request_next();      // (the 4-wave flavour has 84 VGPRs: requested in front of the activation tile's stores, hipcc parks values in the ring's AGPRs)
+    if (fine) fine[1] = __builtin_readcyclecounter();
+    if (s1) store_rows(p_o1 + mrow * ldo * 4, v1);
+    if (fine) fine[2] = __builtin_readcyclecounter();
+    // ---- the wave's next group: descriptor (requested behind the k loop, see above) -> scalars, its epilogue operands and first ring blocks ----
+    nxt.si = nsi; nxt.tp = ntpp; nxt.sg = nsg;
+    if (nsi >= 0) {
+        const int pA = uni(rq.A), pB = uni(rq.B), pC = uni(rq.C);
+        const int qtp1 = (pA >> 16) & 255, qN = pC & 0xffff, qldz = (int)((unsigned)pC >> 16);
+        const bool qVEC = (pB & 1) != 0;
+        const int tp_in = ntpp - (nsg ? qtp1 : 0);                         // pair index inside its segment
+        nxt.KB = pA & 255; nxt.src = (pA >> 8) & 255; nxt.nb = 32 * tp_in;
+        nxt.w0 = uni((gcbytes)(as_global(rq.P) + (long)e * rq.sP + (long)(2 * tp_in) * CH_BLK_FLOATS));
+        nxt.bstep = (pB >> 8) * (CH_BLK_FLOATS * 4);
+        nxt.ntp = (int)((unsigned)pA >> 24); nxt.nx = (unsigned)uni(rq.nx);
+        gcbytes p_bias = uni_ptr(rq.bias), p_z = uni_ptr(rq.z);
+        const bool hz = p_z != nullptr, hb = p_bias != nullptr;
+        const int rowc = row < B ? row : B - 1;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (n0[j] >= N) continue;
-                const unsigned o = 4u * (unsigned)(row * ldo + n0[j]);
-                if (s0) *(gf4p)(b0 + o) = v0[j];
-                if (s1) *(gf4p)(b1 + o) = v1[j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            const int c0 = nxt.nb + 16 * j + 4 * q;
+            if (qVEC) {
+                const int nc = c0 < qN ? c0 : 0;
+                gcbytes bb = hb ? p_bias + ((long)e * qN + nc) * 4 : nxt.w0;
+                gcbytes zb = hz ? p_z + ((mrow + rowc) * qldz + nc) * 4 : nxt.w0;
+                ops.bv[j] = *reinterpret_cast<gcptr4>(bb);
+                ops.zp[j] = *reinterpret_cast<gcptr4>(zb);
+            } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int n = n0[j] + r;
-                    if (n >= N) continue;
-                    const unsigned o = 4u * (unsigned)(row * ldo + n);
-                    if (s0) *(gfp)(b0 + o) = v0[j][r];
-                    if (s1) *(gfp)(b1 + o) = v1[j][r];
+                    const int n = c0 + r, nc = n < qN ? n : qN - 1;
+                    gcbytes bb = hb ? p_bias + ((long)e * qN + nc) * 4 : nxt.w0;
+                    gcbytes zb = hz ? p_z + ((mrow + rowc) * qldz + nc) * 4 : nxt.w0;
+                    ops.bv[j][r] = *reinterpret_cast<gcptr>(bb);
+                    ops.zp[j][r] = *reinterpret_cast<gcptr>(zb);
                 }
+            }
         }
+    } else {
+        nxt.KB = 0; nxt.w0 = nullptr; nxt.bstep = 0; nxt.nb = 0; nxt.src = 0; nxt.ntp = 0; nxt.nx = 31;
     }
-    nxt = next_group<NW>(stg, nst, g.si, g.tp, wave, e);       // (looked up here, not in front of the k loop: its LDS reads are round trips)
-    load_ops(stg, nxt, e, B, row0, lane, ops);
+    if (fine) fine[3] = fine[4] = __builtin_readcyclecounter();      // (one stamp for both: a per-thread branch inside the uniform one above makes hipcc treat the group's scalars as per-lane values)
     ring_prologue(nxt, loff);
     if (dbg) dbg[2] = __builtin_readcyclecounter();
 }
@@ -658,6 +730,17 @@ __device__ __forceinline__ bool xcd_affine_item(int E, int G, int ips, int per, 
     e = xcd / G + 8 * (j / ips);
     item = (j % ips) * G + xcd % G;
     return e < E && item < per;
+}
+// More work items than the affine mapping's XCDs can hold in one round (large batches): that mapping leaves 8 - G E XCDs idle -- three
+// of eight for the 5-member ensemble, found in round 5 with the per-item clocks: an item took 160 k cycles, the launch 6 rounds of them.
+// Then XCD x takes the x-th CONTIGUOUS eighth of the member-major item list instead (as dw_adam_kernel does): every XCD is busy, and
+// its L2 still holds the weights of at most two members (E <= 8).
+__device__ __forceinline__ bool xcd_spread_item(int E, int per_xcd, int per, int& e, int& item) {
+    const int g = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (g >= E * per) return false;
+    e = g / per;
+    item = g - e * per;
+    return true;
 }
 
 // Sums of the workgroups' partials in a fixed order (G groups of threads take contiguous chunks of slots -- loads eight at a
@@ -843,7 +926,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void chain_kernel(const C
     }
     int e, item;
     const int per = a.ntiles * a.ny;
-    if (!xcd_affine_item(a.E, a.G, a.ips, per, e, item)) return;
+    if (a.spread ? !xcd_spread_item(a.E, a.per_xcd, per, e, item) : !xcd_affine_item(a.E, a.G, a.ips, per, e, item)) return;
     const int y = item / a.ntiles, row0 = (item - y * a.ntiles) * CH_ROWS, B = a.B;
     const int nst = y ? a.count[1] : a.count[0];
     const bool timed0 = a.tbuf && item == 0 && e == 0 && tid == 0;
@@ -888,9 +971,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void chain_kernel(const C
             const ChainLoad& d = i == 0 ? d0 : i == 1 ? d1 : i == 2 ? d2 : d3;
             const ChainInSrc& r = i == 0 ? r0 : i == 1 ? r1 : i == 2 ? r2 : r3;
             const int done = (i == 0 ? Q0 : i == 1 ? Q1 : Q2) * CH_THREADS;
-            for (int base = done; base < ((d.zero_to - d.dk0 + 15) & ~15) * CH_ROWS; base += Q2 * CH_THREADS) {
-                chain_input_fetch<CH_THREADS>(d, r, base, tid, q3);
-                chain_input_commit<CH_THREADS>(d, r, base, tid, q3, bufs, a.bufsz);
+            // (four elements per thread and round trip: one at a time, the 4-wave flavour took 13 dependent round trips for the context
+            //  encoder's 240-column tile -- 30 k cycles of prologue under load, tools/chain_timing.py)
+            constexpr int QR = 4;
+            ChainIn<QR> qr;
+            for (int base = done; base < ((d.zero_to - d.dk0 + 15) & ~15) * CH_ROWS; base += QR * CH_THREADS) {
+                chain_input_fetch<CH_THREADS>(d, r, base, tid, qr);
+                chain_input_commit<CH_THREADS>(d, r, base, tid, qr, bufs, a.bufsz);
             }
         }
     }
@@ -910,7 +997,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void chain_kernel(const C
         while (cur.si == si) {
             ChainGroup nxt;
             unsigned long long* dbg = timed ? a.tbuf + 64 + si * 4 : nullptr;
-            chain_group<NW>(stg, nst, wave, cur, nxt, ops, bufs, a.bufsz, e, B, row0, lane, dbg);
+            chain_group<NW>(stg, nst, wave, cur, nxt, ops, bufs, a.bufsz, e, B, row0, lane, dbg, timed ? a.tfine + si * 6 : nullptr);
             cur = nxt;
         }
         if (timed) a.tbuf[64 + si * 4 + 3] = __builtin_readcyclecounter();
@@ -953,6 +1040,9 @@ static_assert(sizeof(DwArgs) <= 4096, "kernel argument block");
 #define TK 32
 #define LDA (TM + 4)
 #define LDB (TN + 4)
+#ifndef CADM_DW_EXPERIMENT
+#define CADM_DW_EXPERIMENT 0
+#endif
 #define DW_NSLAB 1                   // slabs per K panel in flight (registers): one keeps the kernel at 120 VGPRs = 4 workgroups per CU
 
 // One 48 x 64 tile of one job per workgroup, reduction over the batch: the whole step's ~925 tiles then fit the chip's
@@ -961,7 +1051,8 @@ static_assert(sizeof(DwArgs) <= 4096, "kernel argument block");
 // panel depth here: 2-slab panels (156 VGPRs, 3 per CU) and register double-buffering (178 VGPRs) both measured slower.
 __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     constexpr int LDK = TK + 4;                          // fast path: slabs stored [feature][k]
-    constexpr int DW_SMEM = DW_NSLAB * TK * (LDA + LDB) > (TM + TN) * LDK ? DW_NSLAB * TK * (LDA + LDB) : (TM + TN) * LDK;
+    constexpr int DW_SLAB = (TM + TN) * LDK;             // ... in TWO buffers, so that a slab costs one barrier (see the slab loop)
+    constexpr int DW_SMEM = DW_NSLAB * TK * (LDA + LDB) > 2 * DW_SLAB ? DW_NSLAB * TK * (LDA + LDB) : 2 * DW_SLAB;
     __shared__ __attribute__((aligned(16))) float dw_smem[DW_SMEM];
     float* const As = dw_smem;
     float* const Bs = dw_smem + DW_NSLAB * TK * LDA;
@@ -1085,21 +1176,29 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
             if (two) { d.c0 = pB0[d2 / 4]; d.c1 = pB1[d2 / 4]; }     // (used at the stash only: the branch costs no wait)
             pA0 += sA; pA1 += sA; pB0 += sB; pB1 += sB;
         };
-        auto slab = [&](Slab& d, int k0) {
-            if (k0 > 0) __syncthreads();
+        // One barrier per slab: slab s is stashed into buffer s & 1 while the slower waves may still be reading slab s - 1 out of the other
+        // one; the stores of slab s + 1 (same buffer as s - 1) come behind the barrier of slab s, which every wave passes only after its
+        // reads of slab s - 1.  (Single-buffered until round 5: two barriers per 24 MFMAs.)
+        auto slab = [&](Slab& d, int k0, int par) {
+            const int bo = par * DW_SLAB;
+#if CADM_DW_EXPERIMENT == 3      // (timing experiments, tools/build_variant.sh: what a part of the slab loop costs -- results are wrong)
+            if (k0 < 2 * TK)
+#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                wA0[j * LDK] = d.a0[j];
-                if (a1) wA1[j * LDK] = d.a1[j];
-                wB0[j * LDK] = two ? d.b0[j] + d.c0[j] : d.b0[j];
-                wB1[j * LDK] = two ? d.b1[j] + d.c1[j] : d.b1[j];
+                wA0[bo + j * LDK] = d.a0[j];
+                if (a1) wA1[bo + j * LDK] = d.a1[j];
+                wB0[bo + j * LDK] = two ? d.b0[j] + d.c0[j] : d.b0[j];
+                wB1[bo + j * LDK] = two ? d.b1[j] + d.c1[j] : d.b1[j];
             }
             __syncthreads();
+#if CADM_DW_EXPERIMENT != 2
             if (k0 + 2 * TK < KP) fetch(d);
+#endif
             if (do_colsum) {
 #pragma unroll
                 for (int x = 0; x < TK / 4; ++x) {
-                    const floatx4 v = *reinterpret_cast<const floatx4*>(Bt + tid * LDK + 4 * (x ^ ((tid >> 2) & 7)));
+                    const floatx4 v = *reinterpret_cast<const floatx4*>(Bt + bo + tid * LDK + 4 * (x ^ ((tid >> 2) & 7)));
                     colsum += v[0]; colsum += v[1]; colsum += v[2]; colsum += v[3];
                 }
             }
@@ -1107,14 +1206,18 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
                 const int fb = 16 * wn + c;
 #pragma unroll
                 for (int g = 0; g < TK / 16; ++g) {
-                    const floatx4 b4 = *reinterpret_cast<const floatx4*>(Bt + fb * LDK + 4 * ((4 * g + q) ^ ((fb >> 2) & 7)));
+                    const floatx4 b4 = *reinterpret_cast<const floatx4*>(Bt + bo + fb * LDK + 4 * ((4 * g + q) ^ ((fb >> 2) & 7)));
 #pragma unroll
                     for (int i = 0; i < MI; ++i) {
                         if (mb + 16 * i >= M) continue;
                         const int fa = 16 * i + c;
-                        const floatx4 a4 = *reinterpret_cast<const floatx4*>(At + fa * LDK + 4 * ((4 * g + q) ^ ((fa >> 2) & 7)));
+                        const floatx4 a4 = *reinterpret_cast<const floatx4*>(At + bo + fa * LDK + 4 * ((4 * g + q) ^ ((fa >> 2) & 7)));
+#if CADM_DW_EXPERIMENT == 1
+                        acc[i] += a4 * b4;
+#else
 #pragma unroll
                         for (int u = 0; u < 4; ++u) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u], b4[u], acc[i], 0, 0, 0);
+#endif
                     }
                 }
             }
@@ -1122,8 +1225,8 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
         fetch(r[0]);
         if (KP > TK) fetch(r[1]);
         for (int k0 = 0; k0 < KP; k0 += 2 * TK) {
-            slab(r[0], k0);
-            if (k0 + TK < KP) slab(r[1], k0 + TK);
+            slab(r[0], k0, 0);
+            if (k0 + TK < KP) slab(r[1], k0 + TK, 1);
         }
     }
     if (!vec && KP > 0) issue(0);
@@ -1668,6 +1771,24 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
     cur_prog = PROG_BWD_CP; first[PROG_BWD_CP] = (int)prog.size();      // (folded into the dynamics nets' backward chains)
     count[PROG_BWD_CP] = (int)prog.size() - first[PROG_BWD_CP];
     for (int i = 0; i < 5; ++i) CADM_REQUIRE(count[i] <= CH_MAXSTAGE, "training chain too long (more than 20 stages): too many layers");
+    static_assert(CH_MAXSTAGE < 31, "ChainStage::nxt keeps a stage index in 5 bits (31: none)");
+    for (int i = 0; i < 5; ++i)          // where each wave slot goes behind a stage (chain_group looks it up in ONE LDS read instead of walking the table)
+        for (int k = 0; k < count[i]; ++k)
+            for (int w = 0; w < CH_WAVES_MAX; ++w) {
+                unsigned char v = 31;
+                for (int j = k + 1; j < count[i]; ++j)
+                    if (w < prog[first[i] + j].ntp) { v = (unsigned char)(j | (w >= prog[first[i] + j].tp1 ? 0x80 : 0)); break; }
+                prog[first[i] + k].nxt[w] = v;
+            }
+    for (ChainStage& g : prog) {          // packed copies of the fields a lookup needs (fewer registers in flight across an epilogue)
+        CADM_REQUIRE(g.KB < 256 && g.src < 256 && g.tp1 < 256 && g.ntp < 128, "training chain: stage too wide for the packed descriptor");
+        g.pkA = g.KB | g.src << 8 | g.tp1 << 16 | g.ntp << 24;
+        for (ChainSeg& sg : g.seg) {
+            CADM_REQUIRE(sg.nt < (1 << 23) && sg.N < 65536 && sg.ldz < 32768, "training chain: layer too wide for the packed descriptor");
+            sg.pkB = (sg.vec ? 1 : 0) | sg.nt << 8;
+            sg.pkC = sg.N | sg.ldz << 16;
+        }
+    }
 
     const bool same = t->prog_dev && prog.size() == t->prog_host.size() &&
                       memcmp(prog.data(), t->prog_host.data(), prog.size() * sizeof(ChainStage)) == 0;
@@ -1701,7 +1822,8 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s, const Chai
     if (a.ny == 2) { a.npre[1] = t->npre[p1]; for (int i = 0; i < t->npre[p1]; ++i) a.pre[1][i] = t->pre[p1][i]; }
     a.asmp = t->asmp;
     a.B = B; a.bufsz = t->chain_bufsz;
-    a.tbuf = ctx->tbuf ? ctx->tbuf + 256 * (p0 / 2) : nullptr;   // [fwd | bwd | bwd context] x 256 stamps (tools/chain_timing.py)
+    a.tbuf = ctx->tbuf ? ctx->tbuf + 256 * (p0 / 2) : nullptr;   // [fwd | bwd] x 256 stamps (tools/chain_timing.py)
+    a.tfine = ctx->tbuf ? ctx->tbuf + 512 + 128 * (p0 / 2) : nullptr;
     a.E = ctx->E; a.ntiles = (B + CH_ROWS - 1) / CH_ROWS;
     a.G = ctx->E <= 8 ? 8 / ctx->E : 1;
     const int per = a.ntiles * a.ny;
@@ -1727,8 +1849,13 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s, const Chai
         CADM_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = lds;
     }
-    if (wide) hipLaunchKernelGGL(chain_kernel<4>, dim3(8 * a.ips * rounds), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(chain_kernel<8>, dim3(8 * a.ips * rounds), dim3(512), lds, s, a);
+    // member -> XCD affinity while one round of it holds the launch; beyond that every XCD takes a contiguous eighth of the items
+    const int affine_slots = (ctx->n_cus / 8) * (wide ? 3 : 1);        // workgroups an XCD holds at once
+    a.spread = ctx->train_force_spread ? ctx->train_force_spread == 1 : (ctx->E * a.G < 8 && a.ips > affine_slots);
+    a.per_xcd = (int)((items + 7) / 8);
+    const unsigned grid = a.spread ? 8u * (unsigned)a.per_xcd : 8u * (unsigned)(a.ips * rounds);
+    if (wide) hipLaunchKernelGGL(chain_kernel<4>, dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(chain_kernel<8>, dim3(grid), dim3(512), lds, s, a);
     CADM_CHECK_HIP(hipGetLastError());
     return CADM_OK;
 }

@@ -105,7 +105,10 @@ def train_losses(env_name, ff, back, cp, st, batch, cfg):
         x = torch.cat([_norm(batch["cp_obs"], st["cp_obs_mean"], st["cp_obs_std"]),
                        _norm(batch["cp_act"], st["cp_act_mean"], st["cp_act_std"])], -1)
         for i in range(cfg["n_cp_hidden"]):
-            x = torch.relu(torch.matmul(x, cp["cp_hidden_%d_weight" % i]) + cp["cp_hidden_%d_bias" % i])
+            z = torch.matmul(x, cp["cp_hidden_%d_weight" % i]) + cp["cp_hidden_%d_bias" % i]
+            # relu; cfg["cp_relu_threshold"] (tools/fuzz_train.py only, default 0 = the reference's relu) moves the kink by a hair, to tell a
+            # pre-activation that rounds to the other side of 0 in fp32 from a wrong gradient
+            x = torch.where(z > cfg.get("cp_relu_threshold", 0.0), z, torch.zeros_like(z))
         ctx = torch.matmul(x, cp["cp_output_weight"]) + cp["cp_output_bias"]
         feats.append(ctx)
     act = _ACTS[cfg.get("hidden_nonlinearity", "swish")]

@@ -121,12 +121,13 @@ def test_chain_kernel_flavours_agree_bitwise(gpu):
     """Round 5: the chain kernel exists with 8 waves per workgroup (one workgroup per CU: the reference's batch of 256) and with 4 (three
     workgroups per CU: large batches; the launcher picks by the number of work items).  A row's arithmetic -- operand order of every
     MFMA chain, epilogues, the loss phase's reductions -- is the same in both: six training steps from the same state end in bit-identical
-    weights, moments and losses, at a batch size on either side of the switch."""
-    for B in (64, 600):
+    weights, moments and losses, at a batch size on either side of the switch -- and under either mapping of work items to XCDs."""
+    for B in (64, 600, 1100):          # (1100: the launcher's own pick is the 4-wave flavour with the items spread)
         prob = synth.make_problem(env="halfcheetah", context=True, E=5, trained_like=True, with_back=True, seed=29)
         batch = synth.make_train_batch(prob, B=B, seed=5)
         end = {}
-        for fl in (8, 4, 0):
+        # (+ 16: work items spread over all XCDs -- the launcher's mapping once a member's items exceed one round of its XCD --, + 32: member-affine)
+        for fl in (8, 4, 0, 8 + 16, 4 + 16, 4 + 32):
             eng = _dev_engine(prob, 5)
             eng._check(eng.lib.cadm_dev_set_train_flavour(eng._ctx, fl), "cadm_dev_set_train_flavour")
             eng.train_configure(1e-3, WD, CWD, 1.0, 0.5, max_batch=B)
@@ -135,7 +136,7 @@ def test_chain_kernel_flavours_agree_bitwise(gpu):
             ev = eng.train_step(dev, train=False).cpu().numpy()
             end[fl] = (losses, ev, {n: {k: v.cpu().numpy() for k, v in eng.nets[n].items()} for n in eng.net_names()})
             eng.close()
-        for fl in (4, 0):
+        for fl in (4, 0, 8 + 16, 4 + 16, 4 + 32):
             for a, b in zip(end[8][0], end[fl][0]):
                 np.testing.assert_array_equal(a, b)
             np.testing.assert_array_equal(end[8][1], end[fl][1])

@@ -38,6 +38,11 @@ def main():
         print("%-20s total %8.0f ticks | " % (lname, row[n - 1] - row[0]) + " ".join("%5.0f" % x for x in d))
         fine = raw[li, 64:64 + 4 * (n - 1)].reshape(n - 1, 4)
         print("   wave 0 per GEMM stage: k loop / epilogue   " + "  ".join("%d/%d" % (r[1] - r[0], r[2] - r[1]) for r in fine if r[0]))
+        ep = raw[2, 128 * li:128 * li + 6 * (n - 1)].reshape(n - 1, 6)
+        print("   its epilogue: act math (+ z stores) | LDS tile (+ next-group request) | h stores | next group + operands | - | ring prologue")
+        for r, f in zip(fine, ep):
+            if r[0]:
+                print("      %5d %5d %5d %5d %5d %5d" % (f[0] - r[1], f[1] - f[0], f[2] - f[1], f[3] - f[2], f[4] - f[3], r[2] - f[4]))
     dw_report(tbuf)
 
 

@@ -7,7 +7,8 @@ probabilistic, ensemble size, ragged batch size, hidden width incl. widths the p
 checks (i) the forward losses [mse, back_mse, recon] against the fp64 oracle, (ii) every gradient tensor of the hand-written
 backward pass -- read back directly (Adam's first moment after one step with beta1 = 0, developer library) -- element by
 element against torch.autograd on the oracle (<= 1e-5 of the tensor's max), and that variables without a gradient do not move.
-Hidden widths are drawn per layer now and then (zero-padded in the engine).  Same bars as tests/test_gpu_train.py."""
+Hidden widths are drawn per layer now and then (zero-padded in the engine).  The chain kernel's flavour (8 or 4 waves per workgroup) is forced at random in the gradient leg.  Same bars as
+tests/test_gpu_train.py."""
 import os
 import sys
 import time
@@ -28,7 +29,7 @@ WD = (0.000025, 0.00005, 0.000075, 0.000075, 0.0001)
 def main():
     t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 60.0)
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    rounds, worst_l, worst_g = 0, 0.0, 0.0
+    rounds, worst_l, worst_g, kinks = 0, 0.0, 0.0, 0
     while time.time() < t_end:
         env = ENVS[rng.integers(len(ENVS))]
         context = bool(rng.integers(2))
@@ -67,27 +68,49 @@ def main():
         # (ii) gradients, read back directly
         eng = synth.make_engine(prob, p=E, deterministic=det, lib=_lib.load_dev())
         eng.train_configure(1e-3, WD, cwd, 1.0, cfg["back_coeff"], max_batch=B, beta1=0.0)
+        flavour = int(rng.choice([0, 4, 8]))           # 0 = the launcher's pick; 4 / 8 waves per workgroup forced (round 5)
+        eng._check(eng.lib.cadm_dev_set_train_flavour(eng._ctx, flavour), "cadm_dev_set_train_flavour")
+        tag += " flavour=%d" % flavour
         before = {n: {k: v.clone() for k, v in eng.nets[n].items()} for n in eng.net_names()}
         eng.train_step({k: eng._t(batch[k]) for k in keys}, train=True)
-        ff, back, cp = nets64(True)
-        out = otrain.train_losses(env, ff, back, cp, st, tb, cfg)
-        grads = otrain.grads_of(out["loss"], {"ff_model": ff, "backward_model": back, "context_model": cp})
-        for net in eng.net_names():
-            true = eng.param_shapes_true(net)
-            for name, w0 in before[net].items():
-                g_ref = grads[net][name]
-                if g_ref is None:
-                    assert torch.equal(w0, eng.nets[net][name]), "%s: %s/%s moved although it has no gradient" % (tag, net, name)
-                    continue
-                g_hip = eng.dev_read_adam_moment(net, name).cpu().numpy().astype(np.float64)[tuple(slice(0, k) for k in true[name])]
-                g_ref = g_ref.numpy()
-                err = float(np.abs(g_hip - g_ref).max() / max(np.abs(g_ref).max(), 1e-300))
-                assert err <= 1e-5, "%s: %s/%s gradient off: %.3e of the tensor's max" % (tag, net, name, err)
-                worst_g = max(worst_g, err)
+        def off_tensors(thr):
+            """[(net, name, err)] of the gradient tensors further than 1e-5 of their max from fp64 autograd (context relu kink at thr)"""
+            ff, back, cp = nets64(True)
+            out = otrain.train_losses(env, ff, back, cp, st, tb, dict(cfg, cp_relu_threshold=thr))
+            grads = otrain.grads_of(out["loss"], {"ff_model": ff, "backward_model": back, "context_model": cp})
+            bad, worst = [], 0.0
+            for net in eng.net_names():
+                true = eng.param_shapes_true(net)
+                for name, w0 in before[net].items():
+                    g_ref = grads[net][name]
+                    if g_ref is None:
+                        assert torch.equal(w0, eng.nets[net][name]), "%s: %s/%s moved although it has no gradient" % (tag, net, name)
+                        continue
+                    g_hip = eng.dev_read_adam_moment(net, name).cpu().numpy().astype(np.float64)[tuple(slice(0, k) for k in true[name])]
+                    g_ref = g_ref.numpy()
+                    err = float(np.abs(g_hip - g_ref).max() / max(np.abs(g_ref).max(), 1e-300))
+                    if err > 1e-5:
+                        bad.append((net, name, err))
+                    else:
+                        worst = max(worst, err)
+            return bad, worst
+        bad, w = off_tensors(0.0)
+        if bad and context and all(net == "context_model" for net, _, _ in bad):
+            # A context-encoder pre-activation within fp32 roundoff of 0: the fp32 forward pass and the fp64 oracle put that relu unit on
+            # different sides of its kink, and one batch row's contribution to the gradient differs (seen once in ~300 configurations).
+            # Accepted only if the gradient matches the oracle with the kink moved by 1e-6 to one side or the other.
+            for thr in (1e-6, -1e-6):
+                bad2, w2 = off_tensors(thr)
+                if not bad2:
+                    print("relu kink: %s -- %s off by %.1e against relu'(0 +- roundoff), exact with the kink at %g" % (tag, bad[0][1], bad[0][2], thr), flush=True)
+                    bad, w, kinks = [], w2, kinks + 1
+                    break
+        assert not bad, "%s: gradient off: %s" % (tag, ", ".join("%s/%s %.3e of the tensor's max" % b for b in bad))
+        worst_g = max(worst_g, w)
         eng.close()
         rounds += 1
-    print("train fuzz OK: %d random configurations; worst loss deviation %.2e, worst gradient deviation %.2e of the tensor's scale"
-          % (rounds, worst_l, worst_g))
+    print("train fuzz OK: %d random configurations (%d with a context relu unit on its kink, see above); worst loss deviation %.2e, worst gradient "
+          "deviation %.2e of the tensor's scale" % (rounds, kinks, worst_l, worst_g))
 
 
 if __name__ == "__main__":

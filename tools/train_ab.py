@@ -9,9 +9,11 @@ import torch
 from cadm_amd import _lib, synth
 lib = _lib.load_dev(os.path.join(ROOT, "cadm_amd", sys.argv[1])) if len(sys.argv) > 1 else _lib.load_dev()
 WD, CWD = (0.000025, 0.00005, 0.000075, 0.000075, 0.0001), (0.000025, 0.00005, 0.000075)
-for B in (256, 512, 1024, 4096):
+BS = [int(x) for x in os.environ.get("TRAIN_AB_B", "256,512,1024,4096").split(",")]
+FLS = [int(x) for x in os.environ.get("TRAIN_AB_FL", "8,4,0").split(",")]       # + 16: work items spread over all XCDs, + 32: member-affine
+for B in BS:
     prob = synth.make_problem(env="halfcheetah", context=True, E=5, with_back=True, seed=0)
-    for fl in (8, 4, 0):
+    for fl in FLS:
         eng = synth.make_engine(prob, p=20, lib=lib)
         eng._check(lib.cadm_dev_set_train_flavour(eng._ctx, fl), "flavour")
         eng.train_configure(1e-3, WD, CWD, 1.0, 0.5, max_batch=B)
