@@ -186,7 +186,6 @@ __device__ __forceinline__ gptr as_global(float* p) { return (gptr)p; }
 //           chain's epilogue / barrier / stage start (36 % of a stage, chain_timing) runs beside the others' MFMAs.  The throughput
 //           flavour, for launches of more work items than CUs: B = 4096 1.633 -> 1.200 ms per step (0.177 -> 0.241 of the fp32
 //           matrix peak), B = 1024 0.410 -> 0.340; at B = 256 it would be 0.144 instead of 0.120 ms (profiles/r5_train_scaling.md).
-//           With the work items spread over all eight XCDs (xcd_spread_item) B = 4096 0.88 ms (0.328).
 #define CH_WAVES_MAX 8
 #define CH_THREADS_MAX (64 * CH_WAVES_MAX)
 #define CH_RING 8             // operand blocks (16 k x 2 tiles) of a wave's ring; CH_RING - 1 are in flight

@@ -1,8 +1,9 @@
 mkdir -p gpurun_out/r5_final
+python -m pytest tests -q -m gpu > gpurun_out/r5_final/gpu_suite.txt 2>&1
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r5_final/bench.json 2> gpurun_out/r5_final/bench.err
 timeout 400 python tools/fuzz_train.py 150 51 > gpurun_out/r5_final/fuzz_train.txt 2>&1
 timeout 400 python tools/fuzz_rollout.py 200 77 > gpurun_out/r5_final/fuzz_rollout.txt 2>&1
 timeout 300 python tools/soak.py 60 > gpurun_out/r5_final/soak.txt 2>&1
 timeout 300 python tools/soak.py 40 2000 > gpurun_out/r5_final/soak2000.txt 2>&1
 python tools/train_scaling.py > gpurun_out/r5_final/train_scaling.txt 2>&1
-tail -3 gpurun_out/r5_final/*.txt; head -c 600 gpurun_out/r5_final/bench.json
+for f in gpurun_out/r5_final/*.txt; do echo "== $f"; tail -n 3 $f; done; head -c 600 gpurun_out/r5_final/bench.json
