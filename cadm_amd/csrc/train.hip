@@ -179,6 +179,18 @@ typedef __attribute__((address_space(1))) float* gptr;
 __device__ __forceinline__ gcptr as_global(const float* p) { return (gcptr)p; }
 __device__ __forceinline__ gptr as_global(float* p) { return (gptr)p; }
 #define CH_ROWS 16
+#ifndef CADM_Q0_8
+#define CADM_Q0_8 8
+#endif
+#ifndef CADM_Q0_4
+#define CADM_Q0_4 12
+#endif
+#ifndef CADM_Q1_4
+#define CADM_Q1_4 4
+#endif
+#ifndef CADM_Q2_4
+#define CADM_Q2_4 2
+#endif
 // Two flavours of the chain kernel (template parameter NW = waves per workgroup), chosen per launch by the number of work items:
 //   NW = 8  ONE workgroup per CU, two waves per SIMD: one wave's LDS / load / scalar work overlaps the other's MFMAs.  The latency
 //           flavour: a step at the reference's batch size (256 rows x 5 members x 2 nets = 160 work items) is one partial round of the chip.
@@ -186,6 +198,7 @@ __device__ __forceinline__ gptr as_global(float* p) { return (gptr)p; }
 //           chain's epilogue / barrier / stage start (36 % of a stage, chain_timing) runs beside the others' MFMAs.  The throughput
 //           flavour, for launches of more work items than CUs: B = 4096 1.633 -> 1.200 ms per step (0.177 -> 0.241 of the fp32
 //           matrix peak), B = 1024 0.410 -> 0.340; at B = 256 it would be 0.144 instead of 0.120 ms (profiles/r5_train_scaling.md).
+//           With the work items spread over all eight XCDs (xcd_spread_item: the member-affine mapping left three idle) 0.88 ms = 0.328.
 #define CH_WAVES_MAX 8
 #define CH_THREADS_MAX (64 * CH_WAVES_MAX)
 #define CH_RING 8             // operand blocks (16 k x 2 tiles) of a wave's ring; CH_RING - 1 are in flight
@@ -646,7 +659,8 @@ __device__ __forceinline__ void chain_group(const ChainStage* stg, int nst, int 
 // per operand (the assembled inputs are two tiles each: observation columns, action columns), so an element's addresses are
 // base + column: nothing for hipcc to branch on between the loads.
 template <int NU>
-struct ChainIn { float x[NU], a[NU], b[NU]; };
+struct ChainIn { float x[NU], a[NU]; };      // (the third operand -- the std of an assembled column -- is fetched at commit time: an L2 hit by then,
+                                             //  and a third fewer registers per element in flight across the one HBM round trip)
 struct ChainInSrc {
     gcptr x0, a0, b0;
     int hc;                   // half-cheetah obs_preproc (columns 0..2 <- o[1], sin o[2], cos o[2])
@@ -690,7 +704,6 @@ __device__ __forceinline__ void chain_input_fetch(const ChainLoad& d, const Chai
         const int jx = r.hc ? (j == 0 ? 1 : j <= 2 ? 2 : j) : j + r.shift;     // preproc_at's source column
         q.x[u] = r.x0[jx];
         q.a[u] = r.a0[j];
-        q.b[u] = r.b0[j];
     }
 }
 template <int NT, int NU>
@@ -698,6 +711,15 @@ __device__ __forceinline__ void chain_input_commit(const ChainLoad& d, const Cha
                                                    float* bufs, int bufsz) {
     float* dst = bufs + d.dst * bufsz;
     const int m = (tid >> 4) & 15;
+    float sd[NU];
+    if (d.mode != 0) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int idx = base + u * NT + tid;
+            const int k = (idx >> 8) * 16 + (idx & 15);
+            sd[u] = r.b0[k < d.K ? k : 0];
+        }
+    }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int idx = base + u * NT + tid;
@@ -712,7 +734,7 @@ __device__ __forceinline__ void chain_input_commit(const ChainLoad& d, const Cha
                 if (k == 1) t = sinf(t);
                 else if (k == 2) t = cosf(t);
             }
-            x = (t - q.a[u]) / (q.b[u] + 1e-10f);
+            x = (t - q.a[u]) / (sd[u] + 1e-10f);
         }
         x = ok ? x : 0.0f;
         if (d.dk0 + k < d.zero_to) dst[lds_at(d.dk0 + k, m)] = x;
@@ -949,9 +971,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void chain_kernel(const C
         const int np = y ? a.npre[1] : a.npre[0];
         const ChainLoad d0 = y ? a.pre[1][0] : a.pre[0][0], d1 = y ? a.pre[1][1] : a.pre[0][1], d2 = y ? a.pre[1][2] : a.pre[0][2],
                         d3 = y ? a.pre[1][3] : a.pre[0][3];
-        // elements per thread requested in one go: 6 / 4 / 2 / 2 (96 / 64 / 32 / 32 columns; wider tiles loop).  Deeper would
-        // push the prologue past 128 VGPRs: hipcc then parks values in AGPRs -- the ring's (tests/test_isa_hygiene.py).
-        constexpr int Q0 = NW == 8 ? 6 : 2, Q1 = NW == 8 ? 4 : 2, Q2 = NW == 8 ? 2 : 1;      // (4-wave flavour: 84 VGPRs -- fewer in flight)
+        // elements per thread requested in one go -- two registers each: value and mean (or second summand); the std follows at commit
+        // time --: 8 / 4 / 2 / 2 (8 waves: 128 / 64 / 32 / 32 columns) and 12 / 4 / 2 / 2 (4 waves: 192 / 64 / 32 / 32): the reference's
+        // input tiles (180 + 60 history columns, 20 + 6) in ONE round trip to HBM; wider tiles loop.  The 4-wave flavour's 84 VGPRs do not
+        // hold that: hipcc parks values in AGPRs here -- harmless in front of the first ring load, and only there
+        // (tests/test_isa_hygiene.py checks from the first ring load on).
+        constexpr int Q0 = NW == 8 ? CADM_Q0_8 : CADM_Q0_4, Q1 = NW == 8 ? 4 : CADM_Q1_4, Q2 = NW == 8 ? 2 : CADM_Q2_4;
         ChainIn<Q0> q0;
         ChainIn<Q1> q1;
         ChainIn<Q2> q2, q3;

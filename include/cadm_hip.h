@@ -292,7 +292,12 @@ int cadm_build_windows(const void* obs, const void* act, const void* cp_obs, con
  *   cadm_dist_unique_id  rank 0: fill a 128-byte ncclUniqueId, to be broadcast by the host to every rank
  *   cadm_dist_init       every rank: ncclCommInitRank on the ctx's device
  * Once initialised, cadm_cem_plan / cadm_rs_plan take n = GLOBAL candidate count (divisible by nranks),
- * roll out candidates [rank*n/G, (rank+1)*n/G) and return the identical plan on every rank. */
+ * roll out candidates [rank*n/G, (rank+1)*n/G) and return the identical plan on every rank.
+ * cadm_cem_plan: a rank draws only its own candidates (cadm_sample_actions_shard; the draws are keyed by the global
+ * element index) and the refit regenerates the elite sequences (cadm_cem_refit_regen) instead of reading them.  Every
+ * rank's payload carries one more float: a checksum word of its replicated inputs (obs, cp_obs, cp_act, mean, var).
+ * The refit compares the ranks' words; on a mismatch -- the ranks were fed different inputs -- the plan is NaN on EVERY
+ * rank (the call still returns CADM_OK: check the plan; the Python class raises RuntimeError). */
 int cadm_dist_unique_id(char out_id[128]);
 int cadm_dist_init(cadm_ctx* ctx, const char id[128], int nranks, int rank);
 int cadm_dist_destroy(cadm_ctx* ctx);
