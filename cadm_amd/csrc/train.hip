@@ -251,6 +251,8 @@ struct ChainArgs {
     int B, bufsz;                                        // rows per member, floats per LDS activation buffer
     int E, ny, ntiles, G, ips;                           // work decomposition, see chain_kernel
     int spread, per_xcd;                                 // spread: XCD x takes the x-th contiguous eighth of the (member-major) work items
+    int y_base, slot_ny;                                 // loss phase: this launch's chain y counts as y + y_base of slot_ny (a forward pass split
+                                                         //  into one launch per net, launch_forward: same terms, same partial-sum slots as the joint launch)
     unsigned long long* tfine;                           // (same item) wave 0's epilogue, per GEMM stage: [6 si ..] activation math done, LDS tile
                                                          // stored, global stores issued, next group looked up, its operands requested
     unsigned long long* tbuf;                            // cadm_dev_set_timing_buffer: clocks of member 0's first work item:
@@ -885,7 +887,7 @@ __device__ __forceinline__ void chain_loss_phase(const ChainArgs& a, float* bufs
     }
     __syncthreads();
     const int NQ = 4 + 2 * D;
-    const int slot = (e * a.ny + y) * a.ntiles + row0 / CH_ROWS;
+    const int slot = (e * a.slot_ny + y) * a.ntiles + row0 / CH_ROWS;      // (y: the caller passes y + y_base)
     float* part = r.part + (size_t)slot * NQ;
     if (wave < 4) {                                                // scalar terms: wave q sums scr[q][*]
         float v = 0.0f;
@@ -1012,7 +1014,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void chain_kernel(const C
     __syncthreads();
     const bool timed = a.tbuf && item == 0 && e == 0 && tid == 0;
     if (timed) a.tbuf[0] = __builtin_readcyclecounter();
-    const float tgt0 = a.loss_on ? chain_loss_target(a.lossp, e, y, row0, tid) : 0.0f;
+    const float tgt0 = a.loss_on ? chain_loss_target(a.lossp, e, y + a.y_base, row0, tid) : 0.0f;
     ChainOps ops;
     ChainGroup cur = next_group<NW>(stg, nst, -1, 0, wave, e);
     load_ops(stg, cur, e, B, row0, lane, ops);
@@ -1030,7 +1032,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void chain_kernel(const C
     }
     // (the loss terms' scratch: an activation buffer the chain is done with -- the head outputs sit in loss_buf, the other two are dead;
     //  a region of its own behind the buffers cost the third workgroup per CU its LDS)
-    if (a.loss_on) chain_loss_phase<NW>(a, bufs, bufs + ((a.loss_buf + 1) % 3) * a.bufsz, e, y, row0, tid, tgt0);
+    if (a.loss_on) chain_loss_phase<NW>(a, bufs, bufs + ((a.loss_buf + 1) % 3) * a.bufsz, e, y + a.y_base, row0, tid, tgt0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1646,7 +1648,7 @@ extern "C" int cadm_train_reset(cadm_ctx* ctx, void* stream) {
 
 namespace {
 
-enum { PROG_FWD_FF = 0, PROG_FWD_BK = 1, PROG_BWD_FF = 2, PROG_BWD_BK = 3, PROG_BWD_CP = 4 };
+enum { PROG_FWD_FF = 0, PROG_FWD_BK = 1, PROG_BWD_FF = 2, PROG_BWD_BK = 3, PROG_FWD_BK_NOCP = 4 };     // (NOCP: context columns read back, see fwd_prog)
 
 ChainLoad input_tile(const float* g0, const float* g1, float* gsum, int ld_in, int ldg, int K, int dst, int dk0, int zero_to, int mode = 0) {
     ChainLoad d{};
@@ -1698,10 +1700,17 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
         t->pre[cur_prog][t->npre[cur_prog]++] = d;
     };
 
+    // ctx_from: the context vector is not computed by this chain but read back from the forward net's input echo (its context columns,
+    // written by the forward net's launch in front of this one): large batches, launch_forward
     auto fwd_prog = [&](const std::vector<DenseRef>& net, const std::vector<PackDst>& pf, const std::vector<int>& pt, float* X,
-                        NetBufs& nb, bool store_cp, bool want_lv) {
+                        NetBufs& nb, bool store_cp, bool want_lv, const float* ctx_from = nullptr) {
         int cur;
-        if (has_cp) {
+        if (has_cp && ctx_from) {      // (buffer 2, as the chain with the encoder in front: the same walk through the buffers, the same loss_buf)
+            input(input_tile(nullptr, nullptr, X, 0, t->K0p, ctx->P, 2, 0, ctx->P, 1));
+            input(input_tile(nullptr, nullptr, X + ctx->P, 0, t->K0p, ctx->A, 2, ctx->P, PA, 2));
+            input(input_tile(ctx_from, nullptr, X + PA, t->K0p, t->K0p, C, 2, PA, 16 * kblocks(K0)));
+            cur = 2;
+        } else if (has_cp) {
             // both inputs at once: the context encoder's history in buffer 0, this net's (obs, act) columns in buffer 2,
             // where the encoder's last stage drops the context vector behind them
             // (assembled from the raw batch on the way in; the forward net's workgroups also leave the normalised copies that
@@ -1792,8 +1801,9 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
     cur_prog = PROG_FWD_BK; first[PROG_FWD_BK] = (int)prog.size(); if (has_back) fwd_prog(ctx->back, t->pf_bk, t->pt_bk, t->Xbk, t->bk, false, false); count[PROG_FWD_BK] = (int)prog.size() - first[PROG_FWD_BK];
     cur_prog = PROG_BWD_FF; first[PROG_BWD_FF] = (int)prog.size(); bwd_prog(ctx->ff, t->pb_ff, t->ptb_ff, t->ff, t->dMu, det ? nullptr : t->dLv, t->cp.dz); count[PROG_BWD_FF] = (int)prog.size() - first[PROG_BWD_FF];
     cur_prog = PROG_BWD_BK; first[PROG_BWD_BK] = (int)prog.size(); if (has_back) bwd_prog(ctx->back, t->pb_bk, t->ptb_bk, t->bk, t->dBmu, nullptr, t->cp_dz_bk); count[PROG_BWD_BK] = (int)prog.size() - first[PROG_BWD_BK];
-    cur_prog = PROG_BWD_CP; first[PROG_BWD_CP] = (int)prog.size();      // (folded into the dynamics nets' backward chains)
-    count[PROG_BWD_CP] = (int)prog.size() - first[PROG_BWD_CP];
+    cur_prog = PROG_FWD_BK_NOCP; first[PROG_FWD_BK_NOCP] = (int)prog.size();
+    if (has_back && has_cp) fwd_prog(ctx->back, t->pf_bk, t->pt_bk, t->Xbk, t->bk, false, false, t->Xff + PA);
+    count[PROG_FWD_BK_NOCP] = (int)prog.size() - first[PROG_FWD_BK_NOCP];
     for (int i = 0; i < 5; ++i) CADM_REQUIRE(count[i] <= CH_MAXSTAGE, "training chain too long (more than 20 stages): too many layers");
     static_assert(CH_MAXSTAGE < 31, "ChainStage::nxt keeps a stage index in 5 bits (31: none)");
     for (int i = 0; i < 5; ++i)          // where each wave slot goes behind a stage (chain_group looks it up in ONE LDS read instead of walking the table)
@@ -1834,7 +1844,7 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
 
 struct ChainLossCfg { LossP lp; ReduceP rp; int final; };
 
-int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s, const ChainLossCfg* loss = nullptr) {
+int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s, const ChainLossCfg* loss = nullptr, int y_base = 0, int slot_ny = 0) {
     TrainState* t = ctx->train;
     ChainArgs a{};
     a.prog = t->prog_dev;
@@ -1848,14 +1858,16 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s, const Chai
     a.B = B; a.bufsz = t->chain_bufsz;
     a.tbuf = ctx->tbuf ? ctx->tbuf + 256 * (p0 / 2) : nullptr;   // [fwd | bwd] x 256 stamps (tools/chain_timing.py)
     a.tfine = ctx->tbuf ? ctx->tbuf + 512 + 128 * (p0 / 2) : nullptr;
+    if (p0 == PROG_FWD_BK_NOCP) a.tbuf = a.tfine = nullptr;      // (the second launch of a split forward pass is not clocked)
     a.E = ctx->E; a.ntiles = (B + CH_ROWS - 1) / CH_ROWS;
+    a.y_base = y_base; a.slot_ny = slot_ny ? slot_ny : a.ny;
     a.G = ctx->E <= 8 ? 8 / ctx->E : 1;
     const int per = a.ntiles * a.ny;
     a.ips = (per + a.G - 1) / a.G;
     const int rounds = (ctx->E + 7) / 8;
     const size_t lds = CH_MAXSTAGE * sizeof(ChainStage) + 3 * (size_t)t->chain_bufsz * sizeof(float);
     if (loss) {     // closing loss phase: 6 term arrays of the workgroup's 16 x D elements + a flag, in an activation buffer the chain is done with
-        a.loss_on = 1; a.loss_final = loss->final; a.loss_buf = t->loss_buf; a.loss_lv0 = t->loss_lv0; a.loss_slots = ctx->E * a.ny * a.ntiles;
+        a.loss_on = 1; a.loss_final = loss->final; a.loss_buf = t->loss_buf; a.loss_lv0 = t->loss_lv0; a.loss_slots = ctx->E * a.slot_ny * a.ntiles;
         a.lossp = loss->lp; a.lossr = loss->rp;
         const size_t terms = 6 * (size_t)CH_ROWS * ctx->D;          // (the final reduction reuses it for up to 512 chunk sums)
         CADM_REQUIRE(((terms > CH_THREADS_MAX ? terms : CH_THREADS_MAX) + 4) * sizeof(float) <= (size_t)t->chain_bufsz * sizeof(float),
@@ -1904,7 +1916,17 @@ int forward_nets(cadm_ctx* ctx, const RowMap& map, const float* obs, const float
     ap.env = ctx->cfg.env_kind;
     for (int i = 0; i < t->npre[PROG_FWD_FF]; ++i) if (t->pre[PROG_FWD_FF][i].mode == 1) t->pre[PROG_FWD_FF][i].g0 = obs;
     for (int i = 0; i < t->npre[PROG_FWD_BK]; ++i) if (t->pre[PROG_FWD_BK][i].mode == 1) t->pre[PROG_FWD_BK][i].g0 = obs_next;
-    return launch_chain(ctx, B, PROG_FWD_FF, has_back ? PROG_FWD_BK : -1, s, loss);
+    for (int i = 0; i < t->npre[PROG_FWD_BK_NOCP]; ++i) if (t->pre[PROG_FWD_BK_NOCP][i].mode == 1) t->pre[PROG_FWD_BK_NOCP][i].g0 = obs_next;
+    // Large batches: one launch per net, the backward model's behind the forward net's -- its chains then READ the context vector the
+    // forward net's chains have left in their input echo instead of running the context encoder a second time on the same histories
+    // (4 of a chain's 9 stages; in the joint launch -- the reference's batch: one partial round of the chip -- the two chains of a
+    // row tile run side by side and the recomputation costs nothing).  Same arithmetic, same loss partials in the same slots.
+    const long items = (long)ctx->E * 2 * ((B + CH_ROWS - 1) / CH_ROWS);
+    const bool split = has_back && ctx->C > 0 && t->prog_count[PROG_FWD_BK_NOCP] > 0 &&
+                       (ctx->train_force_spread ? ctx->train_force_spread == 1 : 2 * items >= 9L * ctx->n_cus);      // (>= 1.5 rounds of three workgroups per CU: B = 2048 0.4485 -> 0.4445 ms, B = 1024 0.249 -> 0.280)
+    if (!split) return launch_chain(ctx, B, PROG_FWD_FF, has_back ? PROG_FWD_BK : -1, s, loss);
+    if ((rc = launch_chain(ctx, B, PROG_FWD_FF, -1, s, loss, 0, 2))) return rc;
+    return launch_chain(ctx, B, PROG_FWD_BK_NOCP, -1, s, loss, 1, 2);
 }
 
 __global__ void clamp_logvar_kernel(const float* lv, const float* maxlv, const float* minlv, float* out, long n, int D) {

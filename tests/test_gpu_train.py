@@ -126,7 +126,8 @@ def test_chain_kernel_flavours_agree_bitwise(gpu):
         prob = synth.make_problem(env="halfcheetah", context=True, E=5, trained_like=True, with_back=True, seed=29)
         batch = synth.make_train_batch(prob, B=B, seed=5)
         end = {}
-        # (+ 16: work items spread over all XCDs -- the launcher's mapping once a member's items exceed one round of its XCD --, + 32: member-affine)
+        # (+ 16: the large-batch path -- work items spread over all XCDs, the launcher's mapping once a member's items exceed one round of its XCD,
+        #  and one forward launch per net, the backward model's reading the context vector back instead of recomputing it --, + 32: member-affine, joint)
         for fl in (8, 4, 0, 8 + 16, 4 + 16, 4 + 32):
             eng = _dev_engine(prob, 5)
             eng._check(eng.lib.cadm_dev_set_train_flavour(eng._ctx, fl), "cadm_dev_set_train_flavour")
