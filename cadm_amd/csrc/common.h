@@ -134,6 +134,7 @@ struct cadm_ctx {
     size_t chain_attr_lds4 = 0;     // (its 4-wave throughput flavour)
     int train_force_nw = 0;         // developer library only: 4 / 8 = force that flavour of the chain kernel (0: by work items)
     int train_force_spread = 0;     // developer library only: 1 / 2 = force the chain kernel's work items spread over all XCDs / member-affine
+    int train_force_merge = 0;      // developer library only: 1 / 2 = force / forbid the one-pass context backward of large batches
     NormStats st;
     TrainState* train = nullptr;
     // scratch for the context encoder

@@ -32,7 +32,7 @@ int cadm_dev_input_checksum(cadm_ctx* ctx, const float* obs, const float* cp_obs
                             int m, float* word_out, void* stream);
 /* waves per workgroup of the training chain kernel: 8 (latency flavour) / 4 (throughput flavour: three workgroups per CU) / 0 = by the
  * launch's number of work items (the product's rule) */
-int cadm_dev_set_train_flavour(cadm_ctx* ctx, int flavour);   /* 0 / 4 / 8 waves (+ 16: items spread over all XCDs, + 32: member-affine) */
+int cadm_dev_set_train_flavour(cadm_ctx* ctx, int flavour);   /* 0 / 4 / 8 waves (+ 16: large-batch forward path, + 32: member-affine joint launch; + 64 / + 128: one-pass context backward on / off) */
 int cadm_dev_read_adam_moment(cadm_ctx* ctx, int net, int layer, int is_bias, int second, float* dst, long n_floats, void* stream);
 #ifdef __cplusplus
 }

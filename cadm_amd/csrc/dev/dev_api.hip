@@ -109,10 +109,13 @@ extern "C" int cadm_dev_input_checksum(cadm_ctx* ctx, const float* obs, const fl
 }
 
 extern "C" int cadm_dev_set_train_flavour(cadm_ctx* ctx, int flavour) {
-    const int waves = flavour & 15, map = flavour >> 4;          // + 16: work items spread over all XCDs, + 32: member-affine (0: the launcher's rule)
-    CADM_REQUIRE(ctx && (waves == 0 || waves == 4 || waves == 8) && map >= 0 && map <= 2,
-                 "cadm_dev_set_train_flavour: 0, 4 or 8 waves (+ 16 / + 32 to force the XCD mapping)");
+    // + 16: large-batch forward path (work items spread over all XCDs, one launch per net), + 32: member-affine, joint launch;
+    // + 64: one-pass context backward, + 128: one pass per dynamics net (0: the launcher's rules)
+    const int waves = flavour & 15, map = (flavour >> 4) & 3, merge = (flavour >> 6) & 3;
+    CADM_REQUIRE(ctx && flavour >= 0 && flavour < 256 && (waves == 0 || waves == 4 || waves == 8) && map <= 2 && merge <= 2,
+                 "cadm_dev_set_train_flavour: 0, 4 or 8 waves (+ 16 / + 32: forward path, + 64 / + 128: context backward)");
     ctx->train_force_nw = waves;
     ctx->train_force_spread = map;
+    ctx->train_force_merge = merge;
     return CADM_OK;
 }

@@ -1411,8 +1411,8 @@ struct TrainState {
     // chain programs: [fwd ff | fwd back | bwd ff | bwd back | bwd context]
     std::vector<ChainStage> prog_host;
     ChainStage* prog_dev = nullptr;
-    int prog_first[5] = {0, 0, 0, 0, 0}, prog_count[5] = {0, 0, 0, 0, 0};
-    ChainLoad pre[5][4]; int npre[5] = {0, 0, 0, 0, 0};         // the programs' input tiles (kernel arguments of the launch)
+    int prog_first[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prog_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    ChainLoad pre[8][4]; int npre[8] = {0, 0, 0, 0, 0, 0, 0, 0};         // the programs' input tiles (kernel arguments of the launch)
     ChainAsm asmp{};                                            // raw batch of the current call (forward launch)
     int loss_buf = 0, loss_lv0 = 0;                             // where the forward chains leave the head outputs in LDS
     int K0p = 0, cpinp = 0, Dp = 0, Cp = 0;                     // padded row strides of Xff / Xbk, Xcp, dMu / dLv / dBmu, the dctx buffers
@@ -1648,7 +1648,10 @@ extern "C" int cadm_train_reset(cadm_ctx* ctx, void* stream) {
 
 namespace {
 
-enum { PROG_FWD_FF = 0, PROG_FWD_BK = 1, PROG_BWD_FF = 2, PROG_BWD_BK = 3, PROG_FWD_BK_NOCP = 4 };     // (NOCP: context columns read back, see fwd_prog)
+enum { PROG_FWD_FF = 0, PROG_FWD_BK = 1, PROG_BWD_FF = 2, PROG_BWD_BK = 3,
+       PROG_FWD_BK_NOCP = 4,                                  // large batches: the backward model's forward chain with the context columns read back (fwd_prog)
+       PROG_BWD_FF_NOCP = 5, PROG_BWD_BK_NOCP = 6, PROG_BWD_CP = 7,   // ... and the backward chains cut in front of the context encoder + ONE pass down it (bwd_prog)
+       NPROG = 8 };
 
 ChainLoad input_tile(const float* g0, const float* g1, float* gsum, int ld_in, int ldg, int K, int dst, int dk0, int zero_to, int mode = 0) {
     ChainLoad d{};
@@ -1686,10 +1689,10 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
     const int ncp = has_cp ? ctx->cfg.n_cp_hidden : 0;
     const int cpin = (ctx->D + ctx->A) * ctx->cfg.history_length;
     std::vector<ChainStage> prog;
-    int first[5], count[5];
+    int first[NPROG], count[NPROG];
     int maxk = 16;                       // k extent of the widest LDS activation buffer
     int cur_prog = 0;
-    for (int i = 0; i < 5; ++i) t->npre[i] = 0;
+    for (int i = 0; i < NPROG; ++i) t->npre[i] = 0;
     auto push = [&](const ChainStage& g) {
         const int ext = g.dst >= 0 ? g.dk0 + 32 * g.ntp : 0;       // whole tile pairs are written (zeros behind N)
         maxk = ext > maxk ? ext : maxk;
@@ -1759,7 +1762,7 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
         }
     };
     auto bwd_prog = [&](const std::vector<DenseRef>& net, const std::vector<PackDst>& pb, const std::vector<int>& ptb, NetBufs& nb,
-                        const float* dMu, const float* dLv, std::vector<float*>& cp_dz) {
+                        const float* dMu, const float* dLv, std::vector<float*>& cp_dz, bool with_cp = true) {
         const int KBd = kblocks(D);
         // [dMu | dLv] side by side along k (the heads' transposed operands are concatenated the same way)
         input(input_tile(dMu, nullptr, nullptr, t->Dp, 0, D, 0, 0, 16 * KBd));
@@ -1786,7 +1789,8 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
             // ... and it goes on down the context encoder in the same chain: backpropagation is linear in the incoming
             // gradient, so each dynamics net carries ITS share (cp_dz) and the weight-gradient launch adds the two on load --
             // no third chain launch, no pass of the context gradient through global memory
-            for (int l = ncp; l >= 1; --l) {
+            // (with_cp = false, large batches: the chain ends here, with its share of the context gradient in nb.dctx; cp_bwd_prog)
+            for (int l = ncp; with_cp && l >= 1; --l) {
                 const DenseRef& L = ctx->cp[l];
                 dst = (cur + 1) % 3;
                 ChainStage h = gemm_stage(cur, dst, 0, ACT_RELU, ACT_NONE);
@@ -1801,12 +1805,32 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
     cur_prog = PROG_FWD_BK; first[PROG_FWD_BK] = (int)prog.size(); if (has_back) fwd_prog(ctx->back, t->pf_bk, t->pt_bk, t->Xbk, t->bk, false, false); count[PROG_FWD_BK] = (int)prog.size() - first[PROG_FWD_BK];
     cur_prog = PROG_BWD_FF; first[PROG_BWD_FF] = (int)prog.size(); bwd_prog(ctx->ff, t->pb_ff, t->ptb_ff, t->ff, t->dMu, det ? nullptr : t->dLv, t->cp.dz); count[PROG_BWD_FF] = (int)prog.size() - first[PROG_BWD_FF];
     cur_prog = PROG_BWD_BK; first[PROG_BWD_BK] = (int)prog.size(); if (has_back) bwd_prog(ctx->back, t->pb_bk, t->ptb_bk, t->bk, t->dBmu, nullptr, t->cp_dz_bk); count[PROG_BWD_BK] = (int)prog.size() - first[PROG_BWD_BK];
+    // Large batches: ONE pass down the context encoder on the SUM of the two dynamics nets' context gradients (an input tile adds the two on
+    // the way in) instead of one pass per net inside its backward chain: a third launch of short items, half the context-encoder work.
+    // Linear in the incoming gradient, so the same gradient -- summed before the pass instead of behind it (in dw_adam_kernel's loads):
+    // equal to fp32 roundoff, not bit for bit; the gradient bars against fp64 are asserted for both forms.
+    auto cp_bwd_prog = [&]() {
+        input(input_tile(t->ff.dctx, t->bk.dctx, nullptr, t->Cp, 0, C, 0, 0, 16 * kblocks(C)));
+        int cur = 0;
+        for (int l = ncp; l >= 1; --l) {
+            const DenseRef& L = ctx->cp[l];
+            const int dst = (cur + 1) % 3;
+            ChainStage h = gemm_stage(cur, dst, 0, ACT_RELU, ACT_NONE);
+            add_seg(h, t->pb_cp[l], t->ptb_cp[l], nullptr, t->cp.z[l - 1], nullptr, t->cp.dz[l - 1], L.din, L.din, L.din);
+            push(h);
+            cur = dst;
+        }
+    };
+    const bool can_merge = has_back && has_cp && ncp >= 1;
+    cur_prog = PROG_BWD_FF_NOCP; first[cur_prog] = (int)prog.size(); if (can_merge) bwd_prog(ctx->ff, t->pb_ff, t->ptb_ff, t->ff, t->dMu, det ? nullptr : t->dLv, t->cp.dz, false); count[cur_prog] = (int)prog.size() - first[cur_prog];
+    cur_prog = PROG_BWD_BK_NOCP; first[cur_prog] = (int)prog.size(); if (can_merge) bwd_prog(ctx->back, t->pb_bk, t->ptb_bk, t->bk, t->dBmu, nullptr, t->cp_dz_bk, false); count[cur_prog] = (int)prog.size() - first[cur_prog];
+    cur_prog = PROG_BWD_CP; first[cur_prog] = (int)prog.size(); if (can_merge) cp_bwd_prog(); count[cur_prog] = (int)prog.size() - first[cur_prog];
     cur_prog = PROG_FWD_BK_NOCP; first[PROG_FWD_BK_NOCP] = (int)prog.size();
     if (has_back && has_cp) fwd_prog(ctx->back, t->pf_bk, t->pt_bk, t->Xbk, t->bk, false, false, t->Xff + PA);
     count[PROG_FWD_BK_NOCP] = (int)prog.size() - first[PROG_FWD_BK_NOCP];
-    for (int i = 0; i < 5; ++i) CADM_REQUIRE(count[i] <= CH_MAXSTAGE, "training chain too long (more than 20 stages): too many layers");
+    for (int i = 0; i < NPROG; ++i) CADM_REQUIRE(count[i] <= CH_MAXSTAGE, "training chain too long (more than 20 stages): too many layers");
     static_assert(CH_MAXSTAGE < 31, "ChainStage::nxt keeps a stage index in 5 bits (31: none)");
-    for (int i = 0; i < 5; ++i)          // where each wave slot goes behind a stage (chain_group looks it up in ONE LDS read instead of walking the table)
+    for (int i = 0; i < NPROG; ++i)      // where each wave slot goes behind a stage (chain_group looks it up in ONE LDS read instead of walking the table)
         for (int k = 0; k < count[i]; ++k)
             for (int w = 0; w < CH_WAVES_MAX; ++w) {
                 unsigned char v = 31;
@@ -1833,7 +1857,7 @@ int sync_programs(cadm_ctx* ctx, hipStream_t s) {
         CADM_CHECK_HIP(hipMemcpy(t->prog_dev, prog.data(), prog.size() * sizeof(ChainStage), hipMemcpyHostToDevice));
         t->prog_host = prog;
     }
-    for (int i = 0; i < 5; ++i) { t->prog_first[i] = first[i]; t->prog_count[i] = count[i]; }
+    for (int i = 0; i < NPROG; ++i) { t->prog_first[i] = first[i]; t->prog_count[i] = count[i]; }
     t->chain_bufsz = CH_ROWS * ((maxk + 15) & ~15);
     {   // (an activation buffer doubles as the loss phase's scratch: 6 term arrays of 16 x D elements, or 512 chunk sums, + a flag)
         const int terms = 6 * CH_ROWS * ctx->D, need = ((terms > CH_THREADS_MAX ? terms : CH_THREADS_MAX) + 4 + 63) & ~63;
@@ -1858,7 +1882,7 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s, const Chai
     a.B = B; a.bufsz = t->chain_bufsz;
     a.tbuf = ctx->tbuf ? ctx->tbuf + 256 * (p0 / 2) : nullptr;   // [fwd | bwd] x 256 stamps (tools/chain_timing.py)
     a.tfine = ctx->tbuf ? ctx->tbuf + 512 + 128 * (p0 / 2) : nullptr;
-    if (p0 == PROG_FWD_BK_NOCP) a.tbuf = a.tfine = nullptr;      // (the second launch of a split forward pass is not clocked)
+    if (p0 >= PROG_FWD_BK_NOCP) a.tbuf = a.tfine = nullptr;      // (the extra launches of the large-batch path are not clocked)
     a.E = ctx->E; a.ntiles = (B + CH_ROWS - 1) / CH_ROWS;
     a.y_base = y_base; a.slot_ny = slot_ny ? slot_ny : a.ny;
     a.G = ctx->E <= 8 ? 8 / ctx->E : 1;
@@ -1987,7 +2011,15 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     auto wd_dyn = [&](int l) { return coeff * (l < NH ? hp.weight_decays[l] : hp.weight_decays[NH]); };
 
     // backward chains (read W) ...
-    if ((rc = launch_chain(ctx, B, PROG_BWD_FF, has_back ? PROG_BWD_BK : -1, s))) return rc;
+    const long bw_items = (long)E * 2 * ((B + CH_ROWS - 1) / CH_ROWS);
+    const bool merge = has_back && has_cp && t->prog_count[PROG_BWD_CP] > 0 &&
+                       (ctx->train_force_merge ? ctx->train_force_merge == 1 : 2 * bw_items >= 9L * ctx->n_cus);      // (forward_nets' rule)
+    if (!merge) {
+        if ((rc = launch_chain(ctx, B, PROG_BWD_FF, has_back ? PROG_BWD_BK : -1, s))) return rc;
+    } else {
+        if ((rc = launch_chain(ctx, B, PROG_BWD_FF_NOCP, PROG_BWD_BK_NOCP, s))) return rc;
+        if ((rc = launch_chain(ctx, B, PROG_BWD_CP, -1, s))) return rc;
+    }
 
     // ... then every layer's weight gradient + Adam as one grouped launch (overwrites W)
     DwArgs da{};
@@ -2019,7 +2051,7 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
         for (int l = 0; l <= ncp; ++l) {      // gradient = the forward net's share (+ the backward model's), added on load
             if ((rc = add_job(l == 0 ? t->Xcp : t->cp.h[l - 1], l == 0 ? t->cpinp : ctx->cp[l - 1].dout, l == ncp ? t->ff.dctx : t->cp.dz[l],
                               l == ncp ? t->Cp : ctx->cp[l].dout, ctx->cp[l], wd_cp(l), t->a_cp[2 * l], t->a_cp[2 * l + 1], t->pf_cp[l], t->pb_cp[l]))) return rc;
-            if (has_back) da.job[da.njobs - 1].dZ2 = l == ncp ? t->bk.dctx : t->cp_dz_bk[l];
+            if (has_back && !(merge && l < ncp)) da.job[da.njobs - 1].dZ2 = l == ncp ? t->bk.dctx : t->cp_dz_bk[l];      // (merged: cp.dz holds the sum)
         }
     }
     // output_logvar outside the data path (deterministic forward net / backward net): its weight only sees the L2 term

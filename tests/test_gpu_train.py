@@ -95,7 +95,10 @@ def _check_gradients(eng, grads, what):
     return checked
 
 
-@pytest.mark.parametrize("flavour", [8, 4])       # chain kernel: 8 waves x 1 workgroup per CU (latency) / 4 waves x 3 per CU (throughput)
+# chain kernel: 8 waves x 1 workgroup per CU (latency) / 4 waves x 3 per CU (throughput); + 16 + 64: the whole large-batch path forced at these
+# small batches -- work items spread over all XCDs, one forward launch per net (context vector read back), ONE pass of the summed context
+# gradient down the encoder (not bit-identical to one pass per net: this is its gradient test)
+@pytest.mark.parametrize("flavour", [8, 4, 4 + 16 + 64, 8 + 16 + 64])
 @pytest.mark.parametrize("env,context,with_back,det,E,B", CASES)
 def test_gradients_elementwise_vs_fp64_autograd(gpu, env, context, with_back, det, E, B, flavour):
     prob = synth.make_problem(env=env, context=context, E=E, trained_like=True, with_back=with_back, seed=22)

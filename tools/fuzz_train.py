@@ -70,7 +70,8 @@ def main():
         eng.train_configure(1e-3, WD, cwd, 1.0, cfg["back_coeff"], max_batch=B, beta1=0.0)
         # 0 = the launcher's pick; 4 / 8 waves per workgroup forced; + 16: large-batch mapping (work items spread over all XCDs, one forward
         # launch per net with the context vector read back), + 32: member-affine mapping, joint launch (round 5)
-        flavour = int(rng.choice([0, 4, 8, 4 + 16, 8 + 16, 4 + 32]))
+        # + 64: one pass of the summed context gradient down the encoder (the large-batch backward path)
+        flavour = int(rng.choice([0, 4, 8, 4 + 16, 8 + 16, 4 + 32, 4 + 16 + 64, 8 + 64]))
         eng._check(eng.lib.cadm_dev_set_train_flavour(eng._ctx, flavour), "cadm_dev_set_train_flavour")
         tag += " flavour=%d" % flavour
         before = {n: {k: v.clone() for k, v in eng.nets[n].items()} for n in eng.net_names()}
