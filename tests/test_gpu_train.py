@@ -268,9 +268,12 @@ def test_train_then_plan_uses_updated_weights(gpu):
     np.testing.assert_array_equal(r1, r2)
 
 
-def test_train_step_rows_equals_gathered_batch(gpu):
+@pytest.mark.parametrize("flavour", [None, 4 + 16 + 64])      # the product's launch plan / the large-batch plan forced (developer library)
+def test_train_step_rows_equals_gathered_batch(gpu, flavour):
     """cadm_train_step_rows (rows addressed as (window, future offset) inside the kernels) == cadm_train_step on the
-    batch gathered the way the reference's _preprocess_inputs + bootstrap indexing would (dynamics.py:676-696,:478-503)."""
+    batch gathered the way the reference's _preprocess_inputs + bootstrap indexing would (dynamics.py:676-696,:478-503).
+    Also under the large-batch launch plan (one forward launch per net with the context vector read back, one pass of the summed
+    context gradient): its extra input tiles address workspace rows, not dataset rows."""
     env, E, B, N, F, Hh = "halfcheetah", 5, 48, 40, 3, 10
     prob = synth.make_problem(env=env, context=True, E=E, trained_like=True, with_back=True, seed=41)
     r = np.random.default_rng(5)
@@ -283,7 +286,9 @@ def test_train_step_rows_equals_gathered_batch(gpu):
     idx = r.integers(0, w.shape[0], size=(E, B))
     results = []
     for mode in ("rows", "gathered"):
-        eng = make_engine(prob, p=E)
+        eng = make_engine(prob, p=E) if flavour is None else _dev_engine(prob, E)
+        if flavour is not None:
+            eng._check(eng.lib.cadm_dev_set_train_flavour(eng._ctx, flavour), "cadm_dev_set_train_flavour")
         eng.train_configure(1e-3, WD, CWD, 1.0, 0.5, max_batch=B)
         dev = {k: eng._t(v) for k, v in ds.items()}
         tw, tf_, ti = (torch.as_tensor(x, device=eng.device) for x in (w, f, idx))
