@@ -1174,7 +1174,75 @@ __global__ __launch_bounds__(256) void dw_adam_kernel(const DwArgs a) {
     const int Mq = (M + 3) & ~3, Nq = (N + 3) & ~3;
     const bool vec = KP > 0 && (K % TK) == 0 && ((jb.ldx | jb.ldz) & 3) == 0 && Mq <= jb.ldx && Nq <= jb.ldz &&
                      ((reinterpret_cast<size_t>(jb.X) | reinterpret_cast<size_t>(jb.dZ) | reinterpret_cast<size_t>(jb.dZ2)) & 15) == 0;
+#ifndef CADM_DW_NO_DMA
+    // Slabs by LDS-DMA (one gradient source; the jobs that add a second one on load keep the register path below): a slab goes
+    // global -> LDS in 16 buffer_load_dwordx4 .. lds of the workgroup (4 per wave: 4 batch rows x 12 / 16 quads each), no registers, no
+    // ds_write, in the tensors' own [row][feature] order; operands are then single dwords (lane (c, q): feature c of row q of a 4-row
+    // group).  The 4 rows of one MFMA come from 4 DIFFERENT groups -- each group starts 16 floats further round the banks -- so the
+    // four lane groups of a ds_read hit four different quarter-sets of banks: k-steps are taken in the order (t, r) -> rows
+    // {4 (4 t + q) + r : q = 0..3}, any order as long as A and B agree.
+    const bool dma = vec && !two && (size_t)K * jb.ldx * 4 < (1ull << 32) && (size_t)K * jb.ldz * 4 < (1ull << 32);
+    if (dma) {
+        constexpr int AG = 4 * TM + 16, BG = 4 * TN + 16, DBUF = 8 * (AG + BG);      // floats per 4-row group of A / B, per slab buffer
+        static_assert(TK == 32 && 2 * DBUF <= DW_SMEM && TM * LDC <= DBUF, "slab buffers of the LDS-DMA path");
+        typedef __attribute__((address_space(3))) void* ldsp;
+        const int c = lane & 15, kq = lane >> 4, wu = __builtin_amdgcn_readfirstlane(wn);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (unsigned)((size_t)K * jb.ldx * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bm, 0, (unsigned)((size_t)K * jb.ldz * 4), 0x00020000);
+        const int ar = lane / 12, aq = lane - 12 * ar;                               // (lanes 0..47: 4 rows x 12 quads of A)
+        const int ma = mb + 4 * aq < Mq ? mb + 4 * aq : Mq - 4, nq = nb + 4 * c < Nq ? nb + 4 * c : Nq - 4;
+        const unsigned va = (unsigned)((ar * jb.ldx + ma) * 4), vb = (unsigned)((kq * jb.ldz + nq) * 4);
+        const bool n_ok = nb + 16 * wn < N;
+        auto request = [&](int k0, int par) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = 2 * wu + u;
+                float* const ga = dw_smem + par * DBUF + j * AG;
+                float* const gb = dw_smem + par * DBUF + 8 * AG + j * BG;
+                const unsigned sa = (unsigned)(k0 + 4 * j) * (unsigned)jb.ldx * 4u, sb = (unsigned)(k0 + 4 * j) * (unsigned)jb.ldz * 4u;
+                if (lane < 48) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (ldsp)ga, 16, va, sa, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (ldsp)gb, 16, vb, sb, 0, 0);
+            }
+        };
+        auto compute = [&](int par) {
+            const float* Ab = dw_smem + par * DBUF + kq * AG + c;
+            const float* Bb = dw_smem + par * DBUF + 8 * AG + kq * BG + 16 * wn + c;
+            if (do_colsum) {
+                const float* Bc = dw_smem + par * DBUF + 8 * AG + tid;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) colsum += Bc[j * BG + r * TN];
+            }
+            if (n_ok) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float b = Bb[4 * t * BG + r * TN];
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) {
+                            if (mb + 16 * i >= M) continue;
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[4 * t * AG + r * TM + 16 * i], b, acc[i], 0, 0, 0);
+                        }
+                    }
+            }
+        };
+        request(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int par = 0;
+        for (int k0 = 0; k0 < KP; k0 += TK, par ^= 1) {
+            if (k0 + TK < KP) request(k0 + TK, par ^ 1);       // (the buffer computed from one iteration ago: every wave is past that iteration's barrier)
+            compute(par);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    if (vec && !dma) {
+#else
     if (vec) {
+#endif
         float* const At = dw_smem;
         float* const Bt = dw_smem + TM * LDK;
         const int c = lane & 15, q = lane >> 4;

@@ -108,7 +108,10 @@ def train_losses(env_name, ff, back, cp, st, batch, cfg):
             z = torch.matmul(x, cp["cp_hidden_%d_weight" % i]) + cp["cp_hidden_%d_bias" % i]
             # relu; cfg["cp_relu_threshold"] (tools/fuzz_train.py only, default 0 = the reference's relu) moves the kink by a hair, to tell a
             # pre-activation that rounds to the other side of 0 in fp32 from a wrong gradient
-            x = torch.where(z > cfg.get("cp_relu_threshold", 0.0), z, torch.zeros_like(z))
+            thr = cfg.get("cp_relu_threshold", 0.0)
+            if isinstance(thr, dict):          # {layer: tensor shaped like z}: single units moved to one side of the kink or the other
+                thr = thr.get(i, 0.0)
+            x = torch.where(z > thr, z, torch.zeros_like(z))
         ctx = torch.matmul(x, cp["cp_output_weight"]) + cp["cp_output_bias"]
         feats.append(ctx)
     act = _ACTS[cfg.get("hidden_nonlinearity", "swish")]
@@ -152,6 +155,19 @@ def train_losses(env_name, ff, back, cp, st, batch, cfg):
             recon = recon + cfg["back_coeff"] * back_mse                      # :311-312
         loss = recon + reg + l2 * coeff                                       # :314
     return dict(loss=loss, mse=mse, back_mse=back_mse, recon=recon)
+
+
+def context_preacts(cp, st, batch, cfg):
+    """Pre-activations of the context encoder's hidden layers (list of [E,B,width] tensors) -- tools/fuzz_train.py looks for relu units
+    within roundoff of their kink."""
+    x = torch.cat([_norm(batch["cp_obs"], st["cp_obs_mean"], st["cp_obs_std"]),
+                   _norm(batch["cp_act"], st["cp_act_mean"], st["cp_act_std"])], -1)
+    out = []
+    for i in range(cfg["n_cp_hidden"]):
+        z = torch.matmul(x, cp["cp_hidden_%d_weight" % i]) + cp["cp_hidden_%d_bias" % i]
+        out.append(z.detach())
+        x = torch.relu(z)
+    return out
 
 
 def grads_of(loss, nets):
