@@ -138,11 +138,26 @@ __device__ __forceinline__ void sincos_cw(float x, float* sn, float* cs) {
     *cs = ((q + 1) & 2) ? -c0 : c0;
 }
 
-__device__ __forceinline__ float softplus_fast(float x) {     // tf.nn.softplus thresholds (+-13.94)
+__device__ __forceinline__ float softplus_fast(float x) {     // tf.nn.softplus thresholds (+-13.94); the developer library's comparison kernel
     const float ex = __expf(fminf(x, 20.0f));
     const float mid = __builtin_amdgcn_logf(1.0f + ex) * 0.69314718055994531f;   // v_log_f32 is log2
     const float lo = x < -13.942385f ? ex : mid;
     return x > 13.942385f ? x : lo;
+}
+
+// Standard deviation of the Gaussian head (core/utils.py:356-363) with the double soft clamp collapsed algebraically:
+//     lv1 = max - softplus(max - lv)     <=>  e^lv1 = 1 / (e^-max + e^-lv)
+//     lv2 = min + softplus(lv1 - min)    <=>  e^lv2 = e^min + e^lv1
+//     sd  = exp((lv2 + 2 log s) / 2)      =   s * sqrt(e^min + 1 / (e^-max + e^-lv))
+// one v_exp, one v_rcp, one v_sqrt in a chain of 7 instructions instead of 3 exp + 2 log in a chain of ~30 (the state phase is on the
+// critical path of every step of every flavour).  enmax = e^-max, emin = e^min, s = delta std are per-dim constants of the LDS table.
+// Both ends saturate as the clamp does: e^-lv -> inf gives e^min, e^-lv -> 0 gives e^max + e^min.  tf.nn.softplus switches to
+// x / e^x beyond |x| > 13.94; against this exact form that is < 9e-7 relative in the variance (tests/test_gpu_precision.py sweeps lv
+// over +-30 and both thresholds against the oracle's tf_softplus chain).  Envelope: |max_logvar|, |min_logvar| < 80 (e^-max / e^min
+// stay normal fp32 numbers; the reference initialises them to 0.5 / -10 and regularises them towards each other).
+__device__ __forceinline__ float head_sd(float lv, float enmax, float emin, float s) {
+    const float t = __builtin_amdgcn_exp2f(lv * -1.4426950408889634f);             // e^-lv
+    return s * __builtin_amdgcn_sqrtf(emin + __builtin_amdgcn_rcpf(enmax + t));
 }
 
 template <int R0, int R1>

@@ -207,9 +207,9 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
             const int dc = d < D ? d : 0;
             te[0 + h] = a.delta_mean[dc];
             te[2 + h] = a.delta_std[dc] + 1e-10f;
-            te[4 + h] = 2.0f * logf(a.delta_std[dc]);              // core/utils.py:360
-            te[6 + h] = a.maxlv[dc];
-            te[8 + h] = a.minlv[dc];
+            te[4 + h] = a.delta_std[dc];                           // core/utils.py:360-363 through head_sd (rollout_env.h)
+            te[6 + h] = expf(-a.maxlv[dc]);
+            te[8 + h] = expf(a.minlv[dc]);
             int ff[2], fop[2];
             const int nf = d < D ? dim_feats<ENV>(d, ff, fop) : 0;
 #pragma unroll
@@ -352,9 +352,7 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
                             for (int h = 0; h < 2; ++h) {
                                 float delta = v[h] * tv(2 + h) + tv(0 + h);                          // denormalize, :349
                                 if constexpr (NOISE != CADM_NOISE_NONE) {
-                                    float lv = tv(6 + h) - softplus_fast(tv(6 + h) - v[2 + h]);          // :356
-                                    lv = tv(8 + h) + softplus_fast(lv - tv(8 + h));                      // :357
-                                    const float sd = __expf((lv + tv(4 + h)) * 0.5f);                    // :360-363
+                                    const float sd = head_sd(v[2 + h], tv(6 + h), tv(8 + h), tv(4 + h));   // :356-363
                                     delta = delta + (h ? z.y : z.x) * sd;                               // :365
                                 }
                                 po[jj][h] = postproc<ENV>(2 * dp + h, po[jj][h], delta);                // :466

@@ -600,9 +600,9 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
             float* te = tab + sd * G::TABD;
             te[0] = a.delta_mean[sd];
             te[1] = a.delta_std[sd] + 1e-10f;
-            te[2] = 2.0f * logf(a.delta_std[sd]);                       // core/utils.py:360
-            te[3] = a.maxlv[sd];
-            te[4] = a.minlv[sd];
+            te[2] = a.delta_std[sd];                                    // core/utils.py:360-363 through head_sd (rollout_env.h)
+            te[3] = expf(-a.maxlv[sd]);
+            te[4] = expf(a.minlv[sd]);
             int ff[2], fop[2];
             const int nf = dim_feats<ENV>(sd, ff, fop);
 #pragma unroll
@@ -626,9 +626,9 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                 const int dc = d < D ? d : 0;
                 te[0 + h] = a.delta_mean[dc];
                 te[2 + h] = a.delta_std[dc] + 1e-10f;
-                te[4 + h] = 2.0f * logf(a.delta_std[dc]);              // core/utils.py:360
-                te[6 + h] = a.maxlv[dc];
-                te[8 + h] = a.minlv[dc];
+                te[4 + h] = a.delta_std[dc];                           // core/utils.py:360-363 through head_sd (rollout_env.h)
+                te[6 + h] = expf(-a.maxlv[dc]);
+                te[8 + h] = expf(a.minlv[dc]);
                 int ff[2], fop[2];
                 const int nf = d < D ? dim_feats<ENV>(d, ff, fop) : 0;
 #pragma unroll
@@ -713,10 +713,14 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     static_for(std::make_integer_sequence<int, NRESH>{}, [&](auto qc) {
         constexpr int q = decltype(qc)::value;
         constexpr int l = q < Q1 ? 1 : q < Q1 + Q2 ? 2 : 3, ql = q - (l == 1 ? 0 : l == 2 ? Q1 : Q1 + Q2);
-        // (a layer the model does not have loads in-bounds garbage that is never used)
-        const unsigned so = l < XNH ? w_h1 + ((l - 1) * lh_nf + ql) * CADM_XDL_FRAG_BYTES : wbase;
-        xres_load(resH[q][0], rsrc, lane * 16, so);
-        xres_load(resH[q][1], rsrc, lane * 16 + 1024, so);
+        // (a layer the model does not have gets no load: its registers would be dead behind an asynchronous asm load, hipcc reuses dead
+        //  AGPRs as spill space, and a spill written before the load lands would be overwritten -- found by the JIT's ISA scan on a
+        //  two-layer net, cadm_amd/isa_check.py)
+        if constexpr (l < XNH) {
+            const unsigned so = w_h1 + ((l - 1) * lh_nf + ql) * CADM_XDL_FRAG_BYTES;
+            xres_load(resH[q][0], rsrc, lane * 16, so);
+            xres_load(resH[q][1], rsrc, lane * 16 + 1024, so);
+        }
     });
     if constexpr (RESO) {
 #pragma unroll
@@ -838,9 +842,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                         float delta = vp[hh] * tv(1) + tv(0);                                    // denormalize, :349
                         if constexpr (NOISE != CADM_NOISE_NONE) {
                             const float z = reinterpret_cast<const float*>(zb + ((t - 1) & 1) * 256 + dp * 16 + arow)[hh];
-                            float lv = tv(3) - softplus_fast(tv(3) - vp[2 + hh]);               // :356
-                            lv = tv(4) + softplus_fast(lv - tv(4));                              // :357
-                            const float sdv = __expf((lv + tv(2)) * 0.5f);                       // :360-363
+                            const float sdv = head_sd(vp[2 + hh], tv(3), tv(4), tv(2));          // :356-363
                             delta = delta + z * sdv;                                             // :365
                         }
                         po[0][0] = postproc<ENV>(sd, po[0][0], delta);                           // :466
@@ -891,9 +893,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                         for (int h = 0; h < 2; ++h) {
                             float delta = v[h] * tv(2 + h) + tv(0 + h);                          // denormalize, :349
                             if constexpr (NOISE != CADM_NOISE_NONE) {
-                                float lv = tv(6 + h) - softplus_fast(tv(6 + h) - v[2 + h]);          // :356
-                                lv = tv(8 + h) + softplus_fast(lv - tv(8 + h));                      // :357
-                                const float sd = __expf((lv + tv(4 + h)) * 0.5f);                    // :360-363
+                                const float sd = head_sd(v[2 + h], tv(6 + h), tv(8 + h), tv(4 + h));   // :356-363
                                 delta = delta + (h ? z.y : z.x) * sd;                               // :365
                             }
                             po[pi][h] = postproc<ENV>(2 * dp + h, po[pi][h], delta);                // :466

@@ -12,12 +12,14 @@ kernel.  Hidden widths below 113 need no build: they run zero-padded on the 128-
 import ctypes as C
 import fcntl
 import hashlib
+import json
 import os
 import shutil
 import subprocess
 import tempfile
+import warnings
 
-from . import _lib
+from . import _lib, isa_check
 
 ARCH = "gfx950"           # the one target of this library (csrc/Makefile: ARCH); the kernels are written for its MFMA / LDS
 MIN_HID, NARROW_HID = 113, 128     # xdl_geo.h: narrower nets run zero-padded on the compiled-in 128-wide kernel (no build needed)
@@ -114,8 +116,37 @@ def build(env_kind, C_, hid, nh, act, noise, verbose=False):
             print(r.stdout)
         if r.returncode != 0:
             raise _lib.CadmError("building the rollout kernel for hidden=%d x %d, context_out_dim=%d failed:\n%s" % (hid, nh, C_, r.stdout[-2000:]))
+        try:
+            report = isa_scan(tmp, cc)
+        except _lib.CadmError:
+            os.remove(tmp)
+            raise
+        with open(path + ".isa.json", "w") as f:
+            json.dump(report, f, indent=1)
         os.replace(tmp, path)
     return path
+
+
+def isa_scan(so_path, cc=None):
+    """Disassemble a freshly built module with the llvm-objdump of the compiler that built it and apply the hand-scheduling rules of
+    cadm_amd/isa_check.py (resident AGPR fragments never copied, wait states around asm MFMAs / asm loads, LDS-DMA landed before the block
+    barrier).  The kernels pad hazards hipcc cannot see through inline asm; whether the padding holds depends on what THIS hipcc did around
+    it, so a module that breaks a rule is refused (CadmError) rather than registered.  Scratch use is a performance defect only (compiler-managed):
+    reported in the returned dict and as a warning.  Without llvm-objdump the scan cannot run: a RuntimeWarning, and the report says so."""
+    objdump = isa_check.find_objdump(cc or hipcc())
+    if not objdump:
+        warnings.warn("cadm_amd.jit: llvm-objdump not found -- the built rollout module was NOT ISA-checked (set $CADM_OBJDUMP)", RuntimeWarning)
+        return {"checked": False, "reason": "llvm-objdump not found"}
+    rep = isa_check.scan(so_path, objdump, which=("rollout_xdl_kernel", "rollout_wt_kernel"))
+    if rep["kernels"] == 0:
+        raise _lib.CadmError("ISA check of %s: no rollout kernel found in the module" % so_path)
+    if rep["problems"]:
+        raise _lib.CadmError("the rollout module built by %s breaks the kernels' hand-scheduling rules and was not registered (%d problem(s)):\n  %s"
+                             % (cc or hipcc(), len(rep["problems"]), "\n  ".join(rep["problems"][:8])))
+    if rep["scratch"]:
+        warnings.warn("cadm_amd.jit: %d rollout kernel(s) of this geometry spill registers to scratch (slower, not wrong): %s"
+                      % (len(rep["scratch"]), {k[-40:]: v for k, v in list(rep["scratch"].items())[:3]}), RuntimeWarning)
+    return {"checked": True, "objdump": objdump, "kernels": rep["kernels"], "problems": 0, "scratch": rep["scratch"]}
 
 
 def ensure(engine, noise):

@@ -270,3 +270,56 @@ def test_fuzz_rollout_seed(gpu):
     rounds, worst = fuzz_rollout.fuzz(seconds=60.0, seed=20260929)
     print("\nfuzz: %d random problems, worst xdl-vs-fp32-kernel trajectory deviation %.2e of the rms" % (rounds, worst))
     assert rounds >= 20
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (iv) the Gaussian head's standard deviation: the kernels evaluate the reference's double soft clamp (core/utils.py:356-363) in its
+# collapsed form  sd = s * sqrt(e^min + 1 / (e^-max + e^-lv))  (rollout_env.h: head_sd).  Swept here against the oracle's
+# tf.nn.softplus chain (thresholds at +-13.94 in fp32) and against fp64, over lv in [-30, 30], with the points that straddle both thresholds.
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bounds", ["reference_init", "per_dim"])
+@pytest.mark.parametrize("row_tiles", [1, 2, 3])       # cooperative one / two row tiles, wave-tile: three copies of the state phase
+def test_head_sd_sweep_against_tf_softplus(gpu, bounds, row_tiles):
+    E, p, n, D = 5, 20, 16, 18
+    prob = synth.make_problem(env="halfcheetah", context=True, E=E, m=1, H=1, trained_like=True, seed=41)
+    rng = np.random.default_rng(41)
+    ff = prob["ff"]
+    for k in ("output_mu_weight", "output_mu_bias", "output_logvar_weight"):
+        ff[k] = np.zeros_like(ff[k])                      # mu = 0, logvar = its bias: exactly the swept value in both implementations
+    if bounds == "per_dim":
+        ff["max_logvar"] = rng.uniform(-2.0, 3.0, (1, D))
+        ff["min_logvar"] = rng.uniform(-25.0, -3.0, (1, D))
+    prob["stats"]["delta_mean"] = np.zeros(D)
+    mx, mn = ff["max_logvar"][0].astype(np.float32), ff["min_logvar"][0].astype(np.float32)
+    obs_rows = np.zeros((1, n, p, D))
+    actions = rng.uniform(-1, 1, (1, n, 1, prob["A"]))
+    eps = np.where(rng.uniform(size=(1, 1, n, p, D)) < 0.5, -1.0, 1.0) * rng.uniform(0.5, 2.0, (1, 1, n, p, D))
+    eng = make_engine(prob, p=p, H=1, lib=_lib.load_dev())
+    eng.dev_set_rollout("xdl", row_tiles)
+    worst32 = worst64 = 0.0
+    npts = 0
+    for sweep in range(8):
+        lv = rng.uniform(-30.0, 30.0, (E, 1, D)).astype(np.float32)
+        if sweep < 4:      # straddle the thresholds: max - lv = +-13.942385 (softplus #1), lv1 - min = +-13.942385 (softplus #2, lv1 ~ lv below max)
+            th = np.float32(13.942385)
+            off = (np.float32(1e-3) * rng.uniform(-1, 1, (E, 1, D))).astype(np.float32)
+            cand = [mx - th, mx + th, mn + th, mn - th][sweep]
+            lv = (cand[None, None, :] + off).astype(np.float32)
+        ff["output_logvar_bias"] = lv.astype(np.float64)
+        eng.set_net("ff_model", ff)
+        rows, traj, r_ref, t_ref = _one_step(prob, eng, obs_rows, actions, eps, p)
+        o64 = oracle_problem(prob, np.float64)
+        T64 = oplanner.context_table_indexed(onets.context_forward(o64["cp"], o64["cp_obs"], o64["cp_act"], o64["st"]), 0)
+        _, t64 = oplanner.rollout_indexed(o64["env"], o64["ff"], o64["st"], o64["obs"], T64, actions, eps, E, p, False, obs_rows=obs_rows,
+                                          return_traj=True)
+        # next obs = eps * sd on every dim (halfcheetah: dim 0 is the delta itself, the others obs + delta with obs = 0)
+        got, ref32, ref64 = traj[0].astype(np.float64), t_ref[0].astype(np.float64), t64[0]
+        assert np.isfinite(got).all() and (np.abs(ref64) > 0).all()
+        worst32 = max(worst32, float((np.abs(got - ref32) / np.abs(ref32)).max()))
+        worst64 = max(worst64, float((np.abs(got - ref64) / np.abs(ref64)).max()))
+        npts += E * D
+    print("head sd, %s bounds, flavour %d: %d (member, dim) points; pure relative error vs the fp32 tf.nn.softplus chain %.2e, vs fp64 %.2e"
+          % (bounds, row_tiles, npts, worst32, worst64))
+    assert worst32 <= 3e-6, worst32      # north_star's bar is 1e-5; the fp32 chain itself is ~1e-6 from fp64 where |lv| is large
+    assert worst64 <= 2e-6, worst64
+    eng.close()

@@ -1,61 +1,30 @@
-"""Build-time check of the generated gfx950 code of the production rollout kernels (no GPU needed).
+"""Build-time check of the generated gfx950 code of the production kernels (no GPU needed).
 
 The register-resident weight fragments of `rollout_xdl_kernel` are pinned to AGPRs through inline-asm operand constraints
 (cadm_amd/csrc/rollout_xdl.h).  If hipcc ever runs out of registers there it parks a resident fragment in VGPRs / scratch
 and copies it back with `v_accvgpr_write` right in front of the asm MFMA that reads it -- an operand hazard the compiler
 cannot see through inline asm (stale operands, silently wrong rollouts).  So the shipped library itself is disassembled
-and every asm-MFMA geometry must be free of AGPR<->VGPR shuffles and of scratch traffic."""
+and every asm-MFMA geometry must be free of AGPR<->VGPR shuffles and of scratch traffic.
+
+The rules themselves live in the product (cadm_amd/isa_check.py): `cadm_amd.jit.build` applies them to every module it compiles on the
+user's machine, with that machine's hipcc.  This file applies them to the shipped library and adds what is specific to
+the compiled-in geometries (MFMA counts, no scratch at the reference's widths, number of kernels)."""
 import os
 import re
-import struct
 import subprocess
-import tempfile
 
 import pytest
 
+from cadm_amd import isa_check
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "cadm_amd", "libcadm_hip.so")
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
-
-
-def _code_objects(path):
-    """gfx950 ELF images inside the library's .hip_fatbin (clang offload bundles, one per translation unit)."""
-    data = open(path, "rb").read()
-    out, pos = [], 0
-    while True:
-        i = data.find(MAGIC, pos)
-        if i < 0:
-            return out
-        n = struct.unpack_from("<Q", data, i + len(MAGIC))[0]
-        off = i + len(MAGIC) + 8
-        for _ in range(n):
-            o, s, ts = struct.unpack_from("<QQQ", data, off)
-            triple = data[off + 24:off + 24 + ts]
-            off += 24 + ts
-            if b"gfx950" in triple and s > 0:
-                out.append(data[i + o:i + o + s])
-        pos = i + len(MAGIC)
+OBJDUMP = isa_check.find_objdump("/opt/rocm/bin/hipcc") or "/opt/rocm/lib/llvm/bin/llvm-objdump"
+_code_objects = isa_check.code_objects
 
 
 def _kernels(image, match="rollout_xdl_kernel"):
-    """{demangled-ish symbol: instruction text} of the kernels of one code object whose name contains `match`."""
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(image)
-        f.flush()
-        txt = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, check=True).stdout
-    out, name, buf = {}, None, []
-    for line in txt.splitlines():
-        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
-        if m:
-            if name is not None:
-                out[name] = buf
-            name, buf = (m.group(1), []) if match in m.group(1) else (None, [])
-        elif name is not None:
-            buf.append(line.strip())
-    if name is not None:
-        out[name] = buf
-    return out
+    return isa_check.kernels(image, match, OBJDUMP)
 
 
 @pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump not available")
@@ -70,66 +39,14 @@ def test_resident_fragments_never_leave_agprs():
             m = re.search(r"2XCILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi\d+ELi\d+EEE", sym)        # XC<ENV, C, HID, MT, NH, ACT>
             assert m, sym
             hid = int(m.group(3))
-            n_mfma = sum(1 for x in ins if x.startswith("v_mfma_f32_16x16x32_f16"))
-            assert n_mfma > 30, "%s: only %d f16 MFMAs -- wrong kernel?" % (sym, n_mfma)
+            problems, info = isa_check.check_rollout_xdl(sym, ins)      # R1 resident AGPRs, R2 readfirstlane wait states, R3 s_nop in front of asm MFMAs
+            assert info["mfma"] > 30, "%s: only %d f16 MFMAs -- wrong kernel?" % (sym, info["mfma"])
+            assert not problems, problems[:3]
             if hid > 256:
                 continue
-            scratch = [x for x in ins if x.startswith("scratch_")]
-            assert not scratch, "%s: %d scratch accesses (e.g. %s)" % (sym, len(scratch), scratch[0])
-            # The kernel body exists once per wave variant (tiles per wave); each variant loads ITS resident fragments
-            # with a burst of "buffer_load_dwordx4 a[..]" and keeps them to the end.  hipcc may park ordinary VGPR values
-            # in OTHER AGPRs (harmless spills); a copy into or out of a resident one is the hazard.
-            # variant k = [its prologue][burst of resident loads][tile loop][unconditional branch to the common exit]:
-            # a boundary is the first s_branch / s_endpgm behind the last MFMA that precedes the next burst
-            # (the asm statement of a resident load is "s_nop 4; buffer_load_dwordx4 a[..]": that pair identifies them --
-            #  hipcc may also point ordinary ring loads at spare AGPRs, which it tracks itself)
-            loads = [i for i, x in enumerate(ins) if i > 0 and x.startswith("buffer_load_dwordx4 a[") and ins[i - 1].startswith("s_nop 4")]
-            assert loads, "%s: no resident-fragment loads" % sym
-            mfma_at = [i for i, x in enumerate(ins) if x.startswith("v_mfma_")]
-            bursts = []      # a new burst = a resident load with MFMAs between it and the previous burst's loads
-            for k, i in enumerate(loads):
-                if k == 0 or any(loads[k - 1] < m < i for m in mfma_at):
-                    bursts.append(i)
-            starts = [0]
-            for nb in bursts[1:]:
-                last = max(i for i in mfma_at if i < nb)
-                end = next(i for i in range(last, nb) if ins[i].startswith(("s_branch", "s_endpgm")))
-                starts.append(end + 1)
-            for k, b in enumerate(starts):
-                e = starts[k + 1] if k + 1 < len(starts) else len(ins)
-                resident = set()
-                for i in loads:
-                    if b <= i < e:
-                        m2 = re.match(r"buffer_load_dwordx4 a\[(\d+):(\d+)\]", ins[i])
-                        resident.update(range(int(m2.group(1)), int(m2.group(2)) + 1))
-                for x in ins[b:e]:
-                    m2 = re.match(r"v_accvgpr_write_b32 a(\d+),", x) or re.match(r"v_accvgpr_read_b32 v\d+, a(\d+)", x)
-                    assert not (m2 and int(m2.group(1)) in resident), "%s: resident fragment register copied: %s" % (sym, x)
-                    m2 = re.match(r"v_mfma_f32_16x16x32_f16 v\[\d+:\d+\], a\[(\d+):(\d+)\], v\[", x)
-                    assert not (m2 and not set(range(int(m2.group(1)), int(m2.group(2)) + 1)) <= resident), \
-                        "%s: MFMA reads an AGPR operand that is not a resident fragment: %s" % (sym, x)
-            # inline-asm loads are invisible to hipcc's hazard recognizer: an SGPR offset written by a VALU instruction
-            # (v_readfirstlane / v_readlane) needs 5 wait states before a VMEM instruction reads it
-            for i in loads:
-                x = ins[i]
-                m2 = re.match(r"buffer_load_dwordx4 a\[\d+:\d+\], v\d+, s\[\d+:\d+\], (s\d+) offen", x)
-                if not m2:
-                    continue
-                waits = 0
-                for y in reversed(ins[max(0, i - 6):i]):
-                    if re.match(r"v_read(first)?lane_b32 %s," % m2.group(1), y):
-                        assert waits >= 5, "%s: %s only %d wait states after %s" % (sym, x.split("//")[0], waits, y.split("//")[0])
-                        break
-                    m3 = re.match(r"s_nop (\d+)", y)
-                    waits += int(m3.group(1)) + 1 if m3 else 1
-            # every asm MFMA carries its own 2 wait states ("s_nop 1" in the asm statement): whatever VALU instruction hipcc puts
-            # in front of it (v_accvgpr_read of a parked operand, a zeroing v_mov), the MFMA never reads a VGPR too early
-            for i, x in enumerate(ins):
-                if x.startswith("v_mfma_f32_16x16x32_f16"):
-                    assert ins[i - 1].startswith("s_nop") and int(ins[i - 1].split()[1]) >= 1, \
-                        "%s: MFMA without wait states in front: %s / %s" % (sym, ins[i - 1].split("//")[0], x.split("//")[0])
-            res = [x for x in ins if x.startswith("v_mfma_f32_16x16x32_f16") and re.search(r", a\[\d+:\d+\], v\[", x)]
-            assert len(res) > 10, "%s: no MFMA reads its A operand from AGPRs -- residency is off" % sym
+            assert info["scratch"] == 0, "%s: %d scratch accesses" % (sym, info["scratch"])
+            assert info["resident_loads"] > 0, "%s: no resident-fragment loads" % sym
+            assert info["resident_mfma"] > 10, "%s: no MFMA reads its A operand from AGPRs -- residency is off" % sym
             checked += 1
     assert checked >= 5 * 2 * 3      # 5 envs x {C = 0, 10} x 3 noise modes at least for HID = 200
 
@@ -139,35 +56,37 @@ def test_training_chain_ring_registers_are_left_alone():
     """The training chains' operand ring is a[0:63], named literally in inline asm (cadm_amd/csrc/train.hip): hipcc must
     not touch THOSE registers in chain_kernel once the ring is in use (under VGPR pressure it parks values in AGPRs: the 4-wave flavour,
     cut for three waves per SIMD, does -- above a63, or in the kernel prologue), must not spill to scratch, and no MFMA may directly follow a VALU instruction (the
-    asm MFMAs carry no wait states: their operands come from loads and ds_reads)."""
+    asm MFMAs carry no wait states: their operands come from loads and ds_reads).  "Once the ring is in use" follows the kernel's control
+    flow from the first ring load (isa_check.reachable_from), not the linear order of the image."""
     found = 0
     for img in _code_objects(LIB):
         for sym, ins in _kernels(img, "chain_kernel").items():
-            ins = [x.split("//")[0].strip() for x in ins if x.strip()]
             found += 1
-            assert not [x for x in ins if x.startswith("scratch_")], "chain_kernel uses scratch"
-            mine = ("v_mfma_f32_16x16x4_f32", "global_load_dwordx4 a[")
-            # From the first ring load on, a0-a63 hold operand blocks between one asm statement (the load) and another (the MFMAs): a value
-            # hipcc parks there would overwrite them.  In front of it -- the kernel prologue: input tiles, stage table, first look-up -- the
-            # ring is empty and hipcc may use the registers as it likes (the 4-wave flavour's 84 VGPRs do not hold a whole input tile's
-            # loads; the asm statements' clobber lists make it give them up at the first ring load).
-            first_ring = min(i for i, x in enumerate(ins) if x.startswith("global_load_dwordx4 a["))
-            alien = []
-            for x in ins[first_ring:]:
-                if x.startswith(mine):
-                    continue
-                for m in re.finditer(r"\ba\[?(\d+)(?::(\d+))?", x):
-                    if int(m.group(1)) < 64:
-                        alien.append(x)
-            assert not alien, "hipcc touches the ring's AGPRs (a0-a63) behind the first ring load of chain_kernel: %s" % alien[:3]
-            mf = [i for i, x in enumerate(ins) if x.startswith("v_mfma_")]
-            assert len(mf) >= 64
-            for i in mf:
-                assert re.match(r"v_mfma_f32_16x16x4_f32 v\[\d+:\d+\], a\d+, v\d+, v\[", ins[i]), ins[i]
-                assert ins[i - 1].split()[0].startswith(("s_", "v_mfma")), "VALU instruction in front of an asm MFMA: %s / %s" % (ins[i - 1], ins[i])
-            ring = [x for x in ins if x.startswith("global_load_dwordx4 a[")]
-            assert ring and all(re.match(r"global_load_dwordx4 a\[\d+:\d+\], v\d+, s\[\d+:\d+\]", x) for x in ring)
+            problems, info = isa_check.check_chain(sym, ins)
+            assert not problems, problems[:3]
+            assert info["scratch"] == 0, "chain_kernel uses scratch"
+            assert info["mfma"] >= 64
+            # the reachability is a real restriction (the prologue is excluded) and a real graph (the loops are included)
+            assert info["reachable"] > 1000 and info["before_ring_only"] > 0, info
     assert found == 2      # chain_kernel<8>, chain_kernel<4>
+
+
+def test_reachability_follows_branches_not_layout():
+    """isa_check.reachable_from on a hand-made listing: a block placed BEFORE the start instruction in the image but branched to from
+    behind it is reachable; the straight-line prologue is not."""
+    def line(addr, text, tgt=None):
+        return "%-40s // %012X: 00000000%s" % (text, addr, " <k+0x%x>" % (tgt - 0x1000) if tgt is not None else "")
+    ins = [line(0x1000, "s_mov_b32 s0, 0"),                       # 0 prologue
+           line(0x1004, "s_branch 2", 0x1010),                    # 1 -> 4
+           line(0x1008, "v_accvgpr_write_b32 a3, v1"),            # 2 loop tail, placed early in the image
+           line(0x100c, "s_branch 1", 0x1014),                    # 3 -> 5
+           line(0x1010, "global_load_dwordx4 a[0:3], v2, s[0:1]"),    # 4 START
+           line(0x1014, "v_mfma_f32_16x16x4_f32 v[0:3], a0, v4, v[0:3]"),      # 5
+           line(0x1018, "s_cbranch_scc1 65531", 0x1008),          # 6 -> 2
+           line(0x101c, "s_endpgm")]                              # 7
+    assert isa_check.reachable_from(ins, 4) == {2, 3, 4, 5, 6, 7}
+    problems, _ = isa_check.check_chain("k", ins)
+    assert any("T1" in p and "a3" in p for p in problems), problems
 
 
 @pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump not available")
@@ -183,29 +102,15 @@ def test_wave_tile_kernel_shape():
             m = re.search(r"2XCILi(\d+)ELi(\d+)ELi(\d+)ELi1ELi(\d+)ELi\d+EEE", sym)
             assert m, sym
             env, ctx, hid = int(m.group(1)), int(m.group(2)), int(m.group(3))
-            ins = [x.split("//")[0].strip() for x in ins if x.strip()]
-            assert any(x.startswith("buffer_load_dwordx4") and x.endswith(" lds") for x in ins), "%s: no LDS-DMA weight requests" % sym
-            n_mfma = sum(1 for x in ins if x.startswith("v_mfma_f32_16x16x32_f16"))
+            problems, info = isa_check.check_rollout_wt(sym, ins)      # W1 LDS-DMA, W2 vmcnt(0) in front of every block barrier
+            assert not problems, problems[:3]
             if hid == 200 and env == 0:
                 # layer 0: 13 tiles x (1 or 2) chunks x 3; three hidden layers (the layer loop is unrolled: the activation register
                 # sets swap roles): 13 x 7 x 3 each; head: 3 x 7 x 3 -- with two chunks in layer 0 the 960 MFMAs of a rollout step
                 nc0 = (18 + 6 + ctx + 31) // 32
-                assert n_mfma == 13 * nc0 * 3 + 3 * 13 * 7 * 3 + 3 * 7 * 3, "%s: %d MFMAs" % (sym, n_mfma)
+                assert info["mfma"] == 13 * nc0 * 3 + 3 * 13 * 7 * 3 + 3 * 7 * 3, "%s: %d MFMAs" % (sym, info["mfma"])
             if hid <= 200 and env != 2:
-                scratch = [x for x in ins if x.startswith("scratch_")]
-                assert not scratch, "%s: %d scratch accesses (e.g. %s)" % (sym, len(scratch), scratch[0])
-            # the weight ring is only correct if every wave's LDS-DMA pieces (tracked by vmcnt) have landed BEFORE the block
-            # barrier -- walking back from every s_barrier, a `s_waitcnt vmcnt(0)` must come before any LDS-DMA request
-            for i, x in enumerate(ins):
-                if not x.startswith("s_barrier"):
-                    continue
-                j = i - 1
-                while j >= 0 and not (ins[j].startswith("s_waitcnt") and re.search(r"vmcnt\(0\)", ins[j])):
-                    assert not (ins[j].startswith("buffer_load_dwordx4") and ins[j].endswith(" lds")), \
-                        "%s: an LDS-DMA request at instruction %d reaches the barrier at %d without a vmcnt(0) wait" % (sym, j, i)
-                    assert not ins[j].startswith(("s_barrier", "s_endpgm")), "%s: barrier at %d is not preceded by s_waitcnt vmcnt(0)" % (sym, i)
-                    j -= 1
-                assert j >= 0, "%s: barrier at %d is not preceded by s_waitcnt vmcnt(0)" % (sym, i)
+                assert info["scratch"] == 0, "%s: %d scratch accesses" % (sym, info["scratch"])
             seen += 1
     assert seen >= 5 * 2 * 3
 
@@ -260,3 +165,66 @@ def test_coissue_bench_streams_are_what_they_claim(tmp_path):
             assert all(x.startswith("v_pk_fma_f32") for x in fillers), vname
         if kind == "epipk":
             assert packed, vname
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the same rules on what cadm_amd.jit builds
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump not available")
+def test_jit_build_scans_the_module_it_compiled(tmp_path, monkeypatch):
+    """jit.build cross-compiles a geometry the library does not carry (hidden 144 x 2, context 7, relu), scans the fresh .so with the
+    compiler's own llvm-objdump, writes the report next to the module -- and REFUSES a module that breaks a rule (nothing is left in
+    the cache for a later call to load)."""
+    import json
+    from cadm_amd import _lib, jit
+    if not jit.hipcc():
+        pytest.skip("hipcc not available")
+    monkeypatch.setenv("CADM_JIT_CACHE", str(tmp_path))
+    monkeypatch.setattr(jit, "_memo", {})
+    key = (0, 7, 144, 2, _lib.ACT_KINDS["relu"], 0)
+    path = jit.build(*key)
+    assert os.path.exists(path)
+    rep = json.load(open(path + ".isa.json"))
+    assert rep["checked"] and rep["problems"] == 0 and rep["kernels"] >= 3, rep      # cooperative one / two row tiles + wave-tile
+    assert os.path.basename(rep["objdump"]) == "llvm-objdump"
+    # an independent scan of the cached module agrees
+    assert isa_check.scan(path, which=("rollout_xdl_kernel", "rollout_wt_kernel"))["problems"] == []
+    # a module that breaks a rule is not registered: simulate a compiler that copied a resident fragment
+    real = isa_check.check_rollout_xdl
+
+    def broken(sym, raw):
+        problems, info = real(sym, raw)
+        return problems + ["%s: R1 resident fragment register copied: v_accvgpr_read_b32 v9, a17 (simulated)" % sym], info
+    monkeypatch.setattr(isa_check, "CHECKS", (("rollout_xdl_kernel", broken),) + isa_check.CHECKS[1:])
+    key2 = key[:5] + (2,)
+    with pytest.raises(_lib.CadmError, match="hand-scheduling rules"):
+        jit.build(*key2)
+    assert not os.path.exists(jit.module_path(*key2))
+    assert not [f for f in os.listdir(tmp_path) if ".tmp" in f]
+
+
+@pytest.mark.gpu
+def test_modules_built_on_this_box_were_scanned_and_the_loaded_library_is_clean(gpu):
+    """On the GPU box the JIT runs the BOX's hipcc (a different ROCm point release than the one that built libcadm_hip.so): every module
+    it registered must carry a clean scan report made with that toolchain's llvm-objdump, and the library the process has actually
+    mapped passes the rules too."""
+    import json
+    import numpy as np
+    from cadm_amd import _lib, jit, synth
+    from helpers import make_engine
+    prob = synth.make_problem(env="halfcheetah", context=True, E=5, m=1, H=2, hidden_sizes=(144,) * 2, C=7, seed=3)
+    eng = make_engine(prob, p=5, H=2, hidden_nonlinearity="relu")
+    assert not eng.lib.cadm_rollout_builtin(eng._ctx)
+    plan = eng.cem_plan(prob["obs"], prob["cp_obs"], prob["cp_act"], np.zeros((1, 2, 6)), np.full((1, 2, 6), 0.25), 16, seed=1, call=1)
+    assert np.isfinite(plan.cpu().numpy()).all()
+    mods = [p for p in jit._loaded if "_c7_h144_n2_" in p]
+    assert mods
+    objdump = isa_check.find_objdump(jit.hipcc())
+    assert objdump, "no llvm-objdump next to %s: the JIT could not scan what it built" % jit.hipcc()
+    for p in mods:
+        rep = json.load(open(p + ".isa.json"))
+        assert rep["checked"] and rep["problems"] == 0 and rep["kernels"] >= 2, (p, rep)
+    eng.close()
+    lib_path = next(l.split()[-1] for l in open("/proc/self/maps") if l.rstrip().endswith("libcadm_hip.so"))
+    rep = isa_check.scan(lib_path, objdump)
+    assert rep["kernels"] >= 100 and rep["problems"] == [], rep["problems"][:3]
