@@ -105,6 +105,7 @@ DEV_SIGNATURES = {
     "cadm_dev_set_timing_buffer": (_i, [_P, _P]),
     "cadm_dev_read_adam_moment": (_i, [_P, _i, _i, _i, _i, _P, C.c_long, _P]),
     "cadm_dev_rollout_plan": (_i, [_i, _i, _i, C.POINTER(_i)]),
+    "cadm_dev_rollout_plan_for": (_i, [_i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(C.c_float)]),
     "cadm_dev_set_train_flavour": (_i, [_P, _i]),
     "cadm_dev_refit_sharded": (_i, [_P, _P, _i, _i, _i, _i, _P, _P, _u32, _u32, _i, _P, _P]),
     "cadm_dev_input_checksum": (_i, [_P, _P, _P, _P, _P, _P, _i, _P, _P]),

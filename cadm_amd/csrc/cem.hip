@@ -124,12 +124,35 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
         uint64_t* raw = keys + npow2;
         for (int i = threadIdx.x; i < n; i += blockDim.x) raw[i] = make_key(cand_value(cand, rows, p, G, n_local, m, mi, i, rg.gstride), (uint32_t)i);
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint64_t ki = raw[i];
-            int rank = 0;
-            for (int j = 0; j < n; ++j) rank += raw[j] < ki ? 1 : 0;
-            if (rank < K) keys[rank] = ki;
+        // thread (i, part) counts the keys below key i in its part of the key list, 8 independent LDS reads at a time; the parts meet in
+        // an LDS integer (keys[] is not used yet: its first n words hold the ranks)
+        int* rank_s = reinterpret_cast<int*>(keys);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) rank_s[i] = 0;
+        __syncthreads();
+        {
+            const int parts = (int)blockDim.x / n > 0 ? (int)blockDim.x / n : 1;          // n <= 256, 1024 threads: >= 4
+            const int i = threadIdx.x % n, part = threadIdx.x / n;
+            if (part < parts) {
+                const int qn = (n + parts - 1) / parts, j0 = part * qn, j1 = j0 + qn < n ? j0 + qn : n;
+                const uint64_t ki = raw[i];
+                int cnt = 0, j = j0;
+                for (; j + 8 <= j1; j += 8) {
+                    uint64_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = raw[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) cnt += v[u] < ki ? 1 : 0;
+                }
+                for (; j < j1; ++j) cnt += raw[j] < ki ? 1 : 0;
+                if (cnt) atomicAdd(&rank_s[i], cnt);
+            }
         }
+        __syncthreads();
+        int myrank = -1;
+        uint64_t mykey = 0;
+        if ((int)threadIdx.x < n) { myrank = rank_s[threadIdx.x]; mykey = raw[threadIdx.x]; }
+        __syncthreads();
+        if (myrank >= 0 && myrank < K) keys[myrank] = mykey;
         __syncthreads();
         done = true;
     } else {
@@ -300,103 +323,117 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
 #ifndef CADM_FUSED_EPW
 #define CADM_FUSED_EPW 4      // elements per workgroup: n x EPW <= 1024 samples = one round of the workgroup's threads at n <= 256
 #endif
+// how many of the 64 keys at `q` (LDS, 16-byte aligned, every lane the same address: broadcast reads) are below ki -- the reads are
+// independent and issued 16 keys at a time (a rolled loop with a run-time bound waited out one LDS round trip per key: 2.9 us of the kernel)
+__device__ __forceinline__ int count_below_64(const uint64_t* q, uint64_t ki) {
+    const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(q);
+    int cnt = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        ulonglong2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p2[8 * b + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cnt += (v[j].x < ki ? 1 : 0) + (v[j].y < ki ? 1 : 0);
+    }
+    return cnt;
+}
+// candidate return on the fly (cand_value) with the p row returns fetched as float4s where the layout allows; same left-to-right sum
+__device__ __forceinline__ float cand_value_v4(const float* cand, const float* rows, int p, int G, int n_local, int m, int mi, int ni) {
+    if (!rows) return cand_at(cand, G, n_local, m, mi, ni);
+    const float* r = rows + ((size_t)mi * n_local + ni) * p;
+    float s = 0.0f;
+    if ((p & 3) == 0 && p <= 32 && (reinterpret_cast<uintptr_t>(r) & 15) == 0) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 4 * j < p ? reinterpret_cast<const float4*>(r)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (4 * j < p) { s += v[j].x; s += v[j].y; s += v[j].z; s += v[j].w; }
+    } else {
+        for (int j = 0; j < p; ++j) s += r[j];
+    }
+    return s / (float)p;
+}
 __global__ __launch_bounds__(1024) void cem_refit_sample_kernel(const float* __restrict__ cand, const float* __restrict__ rows, int p, int G,
                                                                int n_local, float* __restrict__ actions, int m, int H, int A, int K, float alpha,
                                                                const float* mean_in, const float* var_in, float* mean_out, float* var_out, float lb,
                                                                float ub, uint32_t seed, uint32_t call, int next_it) {
-    __shared__ uint64_t raw[256];
-    __shared__ uint64_t keys[256];
-    __shared__ int rank_s[256];
-    __shared__ float vals[64 * CADM_FUSED_EPW];      // [K <= 64][EPW] elite values of this workgroup's elements
-    __shared__ float part[64 * CADM_FUSED_EPW];      // [KG <= K <= 64][EPW]
-    __shared__ float nd[2 * CADM_FUSED_EPW], nmean[CADM_FUSED_EPW];
+    __shared__ __attribute__((aligned(16))) uint64_t raw[256];
+    __shared__ uint64_t keys[64];
+    __shared__ int rank_q[4][256];
+    __shared__ float vals[CADM_FUSED_EPW][64];       // [EPW][K <= 64] elite values of this workgroup's elements
+    __shared__ float nd[2 * CADM_FUSED_EPW];
     const int HA = H * A, n = G * n_local, tid = threadIdx.x;
     const int NS = (HA + CADM_FUSED_EPW - 1) / CADM_FUSED_EPW;
     const int mi = blockIdx.x / NS, ta0 = (blockIdx.x % NS) * CADM_FUSED_EPW;
     const int ne = HA - ta0 < CADM_FUSED_EPW ? HA - ta0 : CADM_FUSED_EPW;
+    const int wave = tid >> 6, lane = tid & 63;
     // (requested now, consumed behind the statistics: their round trip used to sit at the end of the kernel's dependent chain)
     float mean_pre = 0.0f, var_pre = 0.0f;
-    if (tid < ne) { mean_pre = mean_in[(size_t)mi * HA + ta0 + tid]; var_pre = var_in[(size_t)mi * HA + ta0 + tid]; }
+    if (wave < ne && lane == 0) { mean_pre = mean_in[(size_t)mi * HA + ta0 + wave]; var_pre = var_in[(size_t)mi * HA + ta0 + wave]; }
     // ---- elites: rank by counting (keys are unique: candidate index in the low word), as cem_refit_kernel's small-n path;
-    //      the n x n comparisons are cut in 4 column quarters (1024 threads), partial ranks meet in integer LDS atomics
-    if (tid < 256) rank_s[tid] = 0;
-    if (tid < n) raw[tid] = make_key(cand_value(cand, rows, p, G, n_local, m, mi, tid), (uint32_t)tid);
+    //      the 256 x 256 comparisons (keys padded with +inf keys) are cut in 4 column quarters of 64 over the 1024 threads
+    if (tid < 256) raw[tid] = tid < n ? make_key(cand_value_v4(cand, rows, p, G, n_local, m, mi, tid), (uint32_t)tid) : ~0ull;
     __syncthreads();
     {
         const int i = tid & 255, quarter = tid >> 8;
-        if (i < n) {
-            const uint64_t ki = raw[i];
-            const int qn = (n + 3) >> 2, j0 = quarter * qn, j1 = j0 + qn < n ? j0 + qn : n;
-            int cnt = 0;
-            for (int j = j0; j < j1; ++j) cnt += raw[j] < ki ? 1 : 0;
-            if (cnt) atomicAdd(&rank_s[i], cnt);
-        }
+        rank_q[quarter][i] = count_below_64(raw + 64 * quarter, raw[i]);
     }
     __syncthreads();
-    if (tid < n && rank_s[tid] < K) keys[rank_s[tid]] = raw[tid];
+    if (tid < n) {
+        const int rk = rank_q[0][tid] + rank_q[1][tid] + rank_q[2][tid] + rank_q[3][tid];
+        if (rk < K) keys[rk] = raw[tid];
+    }
     __syncthreads();
-    // ---- elite values of the owned elements
+    // ---- one WAVE per owned element: its K elite values (lane k: elite k), mean / biased variance in cem_refit_kernel's summation
+    //      order -- KG interleaved groups of up to 16 elites whose partial sums are added in group order ("par"), or one sequential
+    //      sum when that split does not cover K -- the EMA update, and the element's new (mean, var) for the sampling below.
+    //      Everything between the gather and the block barrier is wave-local: LDS round trips without workgroup barriers.
     float* act_m = actions + (size_t)mi * n * HA;
-    for (int q = tid; q < K * ne; q += blockDim.x) {
-        const int k = q / ne, e = q % ne;
-        vals[k * CADM_FUSED_EPW + e] = act_m[(size_t)(keys[k] & 0xFFFFFFFFu) * HA + ta0 + e];
-    }
-    __syncthreads();
-    // ---- mean / biased variance over the elites in cem_refit_kernel's summation order: KG interleaved groups of up to 16
-    //      elites whose partial sums are added in group order ("par"), or one sequential sum when that split does not cover K
-    constexpr int MAXE = 16;
-    const int KG0 = 1024 / HA > 0 ? 1024 / HA : 1;
-    const int KG = KG0 < K ? KG0 : K;
-    const bool par = KG * MAXE >= K;
-    if (par) {
-        for (int q = tid; q < KG * ne; q += blockDim.x) {
-            const int kg = q / ne, e = q % ne;
+    if (wave < ne) {
+        const int e = wave;
+        float* vv = vals[e];
+        vv[lane] = lane < K ? act_m[(size_t)(keys[lane] & 0xFFFFFFFFu) * HA + ta0 + e] : 0.0f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int MAXE = 16;
+        const int KG0 = 1024 / HA > 0 ? 1024 / HA : 1;
+        const int KG = KG0 < K ? KG0 : K;
+        const bool par = KG * MAXE >= K;
+        float nm, nv;
+        if (par) {
             float sum = 0.0f;
-            for (int i = 0; i < MAXE; ++i) { const int k = kg + i * KG; sum += k < K ? vals[k * CADM_FUSED_EPW + e] : 0.0f; }
-            part[kg * CADM_FUSED_EPW + e] = sum;
-        }
-        __syncthreads();
-        if (tid < ne) {
-            float nm = 0.0f;
-            for (int g = 0; g < KG; ++g) nm += part[g * CADM_FUSED_EPW + tid];
-            nmean[tid] = nm / (float)K;                                            // :482
-        }
-        __syncthreads();
-        for (int q = tid; q < KG * ne; q += blockDim.x) {
-            const int kg = q / ne, e = q % ne;
-            const float nm = nmean[e];
+            if (lane < KG)
+                for (int i = 0; i < MAXE; ++i) { const int k = lane + i * KG; sum += k < K ? vv[k] : 0.0f; }
+            nm = 0.0f;
+            for (int g = 0; g < KG; ++g) nm += __shfl(sum, g, 64);
+            nm = nm / (float)K;                                                    // :482
             float qq = 0.0f;
-            for (int i = 0; i < MAXE; ++i) {
-                const int k = kg + i * KG;
-                const float d = (k < K ? vals[k * CADM_FUSED_EPW + e] : 0.0f) - nm;
-                qq += k < K ? d * d : 0.0f;
-            }
-            part[kg * CADM_FUSED_EPW + e] = qq;
-        }
-        __syncthreads();
-        if (tid < ne) {
-            float nv = 0.0f;
-            for (int g = 0; g < KG; ++g) nv += part[g * CADM_FUSED_EPW + tid];
+            if (lane < KG)
+                for (int i = 0; i < MAXE; ++i) {
+                    const int k = lane + i * KG;
+                    const float d = (k < K ? vv[k] : 0.0f) - nm;
+                    qq += k < K ? d * d : 0.0f;
+                }
+            nv = 0.0f;
+            for (int g = 0; g < KG; ++g) nv += __shfl(qq, g, 64);
             nv = nv / (float)K;                                                    // :483
-            const size_t o = (size_t)mi * HA + ta0 + tid;
-            const float mo = mean_pre * alpha + (1.0f - alpha) * nmean[tid];       // :485
+        } else {
+            float sum = 0.0f;
+            for (int k = 0; k < K; ++k) sum += vv[k];
+            nm = sum / (float)K;
+            float v = 0.0f;
+            for (int k = 0; k < K; ++k) { const float d = vv[k] - nm; v += d * d; }
+            nv = v / (float)K;
+        }
+        if (lane == 0) {
+            const size_t o = (size_t)mi * HA + ta0 + e;
+            const float mo = mean_pre * alpha + (1.0f - alpha) * nm;               // :485
             const float vo = var_pre * alpha + (1.0f - alpha) * nv;                // :486
             mean_out[o] = mo; var_out[o] = vo;
-            nd[tid] = mo; nd[CADM_FUSED_EPW + tid] = vo;
-        }
-    } else {
-        if (tid < ne) {
-            float sum = 0.0f;
-            for (int k = 0; k < K; ++k) sum += vals[k * CADM_FUSED_EPW + tid];
-            const float nm = sum / (float)K;
-            float v = 0.0f;
-            for (int k = 0; k < K; ++k) { const float d = vals[k * CADM_FUSED_EPW + tid] - nm; v += d * d; }
-            const float nv = v / (float)K;
-            const size_t o = (size_t)mi * HA + ta0 + tid;
-            const float mo = mean_pre * alpha + (1.0f - alpha) * nm;
-            const float vo = var_pre * alpha + (1.0f - alpha) * nv;
-            mean_out[o] = mo; var_out[o] = vo;
-            nd[tid] = mo; nd[CADM_FUSED_EPW + tid] = vo;
+            nd[e] = mo; nd[CADM_FUSED_EPW + e] = vo;
         }
     }
     __syncthreads();

@@ -194,8 +194,13 @@ int cadm_launch_input_checksum(cadm_ctx* ctx, const float* obs, const float* cp_
 int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs,
                         float* out, hipStream_t s);
 // Per-call inputs of a small planner call travel as KERNEL ARGUMENTS (cadm_cem_plan_staged, capi.hip): up to CADM_INGEST_MAX floats.
-#define CADM_INGEST_MAX 896
+#define CADM_INGEST_MAX 960
 struct IngestBlock { float v[CADM_INGEST_MAX]; };
+// the fused head's copy of the block shares the 4 KB kernel-argument segment with the encoder's and the sampler's arguments: a smaller cap
+// (blocks between the two caps take the plain ingest kernel + the unfused head)
+#define CADM_HEAD_INGEST_MAX 896
+struct HeadBlock { float v[CADM_HEAD_INGEST_MAX]; };
+#define CADM_CONTEXT_BATCHED_MIN_ROWS 48    // histories per member from which the context encoder runs as a GEMM chain (context.hip)
 // The head of a staged planner call as ONE launch (context.hip: plan_head_kernel): unpack the ingest block into the device block, the
 // context encoder on the block's history (C > 0), and the candidates of CEM iteration 0.  off[5] = float offsets of obs, cp_obs,
 // cp_act, init_mean, init_var inside the block (-1: absent).

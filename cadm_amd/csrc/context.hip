@@ -8,7 +8,7 @@
 #include "common.h"
 
 #define CP_MAX_WIDTH 1024
-#define CADM_CONTEXT_BATCHED_MIN_ROWS 48    // per member: below, one latency-tuned workgroup per row (the planner's m = 1..10)
+// (CADM_CONTEXT_BATCHED_MIN_ROWS, common.h: below it, one latency-tuned workgroup per row -- the planner's m = 1..10)
 
 struct CpArgs {
     const float* W[CADM_MAX_CP_LAYERS + 1];
@@ -119,7 +119,7 @@ struct PlanHeadArgs {
     int n, H, A; float lb, ub; uint32_t seed, call;
     float* actions;
 };
-__global__ __launch_bounds__(CP_THREADS) void plan_head_kernel(const IngestBlock blk, const CpArgs a, const PlanHeadArgs x) {
+__global__ __launch_bounds__(CP_THREADS) void plan_head_kernel(const HeadBlock blk, const CpArgs a, const PlanHeadArgs x) {
     const int b = blockIdx.x;
     if (b < x.ctx_blocks) {
         const int e = b / a.m, mi = b % a.m;
@@ -398,8 +398,8 @@ static int context_args(cadm_ctx* ctx, CpArgs& a) {
 
 int cadm_launch_plan_head(cadm_ctx* ctx, const float* host_block, int nfloats, const int32_t off[5], float* dev_block, int m, int n,
                           uint32_t seed, uint32_t call, float* ctx_out, float* actions_out, hipStream_t s) {
-    CADM_REQUIRE(nfloats > 0 && nfloats <= CADM_INGEST_MAX && off[3] >= 0 && off[4] >= 0, "plan head: bad ingest block");
-    static_assert(sizeof(IngestBlock) + sizeof(CpArgs) + sizeof(PlanHeadArgs) <= 4096, "kernel argument block");
+    CADM_REQUIRE(nfloats > 0 && nfloats <= CADM_HEAD_INGEST_MAX && off[3] >= 0 && off[4] >= 0, "plan head: bad ingest block");
+    static_assert(sizeof(HeadBlock) + sizeof(CpArgs) + sizeof(PlanHeadArgs) <= 4096, "kernel argument block");
     CpArgs a{};
     PlanHeadArgs x{};
     if (ctx->C > 0) {
@@ -417,7 +417,7 @@ int cadm_launch_plan_head(cadm_ctx* ctx, const float* host_block, int nfloats, c
     const size_t total = (size_t)m * n * ctx->H * ctx->A;
     size_t sb = (total + CP_THREADS - 1) / CP_THREADS;
     if (sb > 2048) sb = 2048;
-    IngestBlock blk;
+    HeadBlock blk;
     memcpy(blk.v, host_block, (size_t)nfloats * sizeof(float));
     hipLaunchKernelGGL(plan_head_kernel, dim3(x.ctx_blocks + 1 + (unsigned)sb), dim3(CP_THREADS), 0, s, blk, a, x);
     CADM_CHECK_HIP(hipGetLastError());

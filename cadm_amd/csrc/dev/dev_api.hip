@@ -68,6 +68,15 @@ extern "C" int cadm_dev_rollout_plan(int units, int two_tile_ok, int wave_tile_o
     return CADM_OK;
 }
 
+extern "C" int cadm_dev_rollout_plan_for(int units, int two_tile_ok, int wave_tile_ok, int env_kind, int hid, int* count_out, float* costs_out) {
+    CADM_REQUIRE(units >= 0 && count_out, "cadm_dev_rollout_plan_for: bad argument");
+    int count[4];
+    const XdlCosts c = xdl_costs(env_kind, hid);
+    xdl_plan_units(units, two_tile_ok != 0, wave_tile_ok != 0, count, c);
+    for (int o = 0; o < 4; ++o) { count_out[o] = count[o]; if (costs_out) costs_out[o] = c.c[o]; }
+    return CADM_OK;
+}
+
 extern "C" int cadm_dev_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf) {
     CADM_REQUIRE(ctx, "cadm_dev_set_timing_buffer: null ctx");
     ctx->tbuf = (unsigned long long*)dev_u64_buf;

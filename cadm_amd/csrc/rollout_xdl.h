@@ -1136,10 +1136,10 @@ namespace {
 // A member's row tiles are cut between the kernel flavours, launch after launch (rows are independent and the flavours agree bit
 // for bit, so the cut changes no result):
 //   cooperative, one row tile per workgroup  (cap = one tile per CU of the member's share: cfg2)         cost 1
-//   cooperative, two row tiles per workgroup (cap 2x)                                                    cost CADM_COST_MT2
-//   wave-tile, 4 tiles per workgroup (one wave per SIMD; cap 4x)                                         cost CADM_COST_WT4
-//   wave-tile, 8 tiles per workgroup (cap 8x, any number of rounds)                                      cost CADM_COST_WT8 per round
-// (xdl_geo.h: xdl_plan_units -- costs in units of the one-tile launch, a small dynamic programme over units of one CU share.)
+//   cooperative, two row tiles per workgroup (cap 2x)                                                    cost xdl_costs(ENV, HID).c[1]
+//   wave-tile, 4 tiles per workgroup (one wave per SIMD; cap 4x)                                         cost .c[2]
+//   wave-tile, 8 tiles per workgroup (cap 8x, any number of rounds)                                      cost .c[3] per round
+// (xdl_geo.h: xdl_plan_units -- costs in units of the one-tile launch, per instantiation; a small dynamic programme over units of one CU share.)
 template <int ENV, int C, int HID, int NH, int ACT, int NOISE = -1>
 int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a0, int rows_per_member, hipStream_t s) {
     using G1 = XC<ENV, C, HID, 1, NH, ACT>;
@@ -1174,7 +1174,7 @@ int xdl_launch(cadm_ctx* ctx, const RolloutArgs& a0, int rows_per_member, hipStr
     const int units = (tiles + per_member - 1) / per_member;
     const int capu[4] = {1, 2, 4, 8};
     int count[4];
-    xdl_plan_units(units, mt2_ok, wt_ok, count);
+    xdl_plan_units(units, mt2_ok, wt_ok, count, xdl_costs(ENV, HID));
     int rem = tiles, t0 = 0;
     for (int o = 3; o >= 0 && rem > 0; --o) {      // biggest flavour first: the last launch takes the ragged rest
         if (!count[o]) continue;

@@ -97,9 +97,17 @@ __host__ __device__ constexpr int xdl_frag_index(int ntw, int nchl, int ti, int 
 //           1: cooperative kernel, two row tiles per workgroup  cap 2        CADM_COST_MT2
 //           2: wave-tile kernel, 4 tiles per workgroup           cap 4        CADM_COST_WT4   (one wave per SIMD: never wins, exists for the tests)
 //           3: wave-tile kernel, 8 tiles per workgroup           cap 8        CADM_COST_WT8   (per round)
-// 1 unit = one CU share of the member (n_cus / E tiles); costs in units of the one-tile launch, measured at the cfg2 / cfg3 geometry
-// (halfcheetah, 51 workgroups per member: 165 / 261 / 600 / 876 us, profiles/r4_s3_flavour_table.txt).  The cheapest cover is a small
+// 1 unit = one CU share of the member (n_cus / E tiles); costs in units of the one-tile launch (halfcheetah at the cfg2 / cfg3 geometry,
+// 51 workgroups per member: 165 / 261 / 600 / 876 us, profiles/r4_s3_flavour_table.txt).  The cheapest cover is a small
 // dynamic programme, f(u) = min over flavours (cost + f(u - cap)); count[o] = launches (rounds) of flavour o.
+// The costs are a property of the INSTANTIATION (env kind -> observation width -> state phase and head; hidden width -> tiles per wave):
+// xdl_costs(env, hid) is a constexpr of the launcher's template arguments, filled from tools/flavour_table.py runs
+//   halfcheetah, HID 200 (profiles/r4_s3_flavour_table.txt):   1 / 1.60 / 3.6 / 5.3
+//   slim humanoid, HID 200 (profiles/r5_*):          1 / 1.74 / 3.8 / 5.5   (45 dims: 6 pair slots per lane, longer state phase)
+// Geometries nobody measured use halfcheetah's.  -DCADM_COST_MT2=.. etc. override every instantiation (tools/build_variant.sh experiments).
+struct XdlCosts { float c[4]; };
+__host__ __device__ constexpr XdlCosts xdl_costs(int env_kind, int hid) {
+#if defined(CADM_COST_MT2) || defined(CADM_COST_WT4) || defined(CADM_COST_WT8)
 #ifndef CADM_COST_MT2
 #define CADM_COST_MT2 1.6f
 #endif
@@ -109,9 +117,14 @@ __host__ __device__ constexpr int xdl_frag_index(int ntw, int nchl, int ti, int 
 #ifndef CADM_COST_WT8
 #define CADM_COST_WT8 5.3f
 #endif
-inline void xdl_plan_units(int units, bool mt2_ok, bool wt_ok, int (&count)[4]) {
+    return XdlCosts{{1.0f, CADM_COST_MT2, CADM_COST_WT4, CADM_COST_WT8}};
+#else
+    return env_kind == 2 /* CADM_ENV_SLIM_HUMANOID */ ? XdlCosts{{1.0f, 1.74f, 3.8f, 5.5f}} : XdlCosts{{1.0f, 1.6f, 3.6f, 5.3f}};
+#endif
+}
+inline void xdl_plan_units(int units, bool mt2_ok, bool wt_ok, int (&count)[4], XdlCosts costs = xdl_costs(0, 200)) {
     const int capu[4] = {1, mt2_ok ? 2 : 0, wt_ok ? 4 : 0, wt_ok ? 8 : 0};
-    const float cost[4] = {1.0f, CADM_COST_MT2, CADM_COST_WT4, CADM_COST_WT8};
+    const float* cost = costs.c;
     for (int o = 0; o < 4; ++o) count[o] = 0;
     // beyond 64 units the answer is "rounds of the biggest flavour" plus the plan of the rest
     const int big = capu[3] ? 3 : capu[1] ? 1 : 0;

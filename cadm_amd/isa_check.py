@@ -98,36 +98,59 @@ def _addr(line):
     return int(m.group(1), 16) if m else None
 
 
-def reachable_from(ins, start):
-    """Indices of the instructions reachable from instruction `start` by control flow (fall-through + direct branches).  An indirect
-    jump (s_setpc / s_swappc) makes everything reachable: the conservative answer."""
+def _successors(ins):
+    """per-instruction successor lists (fall-through + direct branches), or None when the function has an indirect jump / a branch whose
+    target cannot be decoded: the caller then takes the conservative answer"""
     addr = [_addr(x) for x in ins]
     base = addr[0]
     at = {a: i for i, a in enumerate(addr) if a is not None}
     text = strip(ins)
     if any(t.startswith(("s_setpc", "s_swappc")) for t in text):
-        return set(range(len(ins)))
-    succ = {}
+        return None
+    succ = []
     for i, t in enumerate(text):
         nxt = []
-        is_branch = t.startswith(("s_branch", "s_cbranch"))
-        if is_branch:
+        if t.startswith(("s_branch", "s_cbranch")):
             m = re.search(r"<[^>]*\+0x([0-9a-fA-F]+)>", ins[i])
             tgt = at.get(base + int(m.group(1), 16)) if m else None
-            if tgt is None:                       # a target outside the function / not decodable: be conservative
-                return set(range(len(ins)))
+            if tgt is None:
+                return None
             nxt.append(tgt)
         if not t.startswith(("s_branch", "s_endpgm")) and i + 1 < len(ins):
             nxt.append(i + 1)
-        succ[i] = nxt
+        succ.append(nxt)
+    return succ
+
+
+def _reach(succ, start, avoid=-1):
     seen, stack = set(), [start]
     while stack:
         i = stack.pop()
-        if i in seen:
+        if i in seen or i == avoid:
             continue
         seen.add(i)
         stack.extend(succ[i])
     return seen
+
+
+def reachable_from(ins, start):
+    """Indices of the instructions reachable from instruction `start` by control flow (fall-through + direct branches).  An indirect
+    jump (s_setpc / s_swappc) makes everything reachable: the conservative answer."""
+    succ = _successors(ins)
+    if succ is None:
+        return set(range(len(ins)))
+    return _reach(succ, start)
+
+
+def dominated_by(ins, node):
+    """Indices of the instructions DOMINATED by instruction `node`: every path from the function's entry to them passes through it
+    (reachable from the entry, but not once `node` is taken out of the graph).  This is "the code that runs with what `node` did in
+    effect" without knowing the values a branch tests: hipcc merges the tails of the kernel's wave variants into shared blocks guarded by
+    flags, so plain reachability leaks from one variant into the next; dominance does not."""
+    succ = _successors(ins)
+    if succ is None:
+        return set(range(len(ins)))
+    return (_reach(succ, 0) - _reach(succ, 0, avoid=node)) | {node}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -150,35 +173,37 @@ def check_rollout_xdl(sym, raw):
     if not loads:
         return problems, info
     mfma_at = [i for i, x in enumerate(ins) if x.startswith("v_mfma_")]
-    # The kernel body exists once per wave variant (tiles per wave); each variant loads ITS resident fragments with a burst of loads and
-    # keeps them to the end.  variant k = [its prologue][burst of resident loads][tile loop][unconditional branch to the common exit]:
-    # a boundary is the first s_branch / s_endpgm behind the last MFMA that precedes the next burst.
+    # The kernel body exists once per wave variant (tiles per wave: a scalar branch at the kernel's entry picks one, they meet again at
+    # s_endpgm); a variant with resident fragments loads them with a burst of loads in its prologue and keeps them to the end.  What a burst
+    # pins is decided by CONTROL FLOW: the instructions DOMINATED by the burst's first load (every path from the kernel's entry to them
+    # runs through it) are that variant's "fragments are live" region -- a variant WITHOUT resident fragments (one hidden layer: nothing to
+    # pin on the waves that own no head tile) is not dominated by another variant's burst and may use any AGPR as spill space, as may the
+    # prologue in front of a burst.  (Plain reachability is too coarse: hipcc merges the variants' tails into shared, flag-guarded blocks.)
     bursts = []
     for k, i in enumerate(loads):
         if k == 0 or any(loads[k - 1] < m < i for m in mfma_at):
             bursts.append(i)
-    starts = [0]
-    for nb in bursts[1:]:
-        last = max(i for i in mfma_at if i < nb)
-        end = next((i for i in range(last, nb) if ins[i].startswith(("s_branch", "s_endpgm"))), None)
-        if end is None:
-            problems.append("%s: cannot delimit the wave variants (no branch between an MFMA and the next burst of resident loads)" % sym)
-            return problems, info
-        starts.append(end + 1)
-    for k, b in enumerate(starts):
-        e = starts[k + 1] if k + 1 < len(starts) else len(ins)
+    covered = set()
+    for b0 in bursts:
+        live = dominated_by(raw, b0)
+        covered |= live
         resident = set()
         for i in loads:
-            if b <= i < e:
+            if i in live:
                 m2 = re.match(r"buffer_load_dwordx4 a\[(\d+):(\d+)\]", ins[i])
                 resident.update(range(int(m2.group(1)), int(m2.group(2)) + 1))
-        for x in ins[b:e]:
+        for i in sorted(live):
+            x = ins[i]
             m2 = re.match(r"v_accvgpr_write_b32 a(\d+),", x) or re.match(r"v_accvgpr_read_b32 v\d+, a(\d+)", x)
             if m2 and int(m2.group(1)) in resident:
                 problems.append("%s: R1 resident fragment register copied: %s" % (sym, x))
             m2 = re.match(r"v_mfma_f32_16x16x32_f16 v\[\d+:\d+\], a\[(\d+):(\d+)\], v\[", x)
             if m2 and not set(range(int(m2.group(1)), int(m2.group(2)) + 1)) <= resident:
                 problems.append("%s: R1 MFMA reads an AGPR operand that is not a resident fragment: %s" % (sym, x))
+    # an asm MFMA that reads an AGPR operand outside every burst's region has no fragment to read
+    for i, x in enumerate(ins):
+        if i not in covered and re.match(r"v_mfma_f32_16x16x32_f16 v\[\d+:\d+\], a\[", x):
+            problems.append("%s: R1 MFMA reads an AGPR operand on a path without resident loads: %s" % (sym, x))
     for i in loads:
         m2 = re.match(r"buffer_load_dwordx4 a\[\d+:\d+\], v\d+, s\[\d+:\d+\], (s\d+) offen", ins[i])
         if not m2:

@@ -65,3 +65,28 @@ def test_huge_batches_stay_bounded():
         assert cnt[3] >= (units - 64) // 8          # beyond the table: rounds of the biggest flavour
         cnt = plan(units, wave=False)
         assert cnt[2] == cnt[3] == 0 and sum(n * c for n, c in zip(cnt, CAP)) >= units
+
+
+def test_cost_table_is_per_instantiation():
+    """VERDICT r5 #3a: the plan's costs are a constexpr of the launcher's instantiation (xdl_geo.h: xdl_costs(env, hid)), not four global
+    constants: slim humanoid's measured table differs from halfcheetah's, and each table's plan is the cheapest cover under ITS costs."""
+    global COST
+    lib = _lib.load_dev()
+    tables = {}
+    for env_kind, hid in ((0, 200), (2, 200), (1, 256)):
+        cnt, costs = (ct.c_int * 4)(), (ct.c_float * 4)()
+        assert lib.cadm_dev_rollout_plan_for(5, 1, 1, env_kind, hid, cnt, costs) == 0
+        tables[(env_kind, hid)] = tuple(round(float(c), 3) for c in costs)
+        saved = COST
+        try:
+            COST = tuple(float(c) for c in costs)
+            for units in range(1, 33):
+                assert lib.cadm_dev_rollout_plan_for(units, 1, 1, env_kind, hid, cnt, None) == 0
+                got = tuple(cnt)
+                assert sum(n * c for n, c in zip(got, CAP)) >= units
+                assert sum(n * c for n, c in zip(got, COST)) <= brute(units) + 1e-4, (env_kind, hid, units, got)
+        finally:
+            COST = saved
+    assert tables[(0, 200)] == (1.0, 1.6, 3.6, 5.3)
+    assert tables[(2, 200)] == (1.0, 1.74, 3.8, 5.5)          # slim humanoid (profiles/r5: measured 1 / 1.74 / 3.8 / 5.5)
+    assert tables[(1, 256)] == tables[(0, 200)]               # unmeasured geometries use halfcheetah's
