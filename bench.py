@@ -312,10 +312,10 @@ class Planner:
             # _sharding()), the run still measures, but the line SAYS SO: `collective` names the fallback, `rccl_nranks` is 0 and
             # `degraded` is set -- never a silent substitution.
             self.rccl_nranks, rccl_rank = self.eng.dist_info()
-            if self.eng.dist_world == self.world and self.rccl_nranks == self.world and rccl_rank == self.rank:
+            if self.eng._ext is None and self.eng.dist_world == self.world and self.rccl_nranks == self.world and rccl_rank == self.rank:
                 self.collective = "rccl all-gather in libcadm_hip.so"
             else:
-                self.collective = ("FALLBACK: torch.distributed all_gather per CEM iteration (in-library RCCL communicator unavailable: "
+                self.collective = ("FALLBACK: torch.distributed all_gather plugged into the library's sharded planner (in-library RCCL communicator unavailable: "
                                    "dist_world=%d rccl nranks=%d rank=%d, expected %d / %d)" % (self.eng.dist_world, self.rccl_nranks, rccl_rank, self.world, self.rank))
                 self.rccl_nranks = 0
                 self.degraded = True
@@ -345,14 +345,11 @@ class Planner:
         torch.cuda.synchronize(eng.device)
 
     def plan_device(self, c):
-        """One planner call on HBM-resident inputs.  Sharded: the model's own negotiation (`_sharding`: in-library RCCL communicator
-        on every rank, or -- all ranks together -- torch.distributed's all-gather per CEM iteration) decides the path."""
+        """One planner call on HBM-resident inputs.  Sharded: the library's loop on every rank; the model's negotiation (`_sharding`) picks
+        its collective -- the in-library RCCL communicator on every rank, or, all ranks together, torch.distributed's all-gather plugged in."""
         cp_obs, cp_act = (self.cp_obs, self.cp_act) if self.cfg["context"] else (None, None)
-        shard, fused = self.model._sharding()
-        if fused:
-            return self.eng.cem_plan(self.obs, cp_obs, cp_act, self.init_mean, self.init_var, self.n, seed=0, call=c)
-        from cadm_amd import planner as hplanner
-        return hplanner.cem_plan(self.eng, self.obs, cp_obs, cp_act, self.init_mean, self.init_var, self.n, seed=0, call=c, shard=shard)
+        self.model._sharding()
+        return self.eng.cem_plan(self.obs, cp_obs, cp_act, self.init_mean, self.init_var, self.n, seed=0, call=c)
 
     def run_api(self, steps, warmup):
         """K get_action calls through the class, warm start shifted between calls (sampler.py:118-120)."""

@@ -97,7 +97,11 @@ SIGNATURES = {
     "cadm_dist_init": (_i, [_P, C.c_char_p, _i, _i]),
     "cadm_dist_destroy": (_i, [_P]),
     "cadm_dist_info": (_i, [_P, C.POINTER(_i), C.POINTER(_i)]),
+    "cadm_dist_init_external": (_i, [_P, _i, _i, C.c_void_p, _P]),
+    "cadm_dist_mismatch": (_i, [_P, C.POINTER(_i), _P]),
 }
+# int fn(void* user, const void* send, void* recv, size_t count, void* stream)  (include/cadm_hip.h: cadm_allgather_fn)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 # developer entry points (csrc/dev/dev_api.h): only in libcadm_hip_dev.so, typed by load_dev()
 DEV_SIGNATURES = {

@@ -112,6 +112,10 @@ __global__ void cem_refit_kernel(const float* __restrict__ cand, const float* __
         if (rg.gstride > 0 && rg.my_rank >= 0) {
             const unsigned mine = __float_as_uint(cand[(size_t)rg.my_rank * rg.gstride + (size_t)m * n_local]);
             for (int g = 0; g < G; ++g) bad |= __float_as_uint(cand[(size_t)g * rg.gstride + (size_t)m * n_local]) != mine;
+            // the mismatch has its own signal (cadm_dist_mismatch / the words behind a staged call's completion flags): a NaN plan alone
+            // is also what a single-rank call returns for a non-finite observation
+            if (bad && rg.mismatch) atomicOr(rg.mismatch, 1u);
+            if (bad && rg.mismatch_host) rg.mismatch_host[mi] = 1u;      // (fenced to system scope with the plan, below)
         }
         poison_s = bad;
     }
@@ -536,8 +540,8 @@ extern "C" int cadm_sample_uniform(cadm_ctx* ctx, uint32_t seed, uint32_t call, 
     return CADM_OK;
 }
 
-// Checksum of the replicated per-call inputs of a sharded planner call: position-weighted sum of the raw 32-bit patterns, modulo 2^32
-// (exact, order-independent accumulation; NaN-safe; a permutation or a single changed bit changes it).  One workgroup.
+// Checksum of the replicated per-call inputs of a sharded planner call: position-weighted sum of the (canonicalised) 32-bit patterns, modulo 2^32
+// (exact, order-independent accumulation; NaN-safe; a permutation or a single changed value changes it).  One workgroup.
 __global__ void input_checksum_kernel(const float* a0, int n0, const float* a1, int n1, const float* a2, int n2, const float* a3, int n3,
                                       const float* a4, int n4, unsigned* out) {
     __shared__ unsigned red[256];
@@ -546,7 +550,13 @@ __global__ void input_checksum_kernel(const float* a0, int n0, const float* a1, 
     unsigned h = 0u, base = 1u;
     for (int q = 0; q < 5; ++q) {
         if (ptr[q])
-            for (int i = threadIdx.x; i < cnt[q]; i += blockDim.x) h += __float_as_uint(ptr[q][i]) * (2u * (base + (unsigned)i) + 1u);
+            for (int i = threadIdx.x; i < cnt[q]; i += blockDim.x) {
+                // inputs are compared BY VALUE: -0.0 is +0.0, every NaN is the canonical quiet NaN (numerically equal inputs
+                // with different bit patterns must not poison a plan)
+                const float v = ptr[q][i];
+                const unsigned bits = v != v ? 0x7fc00000u : v == 0.0f ? 0u : __float_as_uint(v);
+                h += bits * (2u * (base + (unsigned)i) + 1u);
+            }
         base += (unsigned)cnt[q] + 7u;
     }
     red[threadIdx.x] = h;

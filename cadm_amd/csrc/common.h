@@ -27,7 +27,7 @@ void cadm_set_error(const char* fmt, ...);
 #define CADM_HID_LIST 200              // the reference default --hidden_size (run_cadm_pets.py:129)
 #endif
 // bumped whenever cadm_ctx / RolloutArgs change: a side module built against another layout is refused
-#define CADM_CTX_LAYOUT_TAG 3003
+#define CADM_CTX_LAYOUT_TAG 3004
 
 #define CADM_CHECK_HIP(expr)                                                                   \
     do {                                                                                       \
@@ -150,9 +150,13 @@ struct cadm_ctx {
     // completion flags of a staged planner call (cadm_cem_plan_staged): [m] words in pinned host memory, released by the last refit
     unsigned* plan_done = nullptr;
     unsigned plan_done_val = 0;
-    // RCCL communicator for candidate-sharded planning (dist.hip)
+    // candidate-sharded planning (dist.hip): the RCCL communicator the ctx owns, OR an all-gather supplied by the host
+    // (cadm_dist_init_external: torch.distributed over any backend) -- the planner loop is the same, only the collective differs
     void* comm = nullptr;
     int nranks = 1, rank = 0;
+    cadm_allgather_fn ext_allgather = nullptr;
+    void* ext_user = nullptr;
+    unsigned* dist_flag = nullptr;   // device word: set by the sharded refit when the ranks' input checksums differ (cadm_dist_mismatch)
     // second packed copy of the planner weights for the wave-tile kernel (rollout_wt.h): ONE consumption order for every wave
     XdlGeo xg1;
     unsigned short* xw1 = nullptr;  // [E][member_frags of xg1] fragments of 2 KB
@@ -188,7 +192,10 @@ struct RefitRegen {
     float lb, ub;
     int gstride;               // floats per rank in the gathered buffer (0: m * n_local); m * n_local + 1 with the trailing checksum
     int my_rank;               // >= 0: compare every rank's checksum with this rank's; mismatch -> NaN plan
+    unsigned* mismatch;        // device word raised on a checksum mismatch (ctx->dist_flag), may be null
+    unsigned* mismatch_host;   // pinned host words [m] behind the completion flags of a staged call, may be null
 };
+inline bool cadm_sharded(const cadm_ctx* c) { return c->comm != nullptr || c->ext_allgather != nullptr; }
 int cadm_launch_input_checksum(cadm_ctx* ctx, const float* obs, const float* cp_obs, const float* cp_act, const float* mean, const float* var,
                                int m, unsigned* out, hipStream_t s);
 int cadm_launch_context(cadm_ctx* ctx, const float* cp_obs, const float* cp_act, int m, int bs,

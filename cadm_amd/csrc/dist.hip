@@ -56,6 +56,13 @@ int check_nccl(int rc, const char* what) {
 }
 }  // namespace
 
+static int dist_flag_alloc(cadm_ctx* ctx) {
+    if (ctx->dist_flag) return CADM_OK;
+    CADM_CHECK_HIP(hipMalloc(&ctx->dist_flag, sizeof(unsigned)));
+    CADM_CHECK_HIP(hipMemset(ctx->dist_flag, 0, sizeof(unsigned)));
+    return CADM_OK;
+}
+
 extern "C" int cadm_dist_unique_id(char out_id[128]) {
     CADM_REQUIRE(out_id, "cadm_dist_unique_id: null argument");
     int rc = load_rccl();
@@ -65,7 +72,7 @@ extern "C" int cadm_dist_unique_id(char out_id[128]) {
 
 extern "C" int cadm_dist_init(cadm_ctx* ctx, const char id[128], int nranks, int rank) {
     CADM_REQUIRE(ctx && id && nranks >= 1 && rank >= 0 && rank < nranks, "cadm_dist_init: bad arguments");
-    CADM_REQUIRE(!ctx->comm, "cadm_dist_init: communicator already initialised");
+    CADM_REQUIRE(!cadm_sharded(ctx), "cadm_dist_init: communicator already initialised");
     int rc = load_rccl();
     if (rc) return rc;
     CADM_CHECK_HIP(hipSetDevice(ctx->device));
@@ -84,18 +91,47 @@ extern "C" int cadm_dist_init(cadm_ctx* ctx, const char id[128], int nranks, int
         }
         if (rc) { g_rccl.destroy(comm); return rc; }
     }
+    if ((rc = dist_flag_alloc(ctx))) { g_rccl.destroy(comm); return rc; }
     ctx->comm = comm;
     ctx->nranks = nranks;
     ctx->rank = rank;
     return CADM_OK;
 }
 
+extern "C" int cadm_dist_init_external(cadm_ctx* ctx, int nranks, int rank, cadm_allgather_fn fn, void* user) {
+    CADM_REQUIRE(ctx && fn && nranks >= 1 && rank >= 0 && rank < nranks, "cadm_dist_init_external: bad arguments");
+    CADM_REQUIRE(!cadm_sharded(ctx), "cadm_dist_init_external: the ctx already has a communicator");
+    CADM_ON_DEVICE(ctx);
+    const int rc = dist_flag_alloc(ctx);
+    if (rc) return rc;
+    ctx->ext_allgather = fn;
+    ctx->ext_user = user;
+    ctx->nranks = nranks;
+    ctx->rank = rank;
+    return CADM_OK;
+}
+
 extern "C" int cadm_dist_destroy(cadm_ctx* ctx) {
-    if (!ctx || !ctx->comm) return CADM_OK;
-    g_rccl.destroy(ctx->comm);
+    if (!ctx) return CADM_OK;
+    if (ctx->comm) g_rccl.destroy(ctx->comm);
     ctx->comm = nullptr;
+    ctx->ext_allgather = nullptr;
+    ctx->ext_user = nullptr;
     ctx->nranks = 1;
     ctx->rank = 0;
+    return CADM_OK;
+}
+
+extern "C" int cadm_dist_mismatch(cadm_ctx* ctx, int* mismatch_out, void* stream) {
+    CADM_REQUIRE(ctx && mismatch_out, "cadm_dist_mismatch: null argument");
+    *mismatch_out = 0;
+    if (!ctx->dist_flag) return CADM_OK;
+    CADM_ON_DEVICE(ctx);
+    unsigned v = 0;
+    CADM_CHECK_HIP(hipMemcpyAsync(&v, ctx->dist_flag, sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CADM_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (v) CADM_CHECK_HIP(hipMemsetAsync(ctx->dist_flag, 0, sizeof(unsigned), (hipStream_t)stream));
+    *mismatch_out = v ? 1 : 0;
     return CADM_OK;
 }
 
@@ -103,6 +139,7 @@ extern "C" int cadm_dist_info(cadm_ctx* ctx, int* nranks_out, int* rank_out) {
     CADM_REQUIRE(ctx && nranks_out && rank_out, "cadm_dist_info: null argument");
     *nranks_out = 1;
     *rank_out = 0;
+    if (ctx->ext_allgather) { *nranks_out = ctx->nranks; *rank_out = ctx->rank; return CADM_OK; }      // host-supplied collective
     if (!ctx->comm) return CADM_OK;                         // single-GPU planner: no communicator
     CADM_REQUIRE(g_rccl.count && g_rccl.user_rank, "cadm_dist_info: librccl lacks ncclCommCount / ncclCommUserRank");
     int rc = check_nccl(g_rccl.count(ctx->comm, nranks_out), "ncclCommCount");
@@ -112,6 +149,11 @@ extern "C" int cadm_dist_info(cadm_ctx* ctx, int* nranks_out, int* rank_out) {
 
 // [count] floats per rank -> [nranks * count] on every rank (ncclFloat32 = 7)
 int cadm_dist_allgather(cadm_ctx* ctx, const float* send, float* recv, size_t count, hipStream_t s) {
+    if (ctx->ext_allgather) {
+        const int rc = ctx->ext_allgather(ctx->ext_user, send, recv, count, (void*)s);
+        if (rc) { cadm_set_error("cadm_dist_allgather: the host-supplied all-gather failed (code %d)", rc); return CADM_EHIP; }
+        return CADM_OK;
+    }
     if (!ctx->comm) { cadm_set_error("cadm_dist_allgather: no communicator"); return CADM_ESTATE; }
     return check_nccl(g_rccl.allgather(send, recv, count, 7, ctx->comm, s), "ncclAllGather");
 }

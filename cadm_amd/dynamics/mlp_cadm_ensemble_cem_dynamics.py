@@ -253,28 +253,37 @@ class MLPEnsembleCEMDynamicsModel(object):
             raise ValueError("get_action: cem_init_mean and cem_init_var must be given together")
 
     def _sharding(self):
-        """Candidate shard of this rank + whether the in-library RCCL path is usable on EVERY rank of the group."""
+        """Candidate shard of this rank.  The sharded planner is the library's loop on every rank; what is negotiated on first use is
+        only its collective: the ctx's own RCCL communicator when EVERY rank of the group can build one (backend nccl, one GPU per
+        rank), else -- all ranks together -- torch.distributed's all-gather through `cadm_dist_init_external`.  (The second element,
+        always True, is kept for callers that asked "is the plan one library call?")"""
         if self._group is None:         # never sharded (the default): nothing to negotiate
             if self._shard1 is None or self._shard1.n != self.n_candidates:
                 self._shard1 = _planner.Shard(self.n_candidates)
             return self._shard1, True
         shard = _planner.Shard.from_group(self.n_candidates, self._group)
-        if shard.world > 1 and self.engine.dist_world == 1 and not self._dist_failed:
+        if shard.world > 1 and self.engine.dist_world == 1:
             import torch.distributed as dist
-            ok = 1.0
-            try:       # in-library RCCL communicator: the whole sharded planner stays on the stream
-                self.engine.dist_init(self._group)
-            except Exception as exc:
-                ok = 0.0
-                logger.log("cadm_amd: in-library RCCL init failed on this rank (%s)" % exc)
-            # every rank must take the SAME path, or some would wait in ncclAllGather and others in torch's collective
-            flag = torch.tensor([ok], device=self.engine.device if dist.get_backend(self._group) == "nccl" else "cpu")
+            backend = dist.get_backend(self._group)
+            ok = 0.0
+            if backend == "nccl" and not self._dist_failed:
+                ok = 1.0
+                try:       # in-library RCCL communicator: the whole sharded planner stays on the stream
+                    self.engine.dist_init(self._group)
+                except Exception as exc:
+                    ok = 0.0
+                    logger.log("cadm_amd: in-library RCCL init failed on this rank (%s)" % exc)
+            # every rank must take the SAME collective, or some would wait in ncclAllGather and others in torch's
+            flag = torch.tensor([ok], device=self.engine.device if backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._group)
             if float(flag.item()) < 1.0:
-                self._dist_failed = True
-                self.engine.dist_destroy()
-                logger.log("cadm_amd: a rank failed in-library RCCL init; all ranks use torch.distributed all_gather")
-        return shard, (shard.world == 1 or self.engine.dist_world == shard.world)
+                if self.engine.dist_world > 1:
+                    self.engine.dist_destroy()
+                if backend == "nccl":
+                    self._dist_failed = True
+                    logger.log("cadm_amd: a rank failed in-library RCCL init; all ranks plug torch.distributed's all_gather into the same planner")
+                self.engine.dist_init_external(self._group)
+        return shard, True
 
     def _replication_check_due(self, peek=False):
         """Sharded calls only.  Counts the call (unless `peek`: the same call asking again further down) and says whether this one
@@ -304,7 +313,7 @@ class MLPEnsembleCEMDynamicsModel(object):
                 if shard.world > 1:      # the call is counted HERE, whatever path it then takes (the torch.distributed
                     due = self._replication_check_due()      # fallback used to re-ask with peek=True without ever having counted)
                     counted = True
-                if fused and not due:
+                if not due:
                     self._call += 1
                     return self.engine.cem_plan_host((obs, cp_obs, cp_act, cem_init_mean, cem_init_var), self.n_candidates, seed=self.seed,
                                                      call=self._call & 0xFFFFFFFF, shapes=sig)
@@ -322,7 +331,7 @@ class MLPEnsembleCEMDynamicsModel(object):
         call = self._next_call()
         shard, fused = self._sharding()
         check_due = shard.world > 1 and self._replication_check_due(peek=counted)
-        if fused and host_in and cem_init_mean is not None and not check_due:
+        if host_in and cem_init_mean is not None and not check_due:
             # the hot path of the samplers' loop: one library call from host arrays to the host plan (clipped in the last kernel)
             return self.engine.cem_plan_host((obs, cp_obs, cp_act, cem_init_mean, cem_init_var), self.n_candidates, seed=self.seed, call=call,
                                              shapes=sig)
@@ -332,27 +341,17 @@ class MLPEnsembleCEMDynamicsModel(object):
             self._check_replicated_left = max(0, self._check_replicated_left - 1)
             _planner.check_replicated([self.engine._t(x) for x in (obs, cp_obs, cp_act, cem_init_mean) if x is not None], shard)
         if cem_init_mean is not None:
-            if fused:
-                # the plan lands in a persistent pinned host buffer (written by the last refit kernel): one stream
-                # synchronisation instead of an allocation + D2H copy per call
-                eng = self.engine
-                host = eng.host_out((m, self.n_forwards, self.action_space_dims))
-                eng.cem_plan(obs, cp_obs, cp_act, cem_init_mean, cem_init_var, self.n_candidates, seed=self.seed, call=call, out=host)
-                torch.cuda.current_stream(eng.device).synchronize()
-                action = host.numpy().copy()
-                if shard.world > 1 and np.isnan(action).any():      # (the in-library refit checks every rank's input checksum on every call)
-                    raise RuntimeError("candidate-sharded planning: the plan is NaN -- the ranks of the group were fed different obs / "
-                                       "history / warm start on this call (or an input is non-finite)")
-                return action if self.discrete else np.minimum(np.maximum(action, -1.0), 1.0)
-            else:
-                action = _planner.cem_plan(self.engine, obs, cp_obs, cp_act, cem_init_mean, cem_init_var,
-                                           self.n_candidates, seed=self.seed, call=call, shard=shard)
-        else:
-            if fused:
-                action = self.engine.rs_plan(obs, cp_obs, cp_act, self.n_candidates, seed=self.seed, call=call)
-            else:
-                action, _ = _planner.rs_plan(self.engine, obs, cp_obs, cp_act, self.n_candidates, seed=self.seed,
-                                             call=call, shard=shard)
+            # the plan lands in a persistent pinned host buffer (written by the last refit kernel): one stream
+            # synchronisation instead of an allocation + D2H copy per call
+            eng = self.engine
+            host = eng.host_out((m, self.n_forwards, self.action_space_dims))
+            eng.cem_plan(obs, cp_obs, cp_act, cem_init_mean, cem_init_var, self.n_candidates, seed=self.seed, call=call, out=host)
+            torch.cuda.current_stream(eng.device).synchronize()
+            action = host.numpy().copy()
+            if shard.world > 1 and eng.dist_mismatch():      # (the sharded refit checks every rank's input checksum on every call)
+                raise RuntimeError(eng.MISMATCH_MSG)
+            return action if self.discrete else np.minimum(np.maximum(action, -1.0), 1.0)
+        action = self.engine.rs_plan(obs, cp_obs, cp_act, self.n_candidates, seed=self.seed, call=call)
         action = action.cpu().numpy()
         if not self.discrete:
             action = np.minimum(np.maximum(action, -1.0), 1.0)

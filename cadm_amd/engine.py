@@ -48,7 +48,16 @@ class HipEngine:
                                  "(libcadm_hip.so); there is no CPU fallback")
         # lib: a developer build (tests / tools: _lib.load_dev()); the product always binds libcadm_hip.so
         self.lib = lib if lib is not None else _lib.load()
-        self._check = lambda rc, what="": check(rc, what, self.lib)
+        self._ext = None            # host-supplied all-gather of a sharded planner (dist_init_external)
+
+        def _check(rc, what=""):
+            # an exception raised inside the host-supplied collective cannot cross the library's C frames: re-raise it here
+            ext = self._ext
+            if rc and ext is not None and ext.error is not None:
+                exc, ext.error = ext.error, None
+                raise exc
+            check(rc, what, self.lib)
+        self._check = _check
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         hs = tuple(int(h) for h in hidden_sizes)
         if len(hs) < 1 or min(hs) < 1:
@@ -431,9 +440,10 @@ class HipEngine:
                 views.append(None if sh is None else hv[pos:pos + sz].reshape(sh))
                 pos += sz
             m = shapes[0][0]
-            out = torch.zeros(m * self.H * self.A + m, dtype=torch.float32).pin_memory()       # plan + m completion flags
+            out = torch.zeros(m * self.H * self.A + 2 * m, dtype=torch.float32).pin_memory()   # plan + m completion flags + m mismatch words
+            flags = out.numpy()[m * self.H * self.A + m:].view(np.uint32)
             st = self._host_plan = dict(shapes=shapes, n=n, ws=ptr(self._workspace(m, n)), host=host, views=views, dev=torch.empty(total, dtype=torch.float32, device=self.device),
-                                        off=(ct.c_int32 * 5)(*offs), total=total, out=out, out_np=out.numpy()[:m * self.H * self.A].reshape(m, self.H, self.A), m=m,
+                                        off=(ct.c_int32 * 5)(*offs), total=total, out=out, out_np=out.numpy()[:m * self.H * self.A].reshape(m, self.H, self.A), m=m, mismatch=flags,
                                         hp=ct.c_void_p(host.data_ptr()), op=ct.c_void_p(out.data_ptr()))
             st["dp"] = ct.c_void_p(st["dev"].data_ptr())
             self.ensure_rollout(None, m, max(1, n // self.dist_world))
@@ -445,11 +455,21 @@ class HipEngine:
         if rc:
             self._check(rc, "cadm_cem_plan_staged")
         out = st["out_np"].copy()
-        if self.dist_world > 1 and np.isnan(out).any():
-            # the sharded refit compares the checksums every rank's all-gather payload carries (csrc/cem.hip: RefitRegen)
-            raise RuntimeError("candidate-sharded planning: the plan is NaN -- the ranks of the group were fed different obs / history / warm "
-                               "start on this call (or an input is non-finite); every rank of the group raises on the same call")
+        if self.dist_world > 1 and st["mismatch"].any():
+            # the sharded refit compares the checksums every rank's all-gather payload carries (csrc/cem.hip: RefitRegen) and raises a
+            # flag of its own: a NaN plan alone is also what a single-rank call returns for a non-finite observation
+            self._check(self.lib.cadm_dist_mismatch(self._ctx, ct.byref(ct.c_int(0)), self.stream), "cadm_dist_mismatch")      # (resets the device word)
+            raise RuntimeError(self.MISMATCH_MSG)
         return out
+
+    MISMATCH_MSG = ("candidate-sharded planning: the ranks of the group were fed different obs / history / warm start on this call "
+                    "(input checksums differ; the plan is NaN on every rank, and every rank raises on the same call)")
+
+    def dist_mismatch(self):
+        """Did the last sharded cem_plan see different replicated inputs on some rank?  Synchronises the stream; reading resets the flag."""
+        v = ct.c_int(0)
+        self._check(self.lib.cadm_dist_mismatch(self._ctx, ct.byref(v), self.stream), "cadm_dist_mismatch")
+        return bool(v.value)
 
     def rs_plan(self, obs, cp_obs, cp_act, n, seed=0, call=0):
         obs = self._t(obs)
@@ -537,9 +557,29 @@ class HipEngine:
             raise _lib.CadmError("RCCL communicator reports nranks=%d rank=%d, expected %d / %d" % (nr, rk, world, rank))
         self.dist_world, self.dist_rank = world, rank
 
+    def dist_init_external(self, group=None):
+        """The same sharded planner with the all-gather supplied by torch.distributed over `group`, whatever its backend (gloo, or nccl
+        where the in-library communicator cannot be built): `cadm_cem_plan` / `cadm_rs_plan` run the loop of the RCCL path and call back
+        into `planner.ExternalAllGather` once per CEM iteration.  Both pointers of a call lie inside this engine's planner workspace."""
+        import torch.distributed as dist
+        from . import planner as _planner
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def resolve(ptr_, nbytes):
+            ws = self._ws
+            off = int(ptr_) - ws.data_ptr()
+            if ws is None or off < 0 or off + nbytes > ws.numel() or off % 4:
+                raise _lib.CadmError("external all-gather: pointer outside the planner workspace")
+            return ws[off:off + nbytes].view(torch.float32)
+        ext = _planner.ExternalAllGather(group, resolve)
+        self._check(self.lib.cadm_dist_init_external(self._ctx, world, rank, ct.cast(ext.cfunc, ct.c_void_p), None), "cadm_dist_init_external")
+        self._ext = ext
+        self.dist_world, self.dist_rank = world, rank
+
     def dist_destroy(self):
         self._check(self.lib.cadm_dist_destroy(self._ctx), "cadm_dist_destroy")
         self.dist_world, self.dist_rank = 1, 0
+        self._ext = None
 
     def dist_info(self):
         """(nranks, rank) as RCCL itself reports them for the ctx's communicator (ncclCommCount / ncclCommUserRank)."""

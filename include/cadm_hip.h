@@ -297,10 +297,25 @@ int cadm_build_windows(const void* obs, const void* act, const void* cp_obs, con
  * element index) and the refit regenerates the elite sequences (cadm_cem_refit_regen) instead of reading them.  Every
  * rank's payload carries one more float: a checksum word of its replicated inputs (obs, cp_obs, cp_act, mean, var).
  * The refit compares the ranks' words; on a mismatch -- the ranks were fed different inputs -- the plan is NaN on EVERY
- * rank (the call still returns CADM_OK: check the plan; the Python class raises RuntimeError). */
+ * rank and a flag is raised (cadm_dist_mismatch; a staged call also writes it into m words behind its completion flags).  The
+ * call still returns CADM_OK; the Python class raises RuntimeError on the flag. */
 int cadm_dist_unique_id(char out_id[128]);
 int cadm_dist_init(cadm_ctx* ctx, const char id[128], int nranks, int rank);
 int cadm_dist_destroy(cadm_ctx* ctx);
+/* The same sharded planner over a collective the HOST supplies (any torch.distributed backend, MPI, ...): every rank registers an
+ * all-gather `fn(user, send, recv, count, stream)` -- [count] floats at device pointer `send` of every rank -> [nranks * count] floats at
+ * device pointer `recv`, rank-major, valid for work enqueued on `stream` after fn returns; 0 = success.  cadm_cem_plan / cadm_rs_plan
+ * then run EXACTLY the loop of the RCCL path (same shard arithmetic, same payload with the trailing checksum word, same regenerating
+ * refit) and call fn where they would call ncclAllGather: there is one sharded implementation, the collective is a plug.  fn is called
+ * on the thread that called the planner, between kernel enqueues (it may synchronise `stream`; both pointers lie inside the `workspace`
+ * argument of the planner call). */
+typedef int (*cadm_allgather_fn)(void* user, const void* send, void* recv, size_t count, void* stream);
+int cadm_dist_init_external(cadm_ctx* ctx, int nranks, int rank, cadm_allgather_fn fn, void* user);
+/* Did the ranks of the last sharded cadm_cem_plan feed different replicated inputs (obs, history, warm start)?  *mismatch_out = 1 / 0;
+ * reading resets the flag.  Synchronises `stream`.  On a mismatch the plan of that call is NaN on every rank; a NaN plan WITHOUT this
+ * flag is what a single-rank call returns for the same inputs (a non-finite observation, a diverged model).  Inputs are compared by
+ * value: -0.0 equals +0.0 and every NaN equals every NaN. */
+int cadm_dist_mismatch(cadm_ctx* ctx, int* mismatch_out, void* stream);
 /* (nranks, rank) as RCCL reports them for the ctx's communicator (ncclCommCount / ncclCommUserRank); (1, 0) without one. */
 int cadm_dist_info(cadm_ctx* ctx, int* nranks_out, int* rank_out);
 

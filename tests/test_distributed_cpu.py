@@ -1,6 +1,8 @@
-"""CPU, world_size 2, gloo: the candidate-sharded planner (one all-gather of per-candidate returns per
-CEM iteration) equals the unsharded planner exactly; exercised through cadm_amd.planner with the
-oracle-backed engine stand-in (the HIP engine needs a GPU)."""
+"""CPU, world_size 2, gloo: the host side of candidate-sharded planning.  The sharded planner is ONE implementation -- the library's
+loop (`cadm_cem_plan`), on every rank -- whose collective is a plug; what runs without a GPU is that plug
+(`cadm_amd.planner.ExternalAllGather`, driven through its C function pointer exactly as the library drives it), the shard arithmetic
+and the replicated-input guard.  The loop itself runs with two LIVE ranks in tests/test_gpu_multi.py (two processes on one GPU over
+gloo, and two GPUs over RCCL where a box has them)."""
 import os
 import socket
 import sys
@@ -23,54 +25,56 @@ def _free_port():
 
 
 def _worker(rank, world, port, out_dir):
-    sys.path.insert(0, HERE)
+    """The host-supplied all-gather of the sharded planner (cadm_amd.planner.ExternalAllGather), called the way the library calls it:
+    through its C function pointer, with raw pointers into a "workspace" -- here host memory, so the SAME product code runs under gloo
+    without a GPU.  The payload is the planner's: m * n/G candidate means + one checksum word per rank."""
     sys.path.insert(0, os.path.dirname(HERE))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes as ct
+    from cadm_amd import _lib
     from cadm_amd import planner as hplanner
-    from cadm_amd import synth
-    from helpers import oracle_problem
-    from oracle_engine import OracleEngine
     torch.set_num_threads(1)
-    E, p, m, n, H = 5, 5, 2, 64, 4
-    prob = synth.make_problem(env="halfcheetah", E=E, m=m, H=H, seed=7)
-    eng = OracleEngine(oracle_problem(prob, np.float32), prob, p, H, num_elites=16)
+    m, n = 2, 64
     shard = hplanner.Shard.from_group(n, dist.group.WORLD)
     assert (shard.world, shard.rank, shard.n_local, shard.offset) == (world, rank, n // world, rank * (n // world))
-    plan = hplanner.cem_plan(eng, prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], n,
-                             seed=11, call=3, shard=shard)
-    first, cand = hplanner.rs_plan(eng, prob["obs"], prob["cp_obs"], prob["cp_act"], n, seed=11, call=4, shard=shard)
-    np.save(os.path.join(out_dir, "plan_%d.npy" % rank), plan.numpy())
-    np.save(os.path.join(out_dir, "rs_%d.npy" % rank), first.numpy())
-    np.save(os.path.join(out_dir, "cand_%d.npy" % rank), cand.numpy())
+    count = m * shard.n_local + 1
+    ws = torch.zeros(4096, dtype=torch.uint8)                       # the "workspace": send at byte 256, recv at byte 1024
+    base = ws.data_ptr()
+
+    def resolve(ptr, nbytes):
+        off = int(ptr) - base
+        assert 0 <= off and off + nbytes <= ws.numel()
+        return ws[off:off + nbytes].view(torch.float32)
+    ext = hplanner.ExternalAllGather(dist.group.WORLD, resolve)
+    assert (ext.world, ext.rank, ext.backend) == (world, rank, "gloo")
+    fn = ct.cast(ext.cfunc, _lib.ALLGATHER_FN)                       # the pointer the library would hold
+    send = resolve(base + 256, 4 * count)
+    for it in range(3):                                              # one call per CEM iteration
+        send[:count - 1] = torch.arange(count - 1, dtype=torch.float32) + 1000.0 * rank + 0.5 * it
+        send[count - 1:] = torch.tensor([0x5EED0001 + it], dtype=torch.int32).view(torch.float32)      # the checksum word: a bit pattern
+        assert fn(None, base + 256, base + 1024, count, None) == 0
+        np.save(os.path.join(out_dir, "gath_%d_%d.npy" % (rank, it)), resolve(base + 1024, 4 * count * world).view(torch.int32).numpy().copy())
+    assert ext.calls == 3 and ext.error is None
+    # an exception inside the callback never crosses the C frames: a non-zero code, the exception kept for HipEngine._check to re-raise
+    assert fn(None, base + 4000, base + 1024, count, None) == 1
+    assert isinstance(ext.error, AssertionError)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_cem_equals_single_rank(tmp_path):
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    # single-rank reference in this process
-    sys.path.insert(0, HERE)
-    from cadm_amd import planner as hplanner
-    from cadm_amd import synth
-    from helpers import oracle_problem
-    from oracle_engine import OracleEngine
-    E, p, m, n, H = 5, 5, 2, 64, 4
-    prob = synth.make_problem(env="halfcheetah", E=E, m=m, H=H, seed=7)
-    eng = OracleEngine(oracle_problem(prob, np.float32), prob, p, H, num_elites=16)
-    ref = hplanner.cem_plan(eng, prob["obs"], prob["cp_obs"], prob["cp_act"], prob["init_mean"], prob["init_var"], n,
-                            seed=11, call=3).numpy()
-    rs_ref, cand_ref = hplanner.rs_plan(eng, prob["obs"], prob["cp_obs"], prob["cp_act"], n, seed=11, call=4)
-    p0, p1 = np.load(tmp_path / "plan_0.npy"), np.load(tmp_path / "plan_1.npy")
-    np.testing.assert_array_equal(p0, p1)            # every rank ends with the identical plan
-    np.testing.assert_array_equal(p0, ref)           # and it equals the unsharded planner bit for bit
-    np.testing.assert_array_equal(np.load(tmp_path / "rs_0.npy"), rs_ref.numpy())
-    np.testing.assert_array_equal(np.load(tmp_path / "rs_1.npy"), rs_ref.numpy())
-    c0 = np.load(tmp_path / "cand_0.npy")            # gathered layout [G, m, n_local]
-    assert c0.shape == (2, m, n // 2)
-    np.testing.assert_array_equal(np.concatenate([c0[0], c0[1]], axis=1), cand_ref.numpy()[0])
+def test_external_allgather_world_size_2_gloo(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    m, n, world = 2, 64, 2
+    count = m * (n // world) + 1
+    for it in range(3):
+        g0, g1 = (np.load(tmp_path / ("gath_%d_%d.npy" % (r, it))) for r in range(2))
+        np.testing.assert_array_equal(g0, g1)                        # every rank holds the same gathered buffer
+        g = g0.view(np.float32).reshape(world, count)                # rank-major: [G][m * n_local + 1]
+        for r in range(world):
+            np.testing.assert_array_equal(g[r, :-1], np.arange(count - 1, dtype=np.float32) + 1000.0 * r + 0.5 * it)
+            assert g0.reshape(world, count)[r, -1] == 0x5EED0001 + it       # the checksum word survives bit for bit
 
 
 def test_shard_validation():
@@ -133,22 +137,29 @@ def test_replication_check_schedule():
     assert not any(M._replication_check_due(off) for _ in range(600))
 
 
-def test_replication_guard_fires_on_the_unfused_sharded_path(monkeypatch):
-    """with the torch.distributed fallback (no in-library communicator: `fused` False) the fast-signature branch of
-    get_action used to mark the call as counted without counting it, so `_sharded_calls` stayed at 1 and the periodic check never
-    fired -- in exactly the degraded mode where ranks are most likely to drift apart.  get_action on a stand-in object (the class
-    itself needs a GPU): the check must run on calls 1, 2 (check_replicated_calls) and then on every 4th."""
+def test_replication_guard_fires_on_the_sharded_path(monkeypatch):
+    """the fast-signature branch of get_action used to mark a sharded call as counted without counting it, so
+    `_sharded_calls` stayed at 1 and the periodic check never fired.  get_action on a stand-in object (the class itself needs a GPU),
+    sharded over 2 ranks: the check must run on calls 1, 2 (check_replicated_calls) and then on every 4th, and every call is planned
+    by the engine's one planner (`cem_plan` when the check has staged the inputs, `cem_plan_host` otherwise)."""
     import types
     import torch
     from cadm_amd.dynamics import mlp_cadm_ensemble_cem_dynamics as mod
     M = mod.MLPEnsembleCEMDynamicsModel
     checked, planned = [], []
     monkeypatch.setattr(mod._planner, "check_replicated", lambda tensors, shard: checked.append(len(planned) + 1))
-    monkeypatch.setattr(mod._planner, "cem_plan", lambda eng, *a, **k: (planned.append(1), torch.zeros(1, 3, 2))[1])
-    eng = types.SimpleNamespace(stage=lambda xs: tuple(None if x is None else torch.as_tensor(x) for x in xs), _t=lambda x: x)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda dev=None: types.SimpleNamespace(synchronize=lambda: None))
+
+    def cem_plan(*a, out=None, **k):
+        planned.append("device")
+        out.zero_()
+    host = torch.zeros(1, 3, 2)
+    eng = types.SimpleNamespace(stage=lambda xs: tuple(None if x is None else torch.as_tensor(x) for x in xs), _t=lambda x: x, device="cpu",
+                                cem_plan=cem_plan, host_out=lambda shape: host, dist_mismatch=lambda: False, MISMATCH_MSG="mismatch",
+                                cem_plan_host=lambda *a, **k: (planned.append("host"), np.zeros((1, 3, 2), np.float32))[1])
     me = types.SimpleNamespace(_stats_dirty=False, _checked_sig=None, _call=0, _check_replicated_left=2, _check_replicated_every=4,
                                _sharded_calls=0, engine=eng, n_candidates=8, seed=0, discrete=False, n_forwards=3, action_space_dims=2,
-                               _sharding=lambda: (types.SimpleNamespace(world=2), False))
+                               _sharding=lambda: (types.SimpleNamespace(world=2), True))
     me._next_call = lambda: M._next_call(me)
     me._replication_check_due = lambda peek=False: M._replication_check_due(me, peek=peek)
     me._check_planner_inputs = lambda *a: None
@@ -157,3 +168,4 @@ def test_replication_guard_fires_on_the_unfused_sharded_path(monkeypatch):
         M.get_action(me, obs, None, None, mean, var)
     assert len(planned) == 12 and me._sharded_calls == 12
     assert checked == [1, 2, 4, 8, 12], checked
+    assert [i + 1 for i, k in enumerate(planned) if k == "device"] == checked      # a checked call stages its inputs; the others are one host call
