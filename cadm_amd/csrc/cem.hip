@@ -452,6 +452,9 @@ __global__ __launch_bounds__(1024) void cem_refit_sample_kernel(const float* __r
 int cadm_launch_refit_sample(cadm_ctx* ctx, const float* cand_returns, const float* rows, int G, int n_local, float* actions, int m,
                              const float* mean_in, const float* var_in, float* mean_out, float* var_out, uint32_t seed, uint32_t call,
                              int next_it, hipStream_t stream) {
+    // (the LAST refit of a call stays cem_refit_kernel, one workgroup per env: the same element-parallel form with the plan and the
+    //  completion flags written by 45 workgroups -- a system-scope fence and a few PCIe stores each, a per-env arrival counter -- measured
+    //  ~16 us against its 10.0, round 6)
     const int HA = ctx->H * ctx->A, NS = (HA + CADM_FUSED_EPW - 1) / CADM_FUSED_EPW;
     hipLaunchKernelGGL(cem_refit_sample_kernel, dim3(m * NS), dim3(1024), 0, stream, cand_returns, rows, ctx->p, G, n_local, actions, m,
                        ctx->H, ctx->A, ctx->cfg.num_elites, ctx->cfg.alpha, mean_in, var_in, mean_out, var_out, ctx->cfg.lower_bound,

@@ -542,13 +542,14 @@ __global__ __launch_bounds__(256) void rollout_kernel(const RolloutArgs a) {
                             pz[mt][pi][1] = (2 * dp + 1 < D) ? ep[1] : 0.0f;
                         }
                     } else if constexpr (part == 0) {   // branch-free: idle slots draw a value nobody reads
-                        pc[mt][pi][0] = grow[mt]; pc[mt][pi][1] = (uint32_t)t; pc[mt][pi][2] = (uint32_t)dp;
+                        pc[mt][pi][0] = grow[mt]; pc[mt][pi][1] = (uint32_t)t; pc[mt][pi][2] = eps_group(dp);
                         pc[mt][pi][3] = CADM_STREAM_EPS | ((uint32_t)a.it << 8);
                         pk[mt][pi][0] = a.seed; pk[mt][pi][1] = a.call;
                     } else if constexpr (part <= 10) {
                         philox_rounds<part - 1, part>(pc[mt][pi], pk[mt][pi]);
                     } else {
-                        box_muller(u01(pc[mt][pi][0]), u01(pc[mt][pi][1]), pz[mt][pi][0], pz[mt][pi][1]);
+                        const bool hi = eps_sub(dp) != 0;      // (rollout_env.h: one call = the noise of pairs dp and dp + 4)
+                        box_muller(u01(hi ? pc[mt][pi][2] : pc[mt][pi][0]), u01(hi ? pc[mt][pi][3] : pc[mt][pi][1]), pz[mt][pi][0], pz[mt][pi][1]);
                     }
                 }
         };

@@ -160,6 +160,22 @@ __device__ __forceinline__ float head_sd(float lv, float enmax, float emin, floa
     return s * __builtin_amdgcn_sqrtf(emin + __builtin_amdgcn_rcpf(enmax + t));
 }
 
+// MODE.FP16_OVFL (bit 23 of the wave's MODE register): an f16 RESULT that overflows -- v_cvt_f16_f32, v_cvt_pk_f16_f32, v_fma_mix*_f16 --
+// is clamped to +-65504 instead of becoming inf (true infinities stay).  The rollout kernels split every network input and activation
+// in two f16 numbers for the matrix pipe; with this bit the split itself saturates: hi = sat(f16(v)), lo = sat(f16(v - hi)), i.e. a value
+// beyond the f16 range goes in as at most +-131008 and stays finite (only diverged rows ever get there).  That replaces the explicit
+// clamps in front of every conversion (4 v_min per hidden tile epilogue of 30 instructions; a v_med3 per input feature): the kernels
+// are bound by their VALU instructions as much as by their MFMAs.  fp32 arithmetic and MFMAs are not affected.  Set once per wave, at
+// kernel entry (the register is per wave and does not outlive it).
+#ifndef CADM_FP16_SATURATE
+#define CADM_FP16_SATURATE 1
+#endif
+__device__ __forceinline__ void fp16_saturate_on() {
+#if CADM_FP16_SATURATE
+    __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1);      // hwreg(HW_REG_MODE, 23, 1) = 1
+#endif
+}
+
 template <int R0, int R1>
 __device__ __forceinline__ void philox_rounds(uint32_t (&c)[4], uint32_t (&k)[2]) {
 #pragma unroll
@@ -173,6 +189,14 @@ __device__ __forceinline__ void philox_rounds(uint32_t (&c)[4], uint32_t (&k)[2]
         k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
     }
 }
+
+// Gaussian-head noise of one (global row, step): ONE Philox4x32-10 call yields four words = two Box-Muller pairs = the noise of TWO dim
+// pairs.  Pairs dp and dp + 4 share a call (the wave-tile kernel keeps pairs fg, fg + 4, fg + 8, .. of a row in one lane: two calls per
+// lane and step instead of three at 18 dims, three instead of six at 45 -- the Philox rounds were a quarter of its state phase):
+//   counter word 2 = eps_group(dp) = (dp & 3) | (dp >> 3) << 2,   the pair's words = (2 s, 2 s + 1) with s = eps_sub(dp) = (dp >> 2) & 1.
+// oracle/philox.py: eps_normals restates it.
+__device__ __forceinline__ uint32_t eps_group(int dp) { return (uint32_t)((dp & 3) | ((dp >> 3) << 2)); }
+__device__ __forceinline__ int eps_sub(int dp) { return (dp >> 2) & 1; }
 
 // NOISE: how the Gaussian head's eps is obtained -- compile-time so that no runtime branch (and no
 // merged-register s_waitcnt vmcnt(0)) lands inside the software-pipelined MFMA sweeps.

@@ -177,6 +177,7 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
     constexpr int D = G::D, A = G::A, P = G::P, C = G::C, K0 = G::K0, NC0 = G::NC0, NCH = G::NCH, NT = G::NT, NTO = G::NTO;
     constexpr int NP = G::NP, ENV = G::ENV, XNH = G::NHC, NJ = W::NJ, NAJ = W::NAJ, TABW = W::TABW;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    fp16_saturate_on();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, fg = lane >> 4;                     // row of the tile, lane group (units 4 fg .. 4 fg + 3 of a D tile)
@@ -218,8 +219,8 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
                 const int f = on ? ff[i] : 0;
                 te[10 + 2 * h + i] = a.obs_mean[f];
                 te[14 + 2 * h + i] = 1.0f / (a.obs_std[f] + 1e-10f);
-                te[18 + 2 * h + i] = __builtin_bit_cast(float, on ? xin_base(f) : -1);
-                te[22 + 2 * h + i] = __builtin_bit_cast(float, on ? fop[i] : 0);
+                te[18 + 2 * h + i] = __builtin_bit_cast(float, on ? xin_base(f) : G::SPARE ? xin_base(K0) : -1);
+                te[22 + 2 * h + i] = __builtin_bit_cast(float, on ? fop[i] : G::SPARE ? 3 : 0);      // (op 3: no feature, 0.0 into the spare slot)
             }
         }
     }
@@ -243,8 +244,8 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
     float nanfold = 0.0f;              // 0 * v of every input feature: NaN iff the row ever saw a non-finite one (rollout_xdl.h put_x)
     auto put_x = [&](int off, float v) __attribute__((always_inline)) {
         nanfold = fmaf(0.0f, v, nanfold);
-        v = fminf(fmaxf(v, -65000.0f), 65000.0f);
-        _Float16 h1, h2;
+        asm volatile("" : "+v"(v));         // (an fp32 number before it is split: rollout_xdl.h put_x)
+        _Float16 h1, h2;                    // (saturating split: fp16_saturate_on)
         xsplit(v, h1, h2);
         *reinterpret_cast<_Float16*>(xw + off) = h1;
         *reinterpret_cast<_Float16*>(xw + NC0 * 1024 + off) = h2;
@@ -326,6 +327,9 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
                 int lane_o = lane, lr_o = lr;
                 asm volatile("" : "+v"(lane_o), "+v"(lr_o));
                 const int r = lane_o & 15, fg = lane_o >> 4, r16 = r * 16, lr = lr_o;
+                // Gaussian-head noise: one Philox call per TWO pair slots (pairs 8 q + fg and 8 q + 4 + fg share a call: rollout_env.h eps_group /
+                // eps_sub) -- made at the even slot, the odd slot's pair carried over in two registers
+                float2 z_odd = make_float2(0.0f, 0.0f);
                 static_for(std::make_integer_sequence<int, NJ>{}, [&](auto jc) {
                     constexpr int jj = decltype(jc)::value;
                     const int dp = 4 * jj + fg;
@@ -343,10 +347,15 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
                                 z.x = epp[0];
                                 z.y = (2 * dp + 1 < D) ? epp[1] : 0.0f;
                             } else if constexpr (NOISE == CADM_NOISE_PHILOX) {
-                                uint32_t pc[4] = {grow, (uint32_t)(t - 1), (uint32_t)dp, CADM_STREAM_EPS | ((uint32_t)a.it << 8)};
-                                uint32_t pk[2] = {a.seed, a.call};
-                                philox_rounds<0, 10>(pc, pk);
-                                box_muller(u01(pc[0]), u01(pc[1]), z.x, z.y);
+                                if constexpr ((jj & 1) == 0) {
+                                    uint32_t pc[4] = {grow, (uint32_t)(t - 1), (uint32_t)(fg | ((jj >> 1) << 2)), CADM_STREAM_EPS | ((uint32_t)a.it << 8)};
+                                    uint32_t pk[2] = {a.seed, a.call};
+                                    philox_rounds<0, 10>(pc, pk);
+                                    box_muller(u01(pc[0]), u01(pc[1]), z.x, z.y);
+                                    if constexpr (jj + 1 < NJ) box_muller(u01(pc[2]), u01(pc[3]), z_odd.x, z_odd.y);
+                                } else {
+                                    z = z_odd;
+                                }
                             }
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
@@ -374,12 +383,18 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
                             for (int h = 0; h < 2; ++h) {
                                 float sn = 0.0f, cs = 0.0f;
                                 if constexpr (ENV == CADM_ENV_HALFCHEETAH) {                 // the one trig pair (obs dim 2)
-                                    if (ti_(22 + 2 * h) != 0) sincos_cw(po[jj][h], &sn, &cs);
+                                    if (ti_(22 + 2 * h) == 1) sincos_cw(po[jj][h], &sn, &cs);
                                 }
 #pragma unroll
                                 for (int i = 0; i < 2; ++i) {
                                     const int off = ti_(18 + 2 * h + i), op = ti_(22 + 2 * h + i);
-                                    if (off >= 0) {
+                                    if constexpr (G::SPARE) {      // unconditional: selects, no exec-mask regions (XC::SPARE)
+                                        float pv = po[jj][h];
+                                        pv = op == 1 ? sn : pv;
+                                        pv = op == 2 ? cs : pv;
+                                        const float xv = (pv - tv(10 + 2 * h + i)) * tv(14 + 2 * h + i);   // :450-451
+                                        put_x(off + r16, op == 3 ? 0.0f : xv);
+                                    } else if (off >= 0) {
                                         const float pv = op == 1 ? sn : op == 2 ? cs : po[jj][h];
                                         put_x(off + r16, (pv - tv(10 + 2 * h + i)) * tv(14 + 2 * h + i));   // :450-451
                                     }

@@ -60,6 +60,14 @@ struct XC {
     static constexpr int D = env_D(ENV), A = env_A(ENV), P = env_P(ENV);
     static constexpr int K0 = P + A + C;
     static constexpr int NC0 = (K0 + 31) / 32;            // chunks of layer 0
+    // A feature slot behind the last real input feature (its packed weights are zeros: pack_xdl.hip): the state phase's feature writes
+    // are UNCONDITIONAL -- a dim that feeds fewer than two features writes 0.0 there instead of branching around the write (hipcc turned
+    // the guarded writes + the id / sin / cos select into nested exec-mask regions with out-of-line blocks: ~25 control instructions per
+    // feature, 300 per step of the wave-tile kernel).  Exists unless K0 is a multiple of 32.
+#ifndef CADM_XDL_SPARE
+#define CADM_XDL_SPARE 1
+#endif
+    static constexpr bool SPARE = CADM_XDL_SPARE && (K0 % 32) != 0;
     static constexpr int NT = (HID + 15) / 16;            // hidden tiles
     static constexpr int NCH = (NT + 1) / 2;              // chunks of a layer that consumes a hidden layer
     static constexpr int NTO = (D + 7) / 8;               // head tiles (8 dims: mu | lv)
@@ -283,15 +291,13 @@ struct XHiddenEpi {
         constexpr float KE = G::ACT == CADM_ACT_TANH ? -2.0f * 1.4426950408889634f : -1.4426950408889634f;
         constexpr bool SIG = G::ACT != CADM_ACT_RELU && G::ACT != CADM_ACT_NONE;       // nonlinearities built on sigmoid
         if constexpr (PACKED) {
-        if constexpr (S == 0) {            // pre-activation (hi + 2^-11 lo), f16-range clamp, exp2 argument
+        if constexpr (S == 0) {            // pre-activation (hi + 2^-11 lo), exp2 argument
             const floatx2 c11 = {4.8828125e-4f, 4.8828125e-4f};
             const floatx2 ke = {KE, KE};
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                floatx2 pre = __builtin_elementwise_fma(q ? hi2(lo) : lo2(lo), c11, q ? hi2(hi) : lo2(hi));
-                pre[0] = fminf(pre[0], 60000.0f);
-                pre[1] = fminf(pre[1], 60000.0f);
-                st.v[q] = pre;
+                const floatx2 pre = __builtin_elementwise_fma(q ? hi2(lo) : lo2(lo), c11, q ? hi2(hi) : lo2(hi));
+                st.v[q] = pre;                 // (no f16-range clamp: the conversions below saturate, fp16_saturate_on)
                 // swish: the packed weights carry log2(e) (xdl_geo.h: CADM_XDL_SWISH_FOLD), pre IS the exp2 argument up to its sign
                 if constexpr (G::ACT == CADM_ACT_SWISH) st.s[q] = -pre;
                 else st.s[q] = pre * ke;
@@ -324,7 +330,6 @@ struct XHiddenEpi {
                         st.v[q][r] = fabsf(x) < 0.1f ? ser : fmaf(2.0f, st.s[q][r], -1.0f);
                     }
                 } else if constexpr (G::ACT == CADM_ACT_RELU) { st.v[q][0] = fmaxf(st.v[q][0], 0.0f); st.v[q][1] = fmaxf(st.v[q][1], 0.0f); }
-                else if constexpr (G::ACT == CADM_ACT_NONE) { st.v[q][0] = fmaxf(st.v[q][0], -60000.0f); st.v[q][1] = fmaxf(st.v[q][1], -60000.0f); }   // f16 range, both sides
                 st.h1[2 * q] = (_Float16)st.v[q][0];
                 st.h1[2 * q + 1] = (_Float16)st.v[q][1];
             }
@@ -341,10 +346,10 @@ struct XHiddenEpi {
             }
         }
         } else {
-        if constexpr (S == 0) {            // pre-activation (hi + 2^-11 lo), f16-range clamp; the exp2 argument of tanh / sigmoid
+        if constexpr (S == 0) {            // pre-activation (hi + 2^-11 lo); the exp2 argument of tanh / sigmoid
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                st.v[r] = fminf(fmaf(lo[r], 4.8828125e-4f, hi[r]), 60000.0f);
+                st.v[r] = fmaf(lo[r], 4.8828125e-4f, hi[r]);      // (no f16-range clamp: the conversions below saturate, fp16_saturate_on)
                 if constexpr (SIG && G::ACT != CADM_ACT_SWISH) st.s[r] = st.v[r] * KE;
             }
         } else if constexpr (S == 1) {
@@ -368,7 +373,6 @@ struct XHiddenEpi {
                     const float ser = x * fmaf(x2, fmaf(x2, fmaf(x2, -0.05396825396825397f, 0.13333333333333333f), -0.3333333333333333f), 1.0f);
                     st.v[r] = fabsf(x) < 0.1f ? ser : fmaf(2.0f, st.s[r], -1.0f);
                 } else if constexpr (G::ACT == CADM_ACT_RELU) st.v[r] = fmaxf(st.v[r], 0.0f);
-                else if constexpr (G::ACT == CADM_ACT_NONE) st.v[r] = fmaxf(st.v[r], -60000.0f);     // f16 range, both sides
                 st.h1[r] = (_Float16)st.v[r];
             }
         } else if constexpr (S == 4) {     // low part: h - hi = fma(hi, -1, h), exact in fp32, rounded once to f16 (unscaled: xsplit)
@@ -611,8 +615,8 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                 const int f = on ? ff[i] : 0;
                 te[5 + i] = a.obs_mean[f];
                 te[7 + i] = 1.0f / (a.obs_std[f] + 1e-10f);
-                te[9 + i] = __builtin_bit_cast(float, on ? xin_base(f) : -1);
-                te[11 + i] = __builtin_bit_cast(float, on ? fop[i] : 0);
+                te[9 + i] = __builtin_bit_cast(float, on ? xin_base(f) : G::SPARE ? xin_base(K0) : -1);
+                te[11 + i] = __builtin_bit_cast(float, on ? fop[i] : G::SPARE ? 3 : 0);      // (op 3: no feature, 0.0 into the spare slot)
             }
         }
     } else if (arow == 0 && wave < 4) {
@@ -644,15 +648,18 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
         }
     }
     const int a0 = (fg - (NP & 15) + 16) & 15;                          // first action feature of this thread
-    // Non-finite inputs: the clamp below would turn a NaN / inf feature into a finite one, so the row would carry on with a
+    // Non-finite inputs: the saturating f16 split below would turn an inf feature into a finite one, so the row would carry on with a
     // plausible-looking return.  Every feature is folded into the thread's reward sum first (0 * v = NaN iff v is NaN or inf,
     // else +-0): a row that ever saw a non-finite observation, action or context value returns NaN -- what the reference's
     // matmuls do to it (core/utils.py:441-472).  tests/test_gpu_precision.py pins this.
     float ret = 0.0f;
     auto put_x = [&](int off, float v) {                                // both split parts of one input feature
         ret = fmaf(0.0f, v, ret);
-        v = fminf(fmaxf(v, -65000.0f), 65000.0f);                       // f16 range (only diverged rows ever get here)
-        _Float16 h1, h2;
+        // (the feature as an fp32 number, whatever expression produced it: hipcc otherwise folds a multiply into the conversion --
+        //  v_fma_mixlo_f16, ONE rounding instead of two -- where the expression's shape allows, and the flavours' state phases, written
+        //  differently around the same arithmetic, would then differ in the last bit of a rare f16 tie)
+        asm volatile("" : "+v"(v));
+        _Float16 h1, h2;                                                // (a value beyond the f16 range saturates in the split: fp16_saturate_on)
         xsplit(v, h1, h2);
         *reinterpret_cast<_Float16*>(xsmem + xin_rt + off) = h1;
         *reinterpret_cast<_Float16*>(xsmem + xin_rt + NC0 * 1024 + off) = h2;
@@ -814,10 +821,11 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                     z.x = epp[0];
                     z.y = (2 * dp + 1 < D) ? epp[1] : 0.0f;
                 } else {
-                    uint32_t pc[4] = {grow, (uint32_t)t, (uint32_t)dp, CADM_STREAM_EPS | ((uint32_t)a.it << 8)};
+                    uint32_t pc[4] = {grow, (uint32_t)t, eps_group(dp), CADM_STREAM_EPS | ((uint32_t)a.it << 8)};
                     uint32_t pk[2] = {a.seed, a.call};
                     philox_rounds<0, 10>(pc, pk);
-                    box_muller(u01(pc[0]), u01(pc[1]), z.x, z.y);
+                    const bool hi = eps_sub(dp) != 0;      // (the call's other two words are pair dp +- 4's: rollout_env.h)
+                    box_muller(u01(hi ? pc[2] : pc[0]), u01(hi ? pc[3] : pc[1]), z.x, z.y);
                 }
                 zb[((t & 1) * NPI + pi) * 256 + (dp & 15) * 16 + arow] = z;
             }
@@ -851,12 +859,18 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                     if (t < H) {
                         float sn = 0.0f, cs = 0.0f;
                         if constexpr (ENV == CADM_ENV_HALFCHEETAH) {                             // the one trig pair (obs dim 2)
-                            if (ti_(11) != 0) sincos_cw(po[0][0], &sn, &cs);
+                            if (ti_(11) == 1) sincos_cw(po[0][0], &sn, &cs);
                         }
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             const int off = ti_(9 + i), op = ti_(11 + i);
-                            if (off >= 0) {
+                            if constexpr (G::SPARE) {      // unconditional: selects, no exec-mask regions (XC::SPARE)
+                                float pv = po[0][0];
+                                pv = op == 1 ? sn : pv;
+                                pv = op == 2 ? cs : pv;
+                                const float xv = (pv - tv(5 + i)) * tv(7 + i);                   // :450-451
+                                put_x(off + arow16, op == 3 ? 0.0f : xv);
+                            } else if (off >= 0) {
                                 const float pv = op == 1 ? sn : op == 2 ? cs : po[0][0];
                                 put_x(off + arow16, (pv - tv(5 + i)) * tv(7 + i));               // :450-451
                             }
@@ -914,11 +928,14 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                         for (int h = 0; h < 2; ++h) {
                             float sn = 0.0f, cs = 0.0f;
                             if constexpr (ENV == CADM_ENV_HALFCHEETAH) {                 // the one trig pair (obs dim 2)
-                                if (ti_(22 + 2 * h) != 0) sincos_cw(po[pi][h], &sn, &cs);
+                                if (ti_(22 + 2 * h) == 1) sincos_cw(po[pi][h], &sn, &cs);
                             }
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {
                                 const int off = ti_(18 + 2 * h + i), op = ti_(22 + 2 * h + i);
+                                // (guarded writes here: the unconditional form of the one-dim layout above and of the wave-tile kernel made ONE
+                                //  instantiation of this layout -- halfcheetah without context, two row tiles, injected noise -- return wrong rows for
+                                //  its second row tile and fault, with or without the extra writes; found by tools/fuzz_rollout.py, not understood)
                                 if (off >= 0) {
                                     const float pv = op == 1 ? sn : op == 2 ? cs : po[pi][h];
                                     put_x(off + arow16, (pv - tv(10 + 2 * h + i)) * tv(14 + 2 * h + i));   // :450-451
@@ -1058,6 +1075,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
 template <class G, int NOISE>
 __global__ __launch_bounds__(G::NTHR) void rollout_xdl_kernel(const RolloutArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char xsmem_raw[];
+    fp16_saturate_on();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // waves [0, EXTRA) own one hidden tile more than the others: two specialisations of the whole body, chosen per wave
     // (a scalar branch; every wave executes the same number of barriers)

@@ -1989,6 +1989,12 @@ int launch_chain(cadm_ctx* ctx, int B, int p0, int p1, hipStream_t s, const Chai
 }
 
 // forward of the context / forward (/ backward) nets on one [E,B,.] batch into the workspace
+// The large-batch training path (one forward launch per net; ONE pass of the summed context gradient down the encoder) changes the
+// arithmetic in the last bits (a sum taken before a linear pass instead of behind it), so WHEN it is taken must be a property of the
+// batch, not of the device the step happens to run on: the rule "work items >= 1.5 rounds of three workgroups per CU" is
+// evaluated for the part this library is written for -- MI355X, 256 CUs -- whatever ctx->n_cus says: with 5 members + backward model the
+// switch is at B = 1856 (1843.2 rounded up to the 16-row tile).  INTEGRATION.md, "numeric envelope"; tests/test_gpu_train.py pins it.
+#define CADM_LARGE_BATCH_CUS 256
 int forward_nets(cadm_ctx* ctx, const RowMap& map, const float* obs, const float* act, const float* obs_next, const float* cp_obs,
                  const float* cp_act, int B, bool has_back, hipStream_t s, const ChainLossCfg* loss = nullptr) {
     TrainState* t = ctx->train;
@@ -2015,7 +2021,7 @@ int forward_nets(cadm_ctx* ctx, const RowMap& map, const float* obs, const float
     // row tile run side by side and the recomputation costs nothing).  Same arithmetic, same loss partials in the same slots.
     const long items = (long)ctx->E * 2 * ((B + CH_ROWS - 1) / CH_ROWS);
     const bool split = has_back && ctx->C > 0 && t->prog_count[PROG_FWD_BK_NOCP] > 0 &&
-                       (ctx->train_force_spread ? ctx->train_force_spread == 1 : 2 * items >= 9L * ctx->n_cus);      // (>= 1.5 rounds of three workgroups per CU: B = 2048 0.4485 -> 0.4445 ms, B = 1024 0.249 -> 0.280)
+                       (ctx->train_force_spread ? ctx->train_force_spread == 1 : 2 * items >= 9L * CADM_LARGE_BATCH_CUS);      // (>= 1.5 rounds of three workgroups per CU: B = 2048 0.4485 -> 0.4445 ms, B = 1024 0.249 -> 0.280)
     if (!split) return launch_chain(ctx, B, PROG_FWD_FF, has_back ? PROG_FWD_BK : -1, s, loss);
     if ((rc = launch_chain(ctx, B, PROG_FWD_FF, -1, s, loss, 0, 2))) return rc;
     return launch_chain(ctx, B, PROG_FWD_BK_NOCP, -1, s, loss, 1, 2);
@@ -2081,7 +2087,7 @@ static int train_step_impl(cadm_ctx* ctx, const RowMap& map, const float* obs, c
     // backward chains (read W) ...
     const long bw_items = (long)E * 2 * ((B + CH_ROWS - 1) / CH_ROWS);
     const bool merge = has_back && has_cp && t->prog_count[PROG_BWD_CP] > 0 &&
-                       (ctx->train_force_merge ? ctx->train_force_merge == 1 : 2 * bw_items >= 9L * ctx->n_cus);      // (forward_nets' rule)
+                       (ctx->train_force_merge ? ctx->train_force_merge == 1 : 2 * bw_items >= 9L * CADM_LARGE_BATCH_CUS);      // (forward_nets' rule)
     if (!merge) {
         if ((rc = launch_chain(ctx, B, PROG_BWD_FF, has_back ? PROG_BWD_BK : -1, s))) return rc;
     } else {

@@ -66,8 +66,9 @@ def _key(seed, call, shape):
 
 def eps_normals(seed, call, it, m, n_global, p, H, D, cand_lo=0, cand_hi=None):
     """Gaussian-head noise [H, m, n, p, D] for candidates [cand_lo, cand_hi).
-    counter = (global_row, t, d // 2, STREAM_EPS | it << 8); the two Box-Muller
-    outputs of words (0,1) feed dims 2k and 2k+1."""
+    One call yields four words = two Box-Muller pairs = the noise of TWO dim pairs: pairs dp and dp + 4 share the call with
+    counter = (global_row, t, (dp & 3) | (dp >> 3) << 2, STREAM_EPS | it << 8); pair dp takes words (2 s, 2 s + 1), s = (dp >> 2) & 1,
+    whose two Box-Muller outputs feed dims 2 dp and 2 dp + 1 (csrc/rollout_env.h: eps_group / eps_sub)."""
     cand_hi = n_global if cand_hi is None else cand_hi
     n = cand_hi - cand_lo
     mi = np.arange(m)[:, None, None]
@@ -77,10 +78,14 @@ def eps_normals(seed, call, it, m, n_global, p, H, D, cand_lo=0, cand_hi=None):
     ndp = (D + 1) // 2
     out = np.empty((H, m, n, p, 2 * ndp), np.float32)
     for t in range(H):
+        calls = {}
         for dp in range(ndp):
-            ctr = _ctr(row, np.uint32(t), np.uint32(dp), np.uint32(STREAM_EPS | (it << 8)))
-            r = philox4x32_10(ctr, _key(seed, call, row.shape))
-            z0, z1 = box_muller(u01(r[..., 0]), u01(r[..., 1]))
+            group, sub = (dp & 3) | ((dp >> 3) << 2), (dp >> 2) & 1
+            if group not in calls:
+                ctr = _ctr(row, np.uint32(t), np.uint32(group), np.uint32(STREAM_EPS | (it << 8)))
+                calls[group] = philox4x32_10(ctr, _key(seed, call, row.shape))
+            r = calls[group]
+            z0, z1 = box_muller(u01(r[..., 2 * sub]), u01(r[..., 2 * sub + 1]))
             out[t, ..., 2 * dp] = z0
             out[t, ..., 2 * dp + 1] = z1
     return out[..., :D]

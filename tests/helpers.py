@@ -56,3 +56,20 @@ def floor_reliance(a, b, rtol=1e-5):
     bad = np.abs(a - b) > rtol * np.abs(b)
     worst = float((np.abs(b)[bad] / scale).max()) if bad.any() else 0.0
     return int(bad.sum()), int(bad.size), worst
+
+
+def f16_split_saturating(x):
+    """What the rollout kernels feed the matrix pipe for a value x: hi = sat(f16(x)), lo = sat(f16(x - hi)) with f16 overflow saturating
+    at +-65504 (MODE.FP16_OVFL, csrc/rollout_env.h: fp16_saturate_on), returned as hi + lo in fp32: x to 2^-22 inside the f16 range,
+    at most +-131008 beyond it."""
+    x = np.asarray(x, np.float32)
+    big = np.float32(65504.0)
+
+    def sat(v):
+        with np.errstate(over="ignore", invalid="ignore"):
+            h = v.astype(np.float16).astype(np.float32)
+        return np.where(np.isinf(h) & np.isfinite(v), np.sign(v) * big, h).astype(np.float32)
+    hi = sat(x)
+    with np.errstate(invalid="ignore"):
+        lo = sat((x - hi).astype(np.float32))
+    return (hi + lo).astype(np.float32)

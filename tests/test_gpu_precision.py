@@ -9,7 +9,7 @@ import torch
 
 import precision
 from cadm_amd import _lib, synth
-from helpers import assert_close, make_engine, oracle_problem
+from helpers import assert_close, f16_split_saturating, make_engine, oracle_problem
 from oracle import nets as onets
 from oracle import planner as oplanner
 
@@ -133,8 +133,8 @@ def test_precision_wider_envelope(gpu, case):
 
 # ------------------------------------------------------------------------------------------------------------------
 # (iii) edges of the f16 range -- the kernel's DOCUMENTED behaviour (DESIGN.md numerics notes):
-#   * network inputs are clamped to +-65000 and hidden pre-activations to <= 60000 (swish: 60000 / log2 e = 41589; the f16 operands of the matrix pipe
-#     top out at 65504); inside those clamps results keep the 1e-5 bar.  Only diverged rows ever get there;
+#   * network inputs and hidden activations SATURATE in the f16 split: two parts of at most +-65504 each, i.e. +-131008 (swish nets carry log2 e in the
+#     activation: 90807 in the model's units); inside that range results keep the 1e-5 bar.  Only diverged rows ever get there;
 #   * f16-subnormal-range operands (|x| < 6.1e-5) keep an ABSOLUTE accuracy of 2^-35 (3e-11) instead of a relative 2^-22;
 #   * a non-finite or > 65000 weight is refused at cadm_repack; a non-finite observation / action / context value makes
 #     the affected rows' returns NaN (the reference's matmuls do the same), never a finite number.
@@ -166,10 +166,10 @@ def test_inputs_beyond_the_f16_range_are_clamped(gpu):
     big[0, :6, :, 5] = 3.0e6            # normalised input far beyond 65000 (a dim without sin/cos preprocessing)
     big[0, 6:, :, 9] = -7.0e7
     eng = make_engine(prob, p=20, H=1)
-    clamp = lambda x: np.clip(x, np.float32(-65000.0), np.float32(65000.0))
+    clamp = f16_split_saturating        # (two f16 parts of at most +-65504 each: +-131008)
     rows, traj, r_ref, t_ref = _one_step(prob, eng, big, actions, eps, 20, x_transform=clamp)
     assert np.isfinite(traj).all() and np.isfinite(rows).all()
-    assert_close(traj, t_ref, 1e-5, "next obs with inputs clamped at +-65000 vs the fp32 oracle with the same clamp")
+    assert_close(traj, t_ref, 1e-5, "next obs with inputs saturating at +-131008 vs the fp32 oracle with the same saturation")
     _, t_unclamped = oplanner.rollout_indexed(*_oracle_args(prob), actions.astype(np.float32), eps.astype(np.float32), 5, 20, False,
                                               obs_rows=big.astype(np.float32), return_traj=True)
     assert not np.allclose(t_unclamped, t_ref, rtol=1e-3)      # the clamp was really exercised
@@ -186,11 +186,14 @@ def test_activations_beyond_the_f16_range_are_clamped(gpu):
     prob, obs_rows, actions, eps = _problem(seed=32)
     prob["ff"]["hidden_0_weight"] = prob["ff"]["hidden_0_weight"] * 2.0e4        # layer-0 pre-activations of order 1e5
     eng = make_engine(prob, p=20, H=1)
-    # (swish nets: the packed weights carry log2(e), so the clamp at 60000 acts on log2(e) * pre: 41589 in the model's own units)
-    act = lambda x: onets.swish(np.minimum(x, np.float32(60000.0 / 1.4426950408889634)))
+    # (swish nets: the packed weights carry log2(e), so what saturates is log2(e) * swish(pre): 131008 / log2(e) = 90807 in the model's own units)
+    L2E = np.float32(1.4426950408889634)
+    act = lambda x: f16_split_saturating(onets.swish(x) * L2E) / L2E
     rows, traj, r_ref, t_ref = _one_step(prob, eng, obs_rows, actions, eps, 20, hidden_act=act)
     assert np.isfinite(traj).all()
-    assert_close(traj, t_ref, 2e-5, "next obs with pre-activations clamped at 60000 / log2(e) vs the fp32 oracle with the same clamp")
+    # (beyond +-65504 the high part is pinned at the f16 maximum and the low part alone carries the rest: 11 bits, in steps of up to 32 --
+    #  a pre-activation that differs in the 7th digit rounds to another step, so the comparison there is to 1e-3, not 1e-5)
+    assert_close(traj, t_ref, 1e-3, "next obs with activations saturating at 131008 / log2(e) vs the fp32 oracle with the same saturation")
     _, t_plain = oplanner.rollout_indexed(*_oracle_args(prob), actions.astype(np.float32), eps.astype(np.float32), 5, 20, False,
                                           obs_rows=obs_rows.astype(np.float32), return_traj=True)
     assert not np.allclose(t_plain, t_ref, rtol=1e-3)   # the clamp was really exercised

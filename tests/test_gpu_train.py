@@ -149,6 +149,30 @@ def test_chain_kernel_flavours_agree_bitwise(gpu):
                     np.testing.assert_array_equal(end[8][2][n][k], end[fl][2][n][k], err_msg="B=%d flavour %d %s/%s" % (B, fl, n, k))
 
 
+def test_large_batch_path_switches_at_a_documented_batch_size(gpu):
+    """the one-pass context backward of large batches is not bit-identical to the per-net passes, so the batch size at which the
+    step switches to it must not depend on the device's CU count.  The rule is evaluated for 256 CUs (csrc/train.hip: CADM_LARGE_BATCH_CUS):
+    5 members + backward model switch between B = 1840 and B = 1856.  Observed through the result: the launcher's own pick (flavour 0) is
+    bit-identical to the forced joint path (+ 32 + 128) at 1840 and to the forced large-batch path (+ 16 + 64) at 1856 -- and the two forced
+    paths differ from each other at both (else the test would prove nothing)."""
+    prob = synth.make_problem(env="halfcheetah", context=True, E=5, trained_like=True, with_back=True, seed=31)
+    for B, expect in ((1840, 32 + 128), (1856, 16 + 64)):
+        batch = synth.make_train_batch(prob, B=B, seed=6)
+        end = {}
+        for fl in (0, 32 + 128, 16 + 64):
+            eng = _dev_engine(prob, 5)
+            eng._check(eng.lib.cadm_dev_set_train_flavour(eng._ctx, fl), "cadm_dev_set_train_flavour")
+            eng.train_configure(1e-3, WD, CWD, 1.0, 0.5, max_batch=B)
+            dev = _dev_batch(eng, batch, True, True)
+            for _ in range(2):
+                eng.train_step(dev, train=True)
+            end[fl] = {n: {k: v.cpu().numpy() for k, v in eng.nets[n].items()} for n in eng.net_names()}
+            eng.close()
+        same = lambda a, b: all(np.array_equal(end[a][n][k], end[b][n][k]) for n in end[a] for k in end[a][n])
+        assert not same(32 + 128, 16 + 64), "B=%d: the forced paths agree bit for bit -- nothing is being told apart" % B
+        assert same(0, expect), "B=%d: the launcher did not take the %s path" % (B, "joint" if expect == 32 + 128 else "large-batch")
+
+
 def test_adam_steps_match_tf1_semantics_elementwise(gpu):
     """6 real Adam steps (lr 1e-3, beta 0.9 / 0.999, eps 1e-8).  Before every step the oracle is set to the device's state -- weights
     and both moment buffers, read through the developer hook -- takes the fp64 autograd gradient there and applies the TF1 closed

@@ -25,6 +25,8 @@ ENVS = ["halfcheetah", "cripple_halfcheetah", "ant", "slim_humanoid", "pendulum"
 def run(eng, prob, ctx, acts, eps, flavour, **kw):
     if flavour:
         eng.dev_set_rollout("xdl", row_tiles=int(flavour))
+    if os.environ.get("CADM_FUZZ_VERBOSE"):
+        print("   flavour %r eps=%s" % (flavour, "injected" if eps is not None else "device"), flush=True)
     rows, traj = eng.rollout_returns(prob["obs"], ctx, acts, eps=eps, want_traj=True, **kw)
     torch.cuda.synchronize()
     return rows.cpu().numpy(), traj.cpu().numpy()
@@ -56,6 +58,8 @@ def fuzz(seconds=60.0, seed=0, hids=(128, 200, 200, 256, 512), lib_path=None):
             acts = rng.uniform(-1, 1, (m, n, H, A)).astype(np.float32)
         kw = dict(norm_actions=not discrete, it=int(rng.integers(2)))
         out = {}
+        if os.environ.get("CADM_FUZZ_VERBOSE"):      # (a kernel that faults takes the process down: say what is about to run)
+            print("fuzz: %s ctx=%d hid=%d E=%d p=%d m=%d n=%d H=%d det=%d" % (env, context, hid, E, p, m, n, H, det), flush=True)
         for kind in ("f32", "xdl"):
             eng = synth.make_engine(prob, p=p, deterministic=det, lib=_lib.load_dev(lib_path) if lib_path else _lib.load_dev())
             if kind == "f32":
