@@ -40,7 +40,7 @@ import torch  # noqa: E402
 
 F16_MFMA_PEAK_TFLOPS = 2500.0   # /opt/skills/guides/MI355X_MICROARCH.md: dense f16 / bf16 MFMA
 FP32_MFMA_PEAK_TFLOPS = 157.3   # same guide, "Peak FP32 (matrix)": what v_mfma_f32_*_f32 could reach (reported for context only)
-PMC_FILE = "r5_pmc_%s.json"     # profiles/: mean counters per rollout dispatch from separate rocprofv3 --pmc passes of this command
+PMC_FILE = "r6_pmc_%s.json"     # profiles/: mean counters per rollout dispatch from separate rocprofv3 --pmc passes of this command
 
 
 def flops_per_row_step(K0, hid, D, n_hidden):

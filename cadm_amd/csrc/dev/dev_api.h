@@ -21,7 +21,8 @@ int cadm_dev_set_timing_buffer(cadm_ctx* ctx, void* dev_u64_buf);
 /* The launcher's plan for a member of `units` CU shares of row tiles (csrc/xdl_geo.h: xdl_plan_units): count_out[4] = launches
  * (rounds) of {cooperative one tile, cooperative two tiles, wave-tile 4, wave-tile 8}.  Host logic only: no ctx, no device. */
 int cadm_dev_rollout_plan(int units, int two_tile_ok, int wave_tile_ok, int* count_out);
-/* the same with the cost table of one instantiation (xdl_geo.h: xdl_costs(env_kind, hid)); costs_out[4] (optional) receives that table */
+/* the same with the cost table of one instantiation (xdl_geo.h: xdl_costs(env_kind, hid)); costs_out[7] (optional) receives that table:
+ * one-tile, two-tile, wave-tile 4, wave-tile 8 (full round), then a wave-tile-8 round that covers only 5 / 6 / 7 units */
 int cadm_dev_rollout_plan_for(int units, int two_tile_ok, int wave_tile_ok, int env_kind, int hid, int* count_out, float* costs_out);
 /* The sharded planner's refit on a FABRICATED all-gather result (one GPU plays every rank): payload [G][m * n_local + 1] floats -- every
  * rank's candidate means followed by the checksum word of the inputs it was fed (cadm_dev_input_checksum) --, this rank = my_rank; the

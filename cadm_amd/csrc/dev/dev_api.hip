@@ -74,6 +74,7 @@ extern "C" int cadm_dev_rollout_plan_for(int units, int two_tile_ok, int wave_ti
     const XdlCosts c = xdl_costs(env_kind, hid);
     xdl_plan_units(units, two_tile_ok != 0, wave_tile_ok != 0, count, c);
     for (int o = 0; o < 4; ++o) { count_out[o] = count[o]; if (costs_out) costs_out[o] = c.c[o]; }
+    if (costs_out) for (int k = 0; k < 3; ++k) costs_out[4 + k] = c.wt8p[k];      // (a wave-tile-8 round covering 5 / 6 / 7 units)
     return CADM_OK;
 }
 

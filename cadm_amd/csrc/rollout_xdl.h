@@ -124,14 +124,23 @@ struct XC {
 #ifndef CADM_XDL_RES_MT2_LESS
 #define CADM_XDL_RES_MT2_LESS 6     // two row tiles: twice the accumulators, operand registers and rollout state
 #endif
-#ifndef CADM_XDL_RES_FRAGS_X
-#define CADM_XDL_RES_FRAGS_X 14     // waves with two or more hidden tiles (more accumulators / epilogue state live)
+    // waves with two or more hidden tiles (more accumulators / epilogue state live): 14 until round 5.  Round 6 took the f16-range clamps and
+    // the exec-mask regions out of the epilogue and the state phase; what that freed holds one more fragment in every compiled-in geometry
+    // (15: all 240 kernels of the library free of scratch and of AGPR copies, tests/test_isa_hygiene.py) and two more in the reference's
+    // own geometry (halfcheetah, context 10, hidden 200: 16; the same count spills 2-24 registers in four other geometries).  Same-box:
+    // cfg2 153.2 -> 152.2 -> 151.1 us per launch.  Geometries built on demand (jit.py) keep 14: nobody has looked at their code.
+#ifdef CADM_XDL_RES_FRAGS_X
+    static constexpr int RES_X = CADM_XDL_RES_FRAGS_X;
+#elif defined(CADM_JIT_MODULE)
+    static constexpr int RES_X = 14;
+#else
+    static constexpr int RES_X = (ENV_ == CADM_ENV_HALFCHEETAH && C_ == 10 && HID_ == 200) ? 16 : 15;
 #endif
     static constexpr bool ASM_MFMA = CADM_XDL_RES && NCH <= 8;     // asm MFMAs (AGPR-resident operands) vs builtins
     static constexpr int res_frags(int ntw) {      // (wide observations keep two pair slots of rollout state per thread)
         return (!CADM_XDL_RES || NCH > 8) ? 0
-               : MT > 1 ? (ntw >= 2 ? CADM_XDL_RES_FRAGS_X : CADM_XDL_RES_FRAGS) - (NPI > 1 ? 2 : 0) - CADM_XDL_RES_MT2_LESS - (NT >= 15 ? 1 : 0)
-                        : (ntw >= 2 ? CADM_XDL_RES_FRAGS_X : CADM_XDL_RES_FRAGS) - (NPI > 1 ? 2 : 0) - (NT >= 15 ? 2 : 0);
+               : MT > 1 ? (ntw >= 2 ? RES_X : CADM_XDL_RES_FRAGS) - (NPI > 1 ? 2 : 0) - CADM_XDL_RES_MT2_LESS - (NT >= 15 ? 1 : 0)
+                        : (ntw >= 2 ? RES_X : CADM_XDL_RES_FRAGS) - (NPI > 1 ? 2 : 0) - (NT >= 15 ? 2 : 0);
     }
     static constexpr int MAX_NH_LDS = NH_;
     // (a bias tile in D layout repeats each of its 16 values over the tile's 16 data rows: LDS keeps one copy, 64 B per tile)

@@ -101,11 +101,15 @@ __host__ __device__ constexpr int xdl_frag_index(int ntw, int nchl, int ti, int 
 // 51 workgroups per member: 165 / 261 / 600 / 876 us, profiles/r4_s3_flavour_table.txt).  The cheapest cover is a small
 // dynamic programme, f(u) = min over flavours (cost + f(u - cap)); count[o] = launches (rounds) of flavour o.
 // The costs are a property of the INSTANTIATION (env kind -> observation width -> state phase and head; hidden width -> tiles per wave):
-// xdl_costs(env, hid) is a constexpr of the launcher's template arguments, filled from tools/flavour_table.py runs
-//   halfcheetah, HID 200 (profiles/r4_s3_flavour_table.txt):   1 / 1.60 / 3.6 / 5.3
-//   slim humanoid, HID 200 (profiles/r5_*):          1 / 1.74 / 3.8 / 5.5   (45 dims: 6 pair slots per lane, longer state phase)
+// xdl_costs(env, hid) is a constexpr of the launcher's template arguments, filled from tools/flavour_table.py runs (round 6,
+// profiles/r6_flavour_table.txt; us per rollout / the one-tile launch's):
+//   halfcheetah, HID 200:    two tiles 1.59 (260.7 per full round)   wave-tile 4: 3.15-3.2 (517)   wave-tile 8: 5.19 (851.9)
+//   slim humanoid, HID 200:  two tiles 1.62 (304.0)                  wave-tile 4: 3.62   wave-tile 8: 5.5
+// A wave-tile round that is NOT full is cheaper than a full one -- its workgroups run 5, 6 or 7 waves instead of 8 (wt_launch gives a
+// partly filled round the member's whole CU share): wt8p[k - 5] = cost of a round that covers k = 5, 6, 7 units (halfcheetah 735.6 /
+// 741.8 / 794.0 us: 4.48 / 4.52 / 4.84; at 6 units one partial round beats three two-tile launches, 741.8 against 776.9 us).
 // Geometries nobody measured use halfcheetah's.  -DCADM_COST_MT2=.. etc. override every instantiation (tools/build_variant.sh experiments).
-struct XdlCosts { float c[4]; };
+struct XdlCosts { float c[4]; float wt8p[3]; };
 __host__ __device__ constexpr XdlCosts xdl_costs(int env_kind, int hid) {
 #if defined(CADM_COST_MT2) || defined(CADM_COST_WT4) || defined(CADM_COST_WT8)
 #ifndef CADM_COST_MT2
@@ -117,9 +121,10 @@ __host__ __device__ constexpr XdlCosts xdl_costs(int env_kind, int hid) {
 #ifndef CADM_COST_WT8
 #define CADM_COST_WT8 5.3f
 #endif
-    return XdlCosts{{1.0f, CADM_COST_MT2, CADM_COST_WT4, CADM_COST_WT8}};
+    return XdlCosts{{1.0f, CADM_COST_MT2, CADM_COST_WT4, CADM_COST_WT8}, {CADM_COST_WT8, CADM_COST_WT8, CADM_COST_WT8}};
 #else
-    return env_kind == 2 /* CADM_ENV_SLIM_HUMANOID */ ? XdlCosts{{1.0f, 1.74f, 3.8f, 5.5f}} : XdlCosts{{1.0f, 1.6f, 3.6f, 5.3f}};
+    return env_kind == 2 /* CADM_ENV_SLIM_HUMANOID */ ? XdlCosts{{1.0f, 1.62f, 3.62f, 5.5f}, {4.78f, 4.80f, 5.15f}}
+                                                      : XdlCosts{{1.0f, 1.59f, 3.2f, 5.19f}, {4.48f, 4.52f, 4.84f}};
 #endif
 }
 inline void xdl_plan_units(int units, bool mt2_ok, bool wt_ok, int (&count)[4], XdlCosts costs = xdl_costs(0, 200)) {
@@ -138,7 +143,9 @@ inline void xdl_plan_units(int units, bool mt2_ok, bool wt_ok, int (&count)[4], 
         f[v] = 1e30f;
         for (int o = 0; o < 4; ++o) {
             if (!capu[o]) continue;
-            const float c = cost[o] + f[v > capu[o] ? v - capu[o] : 0];
+            // (a wave-tile-8 round that covers only 5, 6 or 7 units -- the LAST launch of a plan takes the ragged rest -- at its own cost)
+            const float co = (o == 3 && v >= 5 && v <= 7) ? costs.wt8p[v - 5] : cost[o];
+            const float c = co + f[v > capu[o] ? v - capu[o] : 0];
             if (c < f[v] - 1e-6f) { f[v] = c; pick[v] = o; }
         }
     }
