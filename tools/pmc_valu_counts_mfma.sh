@@ -3,7 +3,7 @@
 # tools/micro/mfma_k16_rate.hip: three kernels of 160 000 MFMAs per wave and a handful of other VALU instructions.
 set -x
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/r6l
+OUT=$PWD/gpurun_out/pmc_valu
 mkdir -p $OUT
 hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_k16_rate.hip -o /tmp/mfma_k16_rate || exit 1
 cd /tmp
