@@ -543,8 +543,9 @@ def main():
                      "pipe": "v_mfma_f32_16x16x32_f16", "pipe_peak": F16_MFMA_PEAK_TFLOPS,
                      "pipe_executed": s["executed_f16_mfma_tflops"], "pipe_frac": s["executed_f16_mfma_tflops"] / F16_MFMA_PEAK_TFLOPS,
                      "mfma_busy": mfma_busy, "traffic": traffic, "pmc_source": pmc_src, "pmc_note": pmc_note,
-                     "traffic_note": "fabric bytes per launch summed over the 8 XCD L2s: each L2 fetches the packed weight stream once (algorithmic: "
-                                     "once per chip, ~3.4 MB incl. actions and returns); ~0.2 TB/s, not what bounds the kernel",
+                     "traffic_note": "fabric bytes per launch summed over the 8 XCD L2s; algorithmic: the packed weight stream once per chip, ~3.4 MB incl. "
+                                     "actions and returns.  A member's workgroups sit on two or three XCDs (XCD-affine work items since round 6: ~9 MB; with "
+                                     "every member on every XCD it was 28 MB); < 0.1 TB/s, not what bounds the kernel",
                      "fp32_matrix_peak_for_context": FP32_MFMA_PEAK_TFLOPS,
                      "kernel": "rollout_xdl_kernel", "avg_launch_ms": s["kernel_avg_launch_ms"], "launches": s["launches"],
                      "launch_note": "one 'launch' = one rollout of all rows over the horizon, bracketed by hipEvents inside libcadm_hip.so on "

@@ -5,6 +5,21 @@
 
 #include "common.h"
 
+// Work item of a workgroup.  Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8) and every XCD has its own L2: with the
+// plain item = linear id, every member's workgroups sit on all eight XCDs and each L2 fetches every member's weight stream (28 MB of fabric
+// reads per cfg2 launch for 3.4 MB of weights).  XCD x takes the x-th CONTIGUOUS eighth of the member-major item list instead (as the training
+// kernels do, train.hip: xcd_spread_item): an L2 then holds the streams of two or three members.  A bijection on [0, gridDim.x).
+#ifndef CADM_ROLLOUT_XCD_AFFINE
+#define CADM_ROLLOUT_XCD_AFFINE 1
+#endif
+__device__ __forceinline__ int rollout_item() {
+#if CADM_ROLLOUT_XCD_AFFINE
+    const int lin = (int)blockIdx.x, total = (int)gridDim.x, x = lin & 7;
+    return x * (total >> 3) + (x < (total & 7) ? x : (total & 7)) + (lin >> 3);
+#else
+    return (int)blockIdx.x;
+#endif
+}
 #ifdef CADM_PHASE_TIMING
 #define NPH 24
 #define TS_DECL unsigned long long ts_acc[NPH] = {}; unsigned long long ts_last = __builtin_amdgcn_s_memtime(); unsigned long long* ts_tr = nullptr;

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, fg = lane >> 4;                     // row of the tile, lane group (units 4 fg .. 4 fg + 3 of a D tile)
-    const int e = blockIdx.x / a.wgs_per_member, grp = blockIdx.x % a.wgs_per_member;
+    const int item = rollout_item();
+    const int e = item / a.wgs_per_member, grp = item % a.wgs_per_member;
     const int H = a.H;
     const int wbytes = W::wave_bytes(H);
     unsigned char* xw = sm + W::WAVE0 + wave * wbytes;           // this wave's x_in image: [2 parts][NC0][64 lanes] x 16 B

@@ -560,8 +560,9 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int e = blockIdx.x / a.wgs_per_member;
-    const int grp = blockIdx.x % a.wgs_per_member;
+    const int item = rollout_item();
+    const int e = item / a.wgs_per_member;
+    const int grp = item % a.wgs_per_member;
     const int H = a.H;
     const int arow = tid & 15, fg = (tid >> 4) & 15;
     // feature threads (rollout state, input assembly): MT = 1: waves 0-3, their twins in waves 4-7 make the noise;
@@ -596,7 +597,7 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     }
     for (int i = tid; i < (G::OFULL - G::XIN) / 16; i += G::NTHR) reinterpret_cast<uintx4*>(xsmem + G::XIN)[i] = uintx4{0u, 0u, 0u, 0u};
     if (bias_lds) {
-        const uintx4* src = reinterpret_cast<const uintx4*>(a.xb + (size_t)(blockIdx.x / a.wgs_per_member) * a.xb_member);
+        const uintx4* src = reinterpret_cast<const uintx4*>(a.xb + (size_t)e * a.xb_member);
         // one float4 per (tile, lane group): the copy of data row 0
         for (int i = tid; i < (XNH * G::NT + NTO) * 4; i += G::NTHR) reinterpret_cast<uintx4*>(xsmem + bias_off)[i] = src[(i >> 2) * 64 + (i & 3) * 16];
     }
