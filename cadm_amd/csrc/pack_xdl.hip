@@ -35,9 +35,13 @@ __global__ void pack_xdl_kernel(const XdlPackArgs a) {
         const int ntw = g.ntw(w);
         // which layer
         int layer, nchl;
-        if (fj < ntw * g.NC0) { layer = 0; nchl = g.NC0; }
+        const int nc0s = g.NC0 - g.INV;       // layer-0 chunks in the per-step part of the stream (xdl_geo.h: invariant last chunk)
+        const int inv0 = ntw * nc0s + (g.NH - 1) * ntw * g.NCH + g.nhead(w) * g.NCH;      // first fragment of the invariant chunk's block (INV)
+        bool invf = false;
+        if (g.INV && fj >= inv0) { invf = true; layer = 0; nchl = 1; fj -= inv0; }
+        else if (fj < ntw * nc0s) { layer = 0; nchl = nc0s; }
         else {
-            fj -= ntw * g.NC0;
+            fj -= ntw * nc0s;
             layer = 1 + fj / (ntw * g.NCH);
             nchl = g.NCH;
             if (layer < g.NH) fj -= (layer - 1) * ntw * g.NCH;
@@ -45,7 +49,8 @@ __global__ void pack_xdl_kernel(const XdlPackArgs a) {
         }
         const int grp = lane >> 4, m = lane & 15;
         int tile, c;
-        if (layer < g.NH) {                   // hidden-type outputs: tiles in groups of xdl_group(w), chunk-major inside a group
+        if (invf) { tile = g.tstart(w) + fj; c = g.NC0 - 1; }      // the invariant chunk: one fragment per tile, in tile order
+        else if (layer < g.NH) {              // hidden-type outputs: tiles in groups of xdl_group(w), chunk-major inside a group
             const int gsz = xdl_group(w);
             const int gi = fj / (gsz * nchl), jj = fj - gsz * gi * nchl;
             const int gs = (ntw - gsz * gi) < gsz ? (ntw - gsz * gi) : gsz;

@@ -126,7 +126,9 @@ __device__ __forceinline__ const unsigned char* wt_block_boundary(WTRing& rg, un
 
 // accumulate GS tiles over NCHL chunks from the block at `slot`: hi += w1 x1 + w1 x2, lo += w2 x1 per chunk, in the cooperative
 // kernel's order per accumulator.  HEAD: the block stores its fragments tile-major (xdl_geo.h), else chunk-major.
-template <int GS, int NCHL, bool HEAD, int DBUF, int NX>
+// LASTFIRST: the chunks are taken in the order NCHL-1, 0, 1, .. (layer 0 of a geometry whose last chunk holds only context features: every
+// flavour accumulates that chunk first, xdl_geo.h "invariant last chunk" -- the cooperative kernel runs it once per row tile).
+template <int GS, int NCHL, bool HEAD, int DBUF, bool LASTFIRST = false, int NX>
 __device__ __forceinline__ void wt_accumulate(const unsigned char* slot, int lane, const f16x8 (&X1)[NX], const f16x8 (&X2)[NX],
                                               floatx4 (&hi)[2], floatx4 (&lo)[2]) {
     // the fragments of chunk c + 1 are requested before chunk c's MFMAs (two register sets): a wave alone on its SIMD otherwise
@@ -138,13 +140,14 @@ __device__ __forceinline__ void wt_accumulate(const unsigned char* slot, int lan
 #pragma unroll
         for (int k = 0; k < GS; ++k) { w[q][k][0] = uintx4{1u, 2u, 3u, 4u}; w[q][k][1] = uintx4{1u, 2u, 3u, 4u}; }
 #endif
-    auto wload = [&](auto cc) {
+    auto wload = [&](auto cc) {      // the cc-th chunk in processing order
         constexpr int c = decltype(cc)::value;
+        constexpr int co = LASTFIRST ? (c == 0 ? NCHL - 1 : c - 1) : c;
 #pragma unroll
         for (int k = 0; k < GS; ++k)
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
-                const int fi = HEAD ? k * NCHL + c : c * GS + k;
+                const int fi = HEAD ? k * NCHL + co : co * GS + k;
 #ifndef CADM_WT_EXPERIMENT_NOFRAG
                 w[c % DBUF][k][part] = *reinterpret_cast<const uintx4*>(slot + (fi * 2 + part) * 1024 + lane * 16);
 #else
@@ -155,17 +158,18 @@ __device__ __forceinline__ void wt_accumulate(const unsigned char* slot, int lan
     static_for(std::make_integer_sequence<int, (DBUF - 1 < NCHL ? DBUF - 1 : NCHL)>{}, [&](auto cc) { wload(cc); });
     static_for(std::make_integer_sequence<int, NCHL>{}, [&](auto cc) {
         constexpr int c = decltype(cc)::value;
+        constexpr int co = LASTFIRST ? (c == 0 ? NCHL - 1 : c - 1) : c;      // the chunk whose operands these MFMAs read
         if constexpr (c + DBUF - 1 < NCHL) wload(std::integral_constant<int, c + DBUF - 1>{});
 #ifdef CADM_WT_EXPERIMENT_NOMFMA
 #pragma unroll
-        for (int k = 0; k < GS; ++k) asm volatile("" : "+v"(hi[k]), "+v"(lo[k]) : "v"(w[c % DBUF][k][0]), "v"(w[c % DBUF][k][1]), "v"(X1[c]), "v"(X2[c]));
+        for (int k = 0; k < GS; ++k) asm volatile("" : "+v"(hi[k]), "+v"(lo[k]) : "v"(w[c % DBUF][k][0]), "v"(w[c % DBUF][k][1]), "v"(X1[co]), "v"(X2[co]));
 #else
 #pragma unroll
-        for (int k = 0; k < GS; ++k) hi[k] = xmfma(w[c % DBUF][k][0], X1[c], hi[k]);
+        for (int k = 0; k < GS; ++k) hi[k] = xmfma(w[c % DBUF][k][0], X1[co], hi[k]);
 #pragma unroll
-        for (int k = 0; k < GS; ++k) lo[k] = xmfma(w[c % DBUF][k][1], X1[c], lo[k]);
+        for (int k = 0; k < GS; ++k) lo[k] = xmfma(w[c % DBUF][k][1], X1[co], lo[k]);
 #pragma unroll
-        for (int k = 0; k < GS; ++k) hi[k] = xmfma(w[c % DBUF][k][0], X2[c], hi[k]);
+        for (int k = 0; k < GS; ++k) hi[k] = xmfma(w[c % DBUF][k][0], X2[co], hi[k]);
 #endif
         if constexpr (DBUF > 1) __builtin_amdgcn_sched_barrier(0);      // pin the pipeline: no load sinking / hoisting across chunks
     });
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
             f16x8 Y1[NCH], Y2[NCH];
             // One block: barrier, transport of the NEXT block (NFN fragments), GS tiles accumulated over NCHL chunks of XA / XB from the
             // current slot, epilogue.
-            auto run_block = [&](auto nfn_c, auto gs_c, auto nchl_c, auto head_c, const f16x8 (&XA)[NCH], const f16x8 (&XB)[NCH], int bias_tile,
+            auto run_block = [&](auto nfn_c, auto gs_c, auto nchl_c, auto head_c, auto lf_c, const f16x8 (&XA)[NCH], const f16x8 (&XB)[NCH], int bias_tile,
                                  auto&& epilogue) __attribute__((always_inline)) {
                 constexpr int NFN = decltype(nfn_c)::value, GS = decltype(gs_c)::value, NCHL = decltype(nchl_c)::value;
                 constexpr bool HEAD = decltype(head_c)::value;
@@ -443,14 +447,14 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
                         hi[k] = *reinterpret_cast<const floatx4*>(sm + W::BIAS + (bias_tile + k) * 64 + fg * 16);
                         lo[k] = floatx4{0.f, 0.f, 0.f, 0.f};
                     }
-                    wt_accumulate<GS, NCHL, HEAD, W::DBUF>(slot, lane, XA, XB, hi, lo);
+                    wt_accumulate<GS, NCHL, HEAD, W::DBUF, decltype(lf_c)::value>(slot, lane, XA, XB, hi, lo);
                     epilogue(hi, lo);
                 }
             };
             using TrueT = std::integral_constant<bool, true>;
             using FalseT = std::integral_constant<bool, false>;
             // one hidden-type layer: NCHL input chunks in X, all NT output tiles into Y, pair by pair
-            auto hidden_layer = [&](auto nchl_c, int layer, const f16x8 (&IN1)[NCH], const f16x8 (&IN2)[NCH], f16x8 (&OUT1)[NCH], f16x8 (&OUT2)[NCH]) __attribute__((always_inline)) {
+            auto hidden_layer = [&](auto nchl_c, auto lf_c, int layer, const f16x8 (&IN1)[NCH], const f16x8 (&IN2)[NCH], f16x8 (&OUT1)[NCH], f16x8 (&OUT2)[NCH]) __attribute__((always_inline)) {
                 constexpr int NCHL = decltype(nchl_c)::value;
                 static_for(std::make_integer_sequence<int, W::NG>{}, [&](auto gc) {
                     constexpr int g = decltype(gc)::value, GS = W::gs_hidden(g);
@@ -472,20 +476,20 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
                     // the block behind this one: the layer's next pair; behind a layer's last pair the next layer's first (the head's
                     // first behind the last hidden layer's)
                     if constexpr (g + 1 < W::NG)
-                        run_block(std::integral_constant<int, W::gs_hidden(g + 1 < W::NG ? g + 1 : 0) * NCHL>{}, GSc{}, nchl_c, FalseT{}, IN1, IN2, bt, epilogue);
-                    else if (layer + 1 < XNH) run_block(std::integral_constant<int, W::gs_hidden(0) * NCH>{}, GSc{}, nchl_c, FalseT{}, IN1, IN2, bt, epilogue);
-                    else run_block(std::integral_constant<int, W::gs_head(0) * NCH>{}, GSc{}, nchl_c, FalseT{}, IN1, IN2, bt, epilogue);
+                        run_block(std::integral_constant<int, W::gs_hidden(g + 1 < W::NG ? g + 1 : 0) * NCHL>{}, GSc{}, nchl_c, FalseT{}, lf_c, IN1, IN2, bt, epilogue);
+                    else if (layer + 1 < XNH) run_block(std::integral_constant<int, W::gs_hidden(0) * NCH>{}, GSc{}, nchl_c, FalseT{}, lf_c, IN1, IN2, bt, epilogue);
+                    else run_block(std::integral_constant<int, W::gs_head(0) * NCH>{}, GSc{}, nchl_c, FalseT{}, lf_c, IN1, IN2, bt, epilogue);
                 });
             };
             // layer 0
-            hidden_layer(std::integral_constant<int, NC0>{}, 0, X1, X2, Y1, Y2);
+            hidden_layer(std::integral_constant<int, NC0>{}, std::integral_constant<bool, G::INV>{}, 0, X1, X2, Y1, Y2);      // (G::INV: the invariant last chunk first, xdl_geo.h)
             // hidden layers 1 .. NH-1, unrolled: the two activation register sets swap roles from layer to layer (a rolled loop had to move
             // 2 x NCH x 4 registers per layer: -2.7 % of a full round, profiles/r4_wave_tile.md; nets deeper than 5 layers stay on the
             // cooperative kernel, WT::AVAILABLE)
             static_for(std::make_integer_sequence<int, XNH - 1>{}, [&](auto lc) {
                 constexpr int l = decltype(lc)::value + 1;
-                if constexpr (l & 1) hidden_layer(std::integral_constant<int, NCH>{}, l, Y1, Y2, X1, X2);
-                else hidden_layer(std::integral_constant<int, NCH>{}, l, X1, X2, Y1, Y2);
+                if constexpr (l & 1) hidden_layer(std::integral_constant<int, NCH>{}, FalseT{}, l, Y1, Y2, X1, X2);
+                else hidden_layer(std::integral_constant<int, NCH>{}, FalseT{}, l, X1, X2, Y1, Y2);
             });
             f16x8 (&H1)[NCH] = ((XNH - 1) & 1) ? X1 : Y1;      // the last hidden layer's output: the head's input
             f16x8 (&H2)[NCH] = ((XNH - 1) & 1) ? X2 : Y2;
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(WT<G>::NTHR) void rollout_wt_kernel(const RolloutAr
 #pragma unroll
                         for (int qq = 0; qq < 4; ++qq) hv[2 * g + k][qq] = fmaf(lo[k][qq], 4.8828125e-4f, hi[k][qq]);
                 };
-                run_block(std::integral_constant<int, W::block_frags(q + 1)>{}, std::integral_constant<int, GS>{}, std::integral_constant<int, NCH>{}, TrueT{},
+                run_block(std::integral_constant<int, W::block_frags(q + 1)>{}, std::integral_constant<int, GS>{}, std::integral_constant<int, NCH>{}, TrueT{}, FalseT{},
                           H1, H2, XNH * NT + 2 * g, epilogue);
             });
         }

@@ -69,6 +69,9 @@ struct XC {
 #endif
     static constexpr bool SPARE = CADM_XDL_SPARE && (K0 % 32) != 0;
     static constexpr int NT = (HID + 15) / 16;            // hidden tiles
+    // invariant last chunk of layer 0 (xdl_geo.h): accumulated FIRST by every flavour, once per row tile by this kernel (NC0S chunks per step)
+    static constexpr bool INV = xdl_inv0(K0, P + A, HID);
+    static constexpr int NC0S = NC0 - (INV ? 1 : 0);
     static constexpr int NCH = (NT + 1) / 2;              // chunks of a layer that consumes a hidden layer
     static constexpr int NTO = (D + 7) / 8;               // head tiles (8 dims: mu | lv)
     static constexpr int NW = CADM_XDL_WAVES, NTHR = NW * 64;
@@ -134,7 +137,7 @@ struct XC {
 #elif defined(CADM_JIT_MODULE)
     static constexpr int RES_X = 14;
 #else
-    static constexpr int RES_X = (ENV_ == CADM_ENV_HALFCHEETAH && C_ == 10 && HID_ == 200) ? 16 : 15;
+    static constexpr int RES_X = (INV && NPI > 1) ? 14 : 15;      // (the reference's own geometry held 16 until the invariant-chunk prologue took the registers' last slack; wide observations with it: one less)
 #endif
     static constexpr bool ASM_MFMA = CADM_XDL_RES && NCH <= 8;     // asm MFMAs (AGPR-resident operands) vs builtins
     static constexpr int res_frags(int ntw) {      // (wide observations keep two pair slots of rollout state per thread)
@@ -165,11 +168,12 @@ struct XC {
 #define CADM_XDL_LQ_MAX 2       // (a third slot measured +-0: the stream is no longer what the layer waits for)
 #endif
     static constexpr int NEL = BASE >= 2 ? NW : EXTRA;                 // waves with >= 2 tiles (waves 0 .. NEL-1)
-    static constexpr int LQ_FREE = 160 * 1024 - (CTRL + rup(MT * 16 * 128 * 4, 16) + (BIAS_LDS ? BIAS_BYTES : 0));
+    static constexpr int INV_BYTES = INV ? MT * NT * CADM_XDL_FRAG_BYTES : 0;      // (HI, LO) of "bias + invariant chunk" per (row tile, tile): 64 lanes x 16 B each
+    static constexpr int LQ_FREE = 160 * 1024 - (CTRL + rup(MT * 16 * 128 * 4, 16) + (BIAS_LDS ? BIAS_BYTES : 0)) - INV_BYTES;
     static constexpr int LQ_SLOTS = (MT > 1 || NEL == 0 || !ASM_MFMA || LQ_FREE <= 0) ? 0 : cmin(CADM_XDL_LQ_MAX, LQ_FREE / (NEL * 3 * CADM_XDL_FRAG_BYTES));
     static constexpr int LQ_BYTES = NEL * 3 * LQ_SLOTS * CADM_XDL_FRAG_BYTES;
     static size_t lds_bytes(int H) {                       // dynamic LDS of a launch
-        return (size_t)CTRL + (size_t)rup(MT * 16 * H * 4, 16) + (BIAS_LDS ? (size_t)BIAS_BYTES : 0) + LQ_BYTES;
+        return (size_t)CTRL + (size_t)rup(MT * 16 * H * 4, 16) + (BIAS_LDS ? (size_t)BIAS_BYTES : 0) + LQ_BYTES + INV_BYTES;
     }
 };
 
@@ -280,12 +284,18 @@ struct XHiddenEpi {
     const float* xb;
     int bias_off;
     int layer, out, tstart, lane;
-    __device__ __forceinline__ floatx4 init(int ti) const {       // bias tile (fp32, D layout) of local tile ti
+    const unsigned char* inv = nullptr;      // layer 0 of a geometry with an invariant last chunk (xdl_geo.h): (HI, LO) of "bias + that chunk" per (row tile, tile)
+    __device__ __forceinline__ floatx4 init(int ti, int hh) const {       // accumulator HI: bias tile (fp32, D layout) of local tile ti, or the tile's invariant start
+        if (inv) return *reinterpret_cast<const floatx4*>(inv + ((hh * G::NT + tstart + ti) * 2 + 0) * 1024 + lane * 16);
         const int tile = layer * G::NT + tstart + ti;
         const int bt = tile * 64 + lane;
         // (a select between an LDS and a global POINTER would become a flat load with a full vmcnt/lgkmcnt drain)
         if constexpr (G::BIAS_LDS) return *reinterpret_cast<const floatx4*>(xsmem + bias_off + tile * G::BIAS_TILE_B + (lane >> 4) * 16);
         else return *reinterpret_cast<const floatx4*>(xb + bt * 4);
+    }
+    __device__ __forceinline__ floatx4 init_lo(int ti, int hh) const {    // accumulator LO: zero, or the tile's invariant start
+        if (inv) return *reinterpret_cast<const floatx4*>(inv + ((hh * G::NT + tstart + ti) * 2 + 1) * 1024 + lane * 16);
+        return floatx4{0.f, 0.f, 0.f, 0.f};
     }
     static __device__ __forceinline__ floatx2 lo2(const floatx4& x) { return __builtin_shufflevector(x, x, 0, 1); }
     static __device__ __forceinline__ floatx2 hi2(const floatx4& x) { return __builtin_shufflevector(x, x, 2, 3); }
@@ -413,7 +423,8 @@ struct XHeadEpi {
     unsigned char* xsmem;
     const float* xb;
     int bias_off, bias_tile, ht, lane;
-    __device__ __forceinline__ floatx4 init(int) const {
+    __device__ __forceinline__ floatx4 init_lo(int, int) const { return floatx4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ floatx4 init(int, int) const {
         const int bt = bias_tile * 64 + lane;
         if constexpr (G::BIAS_LDS) return *reinterpret_cast<const floatx4*>(xsmem + bias_off + bias_tile * G::BIAS_TILE_B + (lane >> 4) * 16);
         else return *reinterpret_cast<const floatx4*>(xb + bt * 4);
@@ -439,7 +450,7 @@ struct XHeadEpi {
 //   VALU work of the same wave); the last group's epilogue overlaps with the SIMD's other wave.
 //   NLDS: the LAST NLDS fragments of the layer (consumption order) are LDS-resident (lq: this wave's copy, made once per workgroup):
 //   they go through the ring like streamed ones, from LDS instead of L2.  The first R ring fragments stay streamed.
-template <class G, int NTW, int NCHL, int NRES, int GS, bool SIDE, int NLDS, class Epi>
+template <class G, int NTW, int NCHL, int NRES, int GS, bool SIDE, int NLDS, int NCB = NCHL, class Epi>
 __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2], __amdgpu_buffer_rsrc_t rsrc, unsigned wcur,
                                           unsigned wnext, int nx_nf, const unsigned char* lds_in, int lane, const Epi& epi,
                                           const unsigned char* lq TS_PARAMS) {
@@ -448,14 +459,14 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
     static_assert(NLDS == 0 || NFS - NLDS >= R, "the first R ring fragments of a layer are streamed");
     constexpr int MT = G::MT, XDW = (NTW == 1 && GS == 1 && !SIDE) ? G::XDEPTH1 : G::XDEPTH,      // (the head sweep)
                    XD = NCHL < XDW ? NCHL : XDW;
-    constexpr int IN_T = 2 * NCHL * 1024;                  // bytes of one row tile's operand block
+    constexpr int IN_T = 2 * NCB * 1024;                   // bytes of one row tile's operand block (NCB chunks per split part, the first NCHL of them swept)
     f16x8 X1[XD][MT], X2[XD][MT];
     auto xload = [&](auto cc) {
         constexpr int c = decltype(cc)::value;
 #pragma unroll
         for (int h = 0; h < MT; ++h) {
-            X1[c % XD][h] = *reinterpret_cast<const f16x8*>(lds_in + h * IN_T + ((0 * NCHL + c) * 64 + lane) * 16);
-            X2[c % XD][h] = *reinterpret_cast<const f16x8*>(lds_in + h * IN_T + ((1 * NCHL + c) * 64 + lane) * 16);
+            X1[c % XD][h] = *reinterpret_cast<const f16x8*>(lds_in + h * IN_T + ((0 * NCB + c) * 64 + lane) * 16);
+            X2[c % XD][h] = *reinterpret_cast<const f16x8*>(lds_in + h * IN_T + ((1 * NCB + c) * 64 + lane) * 16);
         }
     };
     auto prefetch = [&](auto jsc) {      // after streamed time slot js: refill its ring slot
@@ -489,7 +500,7 @@ __device__ __forceinline__ void xdl_sweep(XRing<G>& ring, const uintx4 (*res)[2]
         for (int k = 0; k < gs; ++k)
 #pragma unroll
             for (int h = 0; h < MT; ++h) {
-                hi[gp][k][h] = epi.init(GS * g + k); lo[gp][k][h] = floatx4{0.f, 0.f, 0.f, 0.f}; ll[gp][k][h] = floatx4{0.f, 0.f, 0.f, 0.f};
+                hi[gp][k][h] = epi.init(GS * g + k, h); lo[gp][k][h] = epi.init_lo(GS * g + k, h); ll[gp][k][h] = floatx4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
         for (int k = 0; k < gs; ++k)
@@ -683,9 +694,11 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
     const int tstart = wave * G::BASE + (wave < G::EXTRA ? wave : G::EXTRA);
     const int ht = G::NW - 1 - wave;                       // this wave's head tile (if < NTO)
     const int nhead = ht < NTO ? 1 : 0;
-    const int l0_nf = my_ntw * NC0, lh_nf = my_ntw * NCH, hd_nf = nhead * NCH;
+    const int l0_nf = my_ntw * G::NC0S, lh_nf = my_ntw * NCH, hd_nf = nhead * NCH;      // (NC0S: without layer 0's invariant chunk, xdl_geo.h)
     const unsigned w_l0 = wbase, w_h1 = w_l0 + l0_nf * CADM_XDL_FRAG_BYTES;
     const unsigned w_hd = w_h1 + (XNH - 1) * lh_nf * CADM_XDL_FRAG_BYTES;
+    const unsigned w_inv = w_hd + hd_nf * CADM_XDL_FRAG_BYTES;      // the invariant chunk's fragments, one per tile (G::INV)
+    const int inv_off = bias_off + (G::BIAS_LDS ? G::BIAS_BYTES : 0) + G::LQ_BYTES;      // LDS: (HI, LO) of "bias + invariant chunk" per (row tile, tile)
 
     // layer ids: 0 = layer 0, 1 .. NH-1 = hidden, NH = head.
     // Register-resident fragments (never re-read from L2): the whole head tile on the waves that have one and registers to
@@ -841,6 +854,33 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
             }
         };
         __syncthreads();
+        if constexpr (G::INV) {
+            // Layer 0's invariant last chunk (xdl_geo.h): context features only, the same in every step.  Every flavour accumulates it FIRST;
+            // this kernel does so here, once per row tile -- bias -> HI += w1 x1, LO += w2 x1, HI += w1 x2, the instructions a sweep would issue --
+            // and leaves (HI, LO) per tile in LDS: the step loop's layer-0 accumulators start from them.  A wave reads back only its own tiles.
+            floatx4 ll0 = floatx4{0.f, 0.f, 0.f, 0.f};
+            const XHiddenEpi<G> epib{xsmem, xb, bias_off, 0, 0, tstart, lane};
+            static_for(std::make_integer_sequence<int, NTW>{}, [&](auto tc) {
+                constexpr int ti = decltype(tc)::value;
+                const uintx4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16, w_inv + ti * CADM_XDL_FRAG_BYTES, 0);
+                const uintx4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16 + 1024, w_inv + ti * CADM_XDL_FRAG_BYTES, 0);
+#pragma unroll
+                for (int h = 0; h < MT; ++h) {
+                    const unsigned char* xin = xsmem + G::XIN + h * G::XIN_T;
+                    const f16x8 x1 = *reinterpret_cast<const f16x8*>(xin + ((0 * NC0 + NC0 - 1) * 64 + lane) * 16);
+                    const f16x8 x2 = *reinterpret_cast<const f16x8*>(xin + ((1 * NC0 + NC0 - 1) * 64 + lane) * 16);
+                    floatx4 hi = epib.init(ti, h), lo = floatx4{0.f, 0.f, 0.f, 0.f};
+                    xdl_operand_nops<false>(hi, lo, ll0);
+                    xmfma_ring<G::ASM_MFMA>(hi, w0, x1);
+                    xmfma_ring<G::ASM_MFMA>(lo, w1, x1);
+                    xmfma_ring<G::ASM_MFMA>(hi, w0, x2);
+                    xdl_result_nops<false>(hi, lo, ll0);
+                    unsigned char* dst = xsmem + inv_off + ((h * G::NT + tstart + ti) * 2) * 1024 + lane * 16;
+                    *reinterpret_cast<floatx4*>(dst) = hi;
+                    *reinterpret_cast<floatx4*>(dst + 1024) = lo;
+                }
+            });
+        }
         TS_DECL
 
         for (int t = 0; t <= H; ++t) {
@@ -991,8 +1031,10 @@ __device__ __forceinline__ void xdl_run(const RolloutArgs& a, unsigned char* xsm
                 // layer 0
                 {
                     const int nx = next_streamed(0);
-                    xdl_sweep<G, NTW, NC0, 0, GSZ, !SEQ, 0>(ring, nullptr, rsrc, w_l0, lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
-                                              hidden_epi(0, act_out), nullptr TS_ARGS);
+                    XHiddenEpi<G> epi0 = hidden_epi(0, act_out);
+                    if constexpr (G::INV) epi0.inv = xsmem + inv_off;      // accumulators start from "bias + invariant chunk" (made once per row tile, below the tile prologue)
+                    xdl_sweep<G, NTW, G::NC0S, 0, GSZ, !SEQ, 0, NC0>(ring, nullptr, rsrc, w_l0, lay_off(nx), lay_nf(nx), xsmem + act_in, lane,
+                                              epi0, nullptr TS_ARGS);
                 }
                 TS(2)
                 XDL_LAYER_SYNC();

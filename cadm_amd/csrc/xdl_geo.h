@@ -45,8 +45,24 @@
 #define CADM_XDL_NARROW_HID 128
 __host__ __device__ constexpr int xdl_kernel_hid(int hid) { return hid < CADM_XDL_MIN_HID ? CADM_XDL_NARROW_HID : hid; }
 
+// INVARIANT LAST CHUNK OF LAYER 0 (round 6).  Layer 0's inputs are [obs features | action | context]; the context vector does not change
+// over a rollout, so a layer-0 chunk that holds ONLY context features (halfcheetah CaDM: K0 = 18 + 6 + 10 = 34, chunk 1 = context features
+// 8 and 9; slim humanoid: chunk 2 of 3) contributes the same products in all H steps.  Where that holds (xdl_inv0) EVERY flavour accumulates
+// that chunk FIRST -- (bias + chunk NC0-1) + chunk 0 + .. -- and the cooperative kernel runs it ONCE per row tile: the tile prologue leaves
+// (HI, LO) of "bias + last chunk" in LDS per tile, the step loop starts its layer-0 accumulators from them and sweeps NC0 - 1 chunks.  The same
+// instructions on the same operands in the same order as a flavour that runs the chunk in every step (the wave-tile kernel): bit-identical.
+// Stream of the cooperative kernels: layer 0 holds NC0 - 1 chunks per tile; the invariant chunk's fragments (one per tile) follow the head's.
+// A timing build on a vanilla model (K0 = 24: one chunk): cfg2 152.8 -> 144.9 us per rollout (tools/ctx_fold_bound.py).
+#ifndef CADM_XDL_INV0
+#define CADM_XDL_INV0 1
+#endif
+__host__ __device__ constexpr bool xdl_inv0(int k0, int kdyn, int hid_kernel) {      // kdyn = P + A: the inputs that change from step to step
+    return CADM_XDL_INV0 && k0 > kdyn && (k0 + 31) / 32 >= 2 && ((k0 + 31) / 32 - 1) * 32 >= kdyn && (hid_kernel + 15) / 16 <= 13;
+}
+
 struct XdlGeo {
     int K0, HID, D, NH, HIDR;
+    int INV;     // 1: the cooperative kernels' stream keeps layer 0's invariant chunk apart (above); the wave-tile stream (NW = 1) never does
     int NC0, NT, NCH, NTO, BASE, EXTRA, NTOW;
     int NW;      // waves the tiles are dealt to: CADM_XDL_WAVES (cooperative kernel), 1 (wave-tile kernel, rollout_wt.h: every wave owns ALL tiles)
     __host__ __device__ int ntw(int w) const { return BASE + (w < EXTRA ? 1 : 0); }
@@ -57,7 +73,7 @@ struct XdlGeo {
         for (int s = 0; s < NTOW; ++s) n += head_tile(w, s) < NTO ? 1 : 0;
         return n;
     }
-    __host__ __device__ int wave_frags(int w) const { return ntw(w) * NC0 + (NH - 1) * ntw(w) * NCH + nhead(w) * NCH; }
+    __host__ __device__ int wave_frags(int w) const { return ntw(w) * NC0 + (NH - 1) * ntw(w) * NCH + nhead(w) * NCH; }      // (INV: NC0 - 1 chunks in front, 1 behind the head)
     __host__ __device__ int member_frags() const {
         int n = 0;
         for (int w = 0; w < NW; ++w) n += wave_frags(w);
@@ -66,9 +82,10 @@ struct XdlGeo {
     __host__ __device__ int bias_tiles() const { return NH * NT + NTO; }
 };
 
-inline XdlGeo make_xdl_geo(int K0, int hid_model, int D, int NH, int nw = CADM_XDL_WAVES) {
+inline XdlGeo make_xdl_geo(int K0, int hid_model, int D, int NH, int nw = CADM_XDL_WAVES, int kdyn = -1) {
     XdlGeo g;
     g.NW = nw;
+    g.INV = (nw == CADM_XDL_WAVES && kdyn >= 0 && xdl_inv0(K0, kdyn, xdl_kernel_hid(hid_model))) ? 1 : 0;
     const int HID = xdl_kernel_hid(hid_model);
     g.K0 = K0; g.HID = HID; g.HIDR = hid_model; g.D = D; g.NH = NH;
     g.NC0 = (K0 + 31) / 32;
